@@ -1,0 +1,498 @@
+!=======================================================================
+! TEST INFRASTRUCTURE ONLY.  C-ABI capture wrapper around the COMPILED
+! REFERENCE (COSIMA/cice4 Fortran modules built by oracle/build_ref.sh from
+! /root/reference).  It lets tests/ and bench.py's cpu_baseline leg call the
+! reference's own public procedures on arbitrary inputs through ctypes:
+!   stress, stepu, evp_prep1/2, evp_finish, evp         (source/ice_dyn_evp.F90)
+!   ice_strength                                         (source/ice_mechred.F90)
+!   thermo_vertical, frzmlt_bottom_lateral               (source/ice_therm_vertical.F90)
+!   ice_HaloUpdate, to_ugrid                             (serial/ice_boundary.F90, ice_grid.F90)
+! This file is our own code; it contains no reference source.  It is never
+! linked into the product library.
+!=======================================================================
+module ref_capi
+   use iso_c_binding
+   use ice_kinds_mod
+   use ice_constants
+   use ice_domain_size
+   implicit none
+   logical, save :: booted = .false.
+   logical, save :: domain_ready = .false.
+contains
+
+   subroutine cstr(c, f)
+      character(kind=c_char), intent(in) :: c(*)
+      character(len=*), intent(out) :: f
+      integer :: i
+      f = ' '
+      do i = 1, len(f)
+         if (c(i) == c_null_char) exit
+         f(i:i) = c(i)
+      enddo
+   end subroutine cstr
+
+   subroutine ref_boot() bind(C, name='ref_boot')
+      use ice_communicate, only: init_communicate
+      use ice_fileunits, only: init_fileunits
+      use ice_state, only: nt_Tsfc, nt_iage, ntrcr
+      use ice_age, only: tr_iage
+      if (booted) return
+      call init_communicate
+      call init_fileunits
+      nt_Tsfc = 1
+      nt_iage = 2
+      ntrcr   = 2
+      tr_iage = .true.
+      booted = .true.
+   end subroutine ref_boot
+
+   subroutine ref_dims(d) bind(C, name='ref_dims')
+      use ice_blocks, only: nx_block, ny_block
+      integer(c_int), intent(out) :: d(10)
+      d(1) = nx_block; d(2) = ny_block; d(3) = max_blocks
+      d(4) = nx_global; d(5) = ny_global
+      d(6) = ncat; d(7) = nilyr; d(8) = nslyr; d(9) = max_ntrcr
+      d(10) = 0
+   end subroutine ref_dims
+
+   !--------------------------------------------------------------------
+   ! EVP scalar parameters (set_evp_parameters, ice_dyn_evp.F90:535)
+   !--------------------------------------------------------------------
+   subroutine ref_set_evp_parameters(dt, ndte_in, damping, out) &
+         bind(C, name='ref_set_evp_parameters')
+      use ice_dyn_evp
+      real(c_double), value :: dt
+      integer(c_int), value :: ndte_in, damping
+      real(c_double), intent(out) :: out(6)
+      call ref_boot
+      ndte = ndte_in
+      kdyn = 1
+      evp_damping = (damping /= 0)
+      yield_curve = 'ellipse'
+      call set_evp_parameters(dt)
+      out(1) = dtei; out(2) = dte2T; out(3) = denom1; out(4) = denom2
+      out(5) = rcon; out(6) = ecci
+   end subroutine ref_set_evp_parameters
+
+   subroutine ref_set_strength_parameters(kstr, kpartic, kredist, mu) &
+         bind(C, name='ref_set_strength_parameters')
+      use ice_mechred
+      integer(c_int), value :: kstr, kpartic, kredist
+      real(c_double), value :: mu
+      kstrength = kstr; krdg_partic = kpartic; krdg_redist = kredist
+      mu_rdg = mu
+   end subroutine ref_set_strength_parameters
+
+   !--------------------------------------------------------------------
+   ! per-routine pass-throughs, any (nx,ny)
+   !--------------------------------------------------------------------
+   subroutine ref_stress(nx, ny, ksub, icellt, indxti, indxtj, uvel, vvel, &
+         dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, tinyarea, strength, &
+         sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124, &
+         shear, divu, prs_sig, rdg_conv, rdg_shear, str) bind(C, name='ref_stress')
+      use ice_dyn_evp, only: stress
+      integer(c_int), value :: nx, ny, ksub, icellt
+      integer(c_int), intent(in) :: indxti(nx*ny), indxtj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: uvel, vvel, dxt, dyt, dxhy, &
+         dyhx, cxp, cyp, cxm, cym, tarear, tinyarea, strength
+      real(c_double), dimension(nx,ny), intent(inout) :: sp1, sp2, sp3, sp4, sm1, &
+         sm2, sm3, sm4, s121, s122, s123, s124, shear, divu, prs_sig, rdg_conv, rdg_shear
+      real(c_double), intent(out) :: str(nx,ny,8)
+      call stress(nx, ny, ksub, icellt, indxti, indxtj, uvel, vvel, dxt, dyt, &
+         dxhy, dyhx, cxp, cyp, cxm, cym, tarear, tinyarea, strength, &
+         sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124, &
+         shear, divu, prs_sig, rdg_conv, rdg_shear, str)
+   end subroutine ref_stress
+
+   subroutine ref_stepu(nx, ny, icellu, indxui, indxuj, aiu, str, uocn, vocn, &
+         waterx, watery, forcex, forcey, umassdtei, fm, uarear, strocnx, strocny, &
+         strintx, strinty, uvel, vvel) bind(C, name='ref_stepu')
+      use ice_dyn_evp, only: stepu
+      integer(c_int), value :: nx, ny, icellu
+      integer(c_int), intent(in) :: indxui(nx*ny), indxuj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: aiu, uocn, vocn, waterx, &
+         watery, forcex, forcey, umassdtei, fm, uarear
+      real(c_double), intent(in) :: str(nx,ny,8)
+      real(c_double), dimension(nx,ny), intent(inout) :: strocnx, strocny, strintx, &
+         strinty, uvel, vvel
+      call stepu(nx, ny, icellu, indxui, indxuj, aiu, str, uocn, vocn, waterx, &
+         watery, forcex, forcey, umassdtei, fm, uarear, strocnx, strocny, &
+         strintx, strinty, uvel, vvel)
+   end subroutine ref_stepu
+
+   subroutine ref_evp_prep1(nx, ny, ilo, ihi, jlo, jhi, aice, vice, vsno, tmask, &
+         strairxT, strairyT, strairx, strairy, tmass, icetmask) bind(C, name='ref_evp_prep1')
+      use ice_dyn_evp, only: evp_prep1
+      integer(c_int), value :: nx, ny, ilo, ihi, jlo, jhi
+      real(c_double), dimension(nx,ny), intent(in) :: aice, vice, vsno, strairxT, strairyT
+      integer(c_int), intent(in) :: tmask(nx,ny)
+      real(c_double), dimension(nx,ny), intent(out) :: strairx, strairy, tmass
+      integer(c_int), intent(out) :: icetmask(nx,ny)
+      logical(log_kind) :: ltm(nx,ny)
+      ltm = (tmask /= 0)
+      call evp_prep1(nx, ny, ilo, ihi, jlo, jhi, aice, vice, vsno, ltm, &
+         strairxT, strairyT, strairx, strairy, tmass, icetmask)
+   end subroutine ref_evp_prep1
+
+   subroutine ref_evp_prep2(nx, ny, ilo, ihi, jlo, jhi, icellt, icellu, &
+         indxti, indxtj, indxui, indxuj, aiu, umass, umassdtei, fcor, umask, &
+         uocn, vocn, strairx, strairy, ss_tltx, ss_tlty, icetmask, iceumask, fm, &
+         strtltx, strtlty, strocnx, strocny, strintx, strinty, waterx, watery, &
+         forcex, forcey, sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, &
+         s124, uvel, vvel) bind(C, name='ref_evp_prep2')
+      use ice_dyn_evp, only: evp_prep2
+      integer(c_int), value :: nx, ny, ilo, ihi, jlo, jhi
+      integer(c_int), intent(out) :: icellt, icellu
+      integer(c_int), dimension(nx*ny), intent(out) :: indxti, indxtj, indxui, indxuj
+      real(c_double), dimension(nx,ny), intent(in) :: aiu, umass, fcor, uocn, vocn, &
+         strairx, strairy, ss_tltx, ss_tlty
+      integer(c_int), intent(in) :: umask(nx,ny), icetmask(nx,ny)
+      integer(c_int), intent(inout) :: iceumask(nx,ny)
+      real(c_double), dimension(nx,ny), intent(out) :: umassdtei, waterx, watery, &
+         forcex, forcey
+      real(c_double), dimension(nx,ny), intent(inout) :: fm, strtltx, strtlty, &
+         strocnx, strocny, strintx, strinty, sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, &
+         s121, s122, s123, s124, uvel, vvel
+      logical(log_kind) :: lum(nx,ny), lium(nx,ny)
+      lum = (umask /= 0)
+      lium = (iceumask /= 0)
+      call evp_prep2(nx, ny, ilo, ihi, jlo, jhi, icellt, icellu, indxti, indxtj, &
+         indxui, indxuj, aiu, umass, umassdtei, fcor, lum, uocn, vocn, strairx, &
+         strairy, ss_tltx, ss_tlty, icetmask, lium, fm, strtltx, strtlty, strocnx, &
+         strocny, strintx, strinty, waterx, watery, forcex, forcey, sp1, sp2, sp3, &
+         sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124, uvel, vvel)
+      where (lium)
+         iceumask = 1
+      elsewhere
+         iceumask = 0
+      end where
+   end subroutine ref_evp_prep2
+
+   subroutine ref_evp_finish(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, &
+         aiu, strocnx, strocny, strocnxT, strocnyT) bind(C, name='ref_evp_finish')
+      use ice_dyn_evp, only: evp_finish
+      integer(c_int), value :: nx, ny, icellu
+      integer(c_int), intent(in) :: indxui(nx*ny), indxuj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: uvel, vvel, uocn, vocn, aiu
+      real(c_double), dimension(nx,ny), intent(inout) :: strocnx, strocny, strocnxT, strocnyT
+      call evp_finish(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, &
+         strocnx, strocny, strocnxT, strocnyT)
+   end subroutine ref_evp_finish
+
+   subroutine ref_ice_strength(nx, ny, ilo, ihi, jlo, jhi, icells, indxi, indxj, &
+         aice, vice, aice0, aicen, vicen, strength) bind(C, name='ref_ice_strength')
+      use ice_mechred, only: ice_strength
+      integer(c_int), value :: nx, ny, ilo, ihi, jlo, jhi, icells
+      integer(c_int), intent(in) :: indxi(nx*ny), indxj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: aice, vice, aice0
+      real(c_double), dimension(nx,ny,ncat), intent(in) :: aicen, vicen
+      real(c_double), intent(out) :: strength(nx,ny)
+      call ice_strength(nx, ny, ilo, ihi, jlo, jhi, icells, indxi, indxj, aice, &
+         vice, aice0, aicen, vicen, strength)
+   end subroutine ref_ice_strength
+
+   !--------------------------------------------------------------------
+   ! thermodynamics
+   !--------------------------------------------------------------------
+   subroutine ref_init_thermo(heatcap, calcts, conduct_id, ustarmin, salin_out, &
+         tmlt_out) bind(C, name='ref_init_thermo')
+      use ice_therm_vertical
+      use ice_itd, only: ilyr1, ilyrn, slyr1, slyrn
+      integer(c_int), value :: heatcap, calcts, conduct_id
+      real(c_double), value :: ustarmin
+      real(c_double), intent(out) :: salin_out(nilyr+1), tmlt_out(nilyr+1)
+      integer :: n
+      call ref_boot
+      heat_capacity = (heatcap /= 0)
+      calc_Tsfc = (calcts /= 0)
+      if (conduct_id == 0) then
+         conduct = 'MU71'
+      else
+         conduct = 'bubbly'
+      endif
+      ustar_min = ustarmin
+      call init_thermo_vertical
+      salin_out = salin
+      tmlt_out = Tmlt
+      ! layer index maps exactly as init_itd sets them (ice_itd.F90:240-260)
+      ilyr1(1) = 1; ilyrn(1) = nilyr; slyr1(1) = 1; slyrn(1) = nslyr
+      do n = 2, ncat
+         ilyr1(n) = ilyrn(n-1) + 1; ilyrn(n) = ilyrn(n-1) + nilyr
+         slyr1(n) = slyrn(n-1) + 1; slyrn(n) = slyrn(n-1) + nslyr
+      enddo
+   end subroutine ref_init_thermo
+
+   subroutine ref_thermo_vertical(nx, ny, dt, icells, indxi, indxj, aicen, trcrn, &
+         vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot, lhcoef, &
+         shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, fsurfn, fcondtopn, fsensn, &
+         flatn, fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, meltt, melts, meltb, &
+         congel, snoice, mlt_onset, frz_onset, yday, l_stop, istop, jstop) &
+         bind(C, name='ref_thermo_vertical')
+      use ice_therm_vertical, only: thermo_vertical
+      integer(c_int), value :: nx, ny, icells
+      real(c_double), value :: dt, yday
+      integer(c_int), intent(in) :: indxi(nx*ny), indxj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(inout) :: aicen, vicen, vsnon
+      real(c_double), intent(inout) :: trcrn(nx,ny,max_ntrcr), eicen(nx,ny,nilyr), &
+         esnon(nx,ny,nslyr)
+      real(c_double), dimension(nx,ny), intent(in) :: flw, potT, Qa, rhoa, fsnow, &
+         fbot, Tbot, lhcoef, shcoef
+      real(c_double), dimension(nx,ny), intent(inout) :: fswsfc, fswint, fswthrun
+      real(c_double), intent(inout) :: Sswabs(nx,ny,nslyr), Iswabs(nx,ny,nilyr)
+      real(c_double), dimension(nx,ny), intent(inout) :: fsurfn, fcondtopn, fsensn, &
+         flatn, fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, meltt, melts, meltb, &
+         congel, snoice, mlt_onset, frz_onset
+      integer(c_int), intent(out) :: l_stop, istop, jstop
+      logical(log_kind) :: ls
+      call thermo_vertical(nx, ny, dt, icells, indxi, indxj, aicen, trcrn, vicen, &
+         vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot, lhcoef, shcoef, &
+         fswsfc, fswint, fswthrun, Sswabs, Iswabs, fsurfn, fcondtopn, fsensn, flatn, &
+         fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, meltt, melts, meltb, congel, &
+         snoice, mlt_onset, frz_onset, yday, ls, istop, jstop)
+      l_stop = 0
+      if (ls) l_stop = 1
+   end subroutine ref_thermo_vertical
+
+   subroutine ref_frzmlt_bottom_lateral(nx, ny, ilo, ihi, jlo, jhi, dt, aice, frzmlt, &
+         eicen, esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside) &
+         bind(C, name='ref_frzmlt_bottom_lateral')
+      use ice_therm_vertical, only: frzmlt_bottom_lateral
+      integer(c_int), value :: nx, ny, ilo, ihi, jlo, jhi
+      real(c_double), value :: dt
+      real(c_double), dimension(nx,ny), intent(in) :: aice, frzmlt, sst, Tf, strocnxT, strocnyT
+      real(c_double), intent(in) :: eicen(nx,ny,ntilyr), esnon(nx,ny,ntslyr)
+      real(c_double), dimension(nx,ny), intent(out) :: Tbot, fbot, rside
+      call frzmlt_bottom_lateral(nx, ny, ilo, ihi, jlo, jhi, dt, aice, frzmlt, eicen, &
+         esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside)
+   end subroutine ref_frzmlt_bottom_lateral
+
+   !--------------------------------------------------------------------
+   ! whole-domain set-up (cice_init subset, CICE_InitMod.F90:124-150) so that
+   ! evp(dt) can run on the reference's own module arrays, blocks and halos.
+   ! The working directory must hold an `ice_in` with a domain_nml.
+   !--------------------------------------------------------------------
+   integer(c_int) function ref_init_domain(grid_kind, gridfile, kmtfile, dt, ndte_in, &
+         damping) bind(C, name='ref_init_domain')
+      use ice_work, only: init_work
+      use ice_domain, only: init_domain_blocks, nblocks
+      use ice_grid
+      use ice_timers, only: init_ice_timers
+      use ice_dyn_evp
+      use ice_flux, only: init_coupler_flux
+      use ice_itd, only: init_itd, kitd, kcatbound
+      integer(c_int), value :: grid_kind, ndte_in, damping
+      character(kind=c_char), intent(in) :: gridfile(*), kmtfile(*)
+      real(c_double), value :: dt
+      call ref_boot
+      if (domain_ready) then
+         ref_init_domain = nblocks
+         return
+      endif
+      if (grid_kind == 1) then
+         grid_type = 'displaced_pole'
+         grid_format = 'bin'
+         call cstr(gridfile, grid_file)
+         call cstr(kmtfile, kmt_file)
+      else
+         grid_type = 'rectangular'
+         grid_format = 'bin'
+      endif
+      call init_work
+      call init_domain_blocks
+      call init_grid1
+      call init_ice_timers
+      call init_grid2
+      ndte = ndte_in
+      kdyn = 1
+      evp_damping = (damping /= 0)
+      yield_curve = 'ellipse'
+      call init_evp(dt)
+      call init_coupler_flux
+      kitd = 1
+      kcatbound = 0
+      call init_itd
+      domain_ready = .true.
+      ref_init_domain = nblocks
+   end function ref_init_domain
+
+   subroutine ref_block_info(iblk, info, iglob, jglob) bind(C, name='ref_block_info')
+      use ice_blocks
+      use ice_domain, only: blocks_ice
+      integer(c_int), value :: iblk
+      integer(c_int), intent(out) :: info(6), iglob(nx_block), jglob(ny_block)
+      type(block) :: b
+      b = get_block(blocks_ice(iblk), iblk)
+      info(1) = b%ilo; info(2) = b%ihi; info(3) = b%jlo; info(4) = b%jhi
+      info(5) = b%block_id; info(6) = b%local_id
+      iglob = b%i_glob
+      jglob = b%j_glob
+   end subroutine ref_block_info
+
+   subroutine ref_evp(dt) bind(C, name='ref_evp')
+      use ice_dyn_evp, only: evp
+      real(c_double), value :: dt
+      call evp(dt)
+   end subroutine ref_evp
+
+   subroutine ref_halo_r8(a, loc, kind) bind(C, name='ref_halo_r8')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_boundary
+      use ice_domain, only: halo_info
+      real(c_double), intent(inout) :: a(nx_block,ny_block,max_blocks)
+      integer(c_int), value :: loc, kind
+      call ice_HaloUpdate(a, halo_info, loc, kind)
+   end subroutine ref_halo_r8
+
+   subroutine ref_halo_i4(a, loc, kind) bind(C, name='ref_halo_i4')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_boundary
+      use ice_domain, only: halo_info
+      integer(c_int), intent(inout) :: a(nx_block,ny_block,max_blocks)
+      integer(c_int), value :: loc, kind
+      call ice_HaloUpdate(a, halo_info, loc, kind)
+   end subroutine ref_halo_i4
+
+   subroutine ref_to_ugrid(w1, w2) bind(C, name='ref_to_ugrid')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_grid, only: to_ugrid
+      real(c_double), intent(in) :: w1(nx_block,ny_block,max_blocks)
+      real(c_double), intent(out) :: w2(nx_block,ny_block,max_blocks)
+      call to_ugrid(w1, w2)
+   end subroutine ref_to_ugrid
+
+   !--------------------------------------------------------------------
+   ! field access by name: dir = 0 get (module -> buf), 1 set (buf -> module).
+   ! nlev = number of (nx_block,ny_block,max_blocks) slabs in buf; returns
+   ! nlev actually moved, or -1 for an unknown name.  Logical masks travel
+   ! as 0.0 / 1.0.
+   !--------------------------------------------------------------------
+   integer(c_int) function ref_field(cname, dir, buf) bind(C, name='ref_field')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_state
+      use ice_flux
+      use ice_grid
+      use ice_dyn_evp, only: fcor_blk
+      character(kind=c_char), intent(in) :: cname(*)
+      integer(c_int), value :: dir
+      real(c_double), intent(inout) :: buf(nx_block,ny_block,*)
+      character(len=32) :: name
+      integer :: n, k, m, iblk
+      call cstr(cname, name)
+      n = 1
+#define F2(nm) if (dir == 0) then; buf(:,:,1:max_blocks) = nm; else; nm = buf(:,:,1:max_blocks); endif
+      select case (trim(name))
+      case ('aice');  F2(aice)
+      case ('vice');  F2(vice)
+      case ('vsno');  F2(vsno)
+      case ('aice0'); F2(aice0)
+      case ('uvel');  F2(uvel)
+      case ('vvel');  F2(vvel)
+      case ('divu');  F2(divu)
+      case ('shear'); F2(shear)
+      case ('strength'); F2(strength)
+      case ('rdg_conv'); F2(rdg_conv)
+      case ('rdg_shear'); F2(rdg_shear)
+      case ('prs_sig'); F2(prs_sig)
+      case ('strairxT'); F2(strairxT)
+      case ('strairyT'); F2(strairyT)
+      case ('strairx'); F2(strairx)
+      case ('strairy'); F2(strairy)
+      case ('uocn'); F2(uocn)
+      case ('vocn'); F2(vocn)
+      case ('ss_tltx'); F2(ss_tltx)
+      case ('ss_tlty'); F2(ss_tlty)
+      case ('strtltx'); F2(strtltx)
+      case ('strtlty'); F2(strtlty)
+      case ('strocnx'); F2(strocnx)
+      case ('strocny'); F2(strocny)
+      case ('strocnxT'); F2(strocnxT)
+      case ('strocnyT'); F2(strocnyT)
+      case ('strintx'); F2(strintx)
+      case ('strinty'); F2(strinty)
+      case ('fm'); F2(fm)
+      case ('stressp_1'); F2(stressp_1)
+      case ('stressp_2'); F2(stressp_2)
+      case ('stressp_3'); F2(stressp_3)
+      case ('stressp_4'); F2(stressp_4)
+      case ('stressm_1'); F2(stressm_1)
+      case ('stressm_2'); F2(stressm_2)
+      case ('stressm_3'); F2(stressm_3)
+      case ('stressm_4'); F2(stressm_4)
+      case ('stress12_1'); F2(stress12_1)
+      case ('stress12_2'); F2(stress12_2)
+      case ('stress12_3'); F2(stress12_3)
+      case ('stress12_4'); F2(stress12_4)
+      case ('fcor'); F2(fcor_blk)
+      case ('dxt'); F2(dxt)
+      case ('dyt'); F2(dyt)
+      case ('dxu'); F2(dxu)
+      case ('dyu'); F2(dyu)
+      case ('HTE'); F2(HTE)
+      case ('HTN'); F2(HTN)
+      case ('tarea'); F2(tarea)
+      case ('uarea'); F2(uarea)
+      case ('tarear'); F2(tarear)
+      case ('uarear'); F2(uarear)
+      case ('tinyarea'); F2(tinyarea)
+      case ('dxhy'); F2(dxhy)
+      case ('dyhx'); F2(dyhx)
+      case ('cxp'); F2(cxp)
+      case ('cyp'); F2(cyp)
+      case ('cxm'); F2(cxm)
+      case ('cym'); F2(cym)
+      case ('ULAT'); F2(ULAT)
+      case ('ULON'); F2(ULON)
+      case ('TLAT'); F2(TLAT)
+      case ('TLON'); F2(TLON)
+      case ('ANGLE'); F2(ANGLE)
+      case ('hm'); F2(hm)
+      case ('uvm'); F2(uvm)
+      case ('tmask')
+         if (dir == 0) then
+            buf(:,:,1:max_blocks) = merge(1.0d0, 0.0d0, tmask)
+         else
+            tmask = (buf(:,:,1:max_blocks) /= 0.0d0)
+         endif
+      case ('umask')
+         if (dir == 0) then
+            buf(:,:,1:max_blocks) = merge(1.0d0, 0.0d0, umask)
+         else
+            umask = (buf(:,:,1:max_blocks) /= 0.0d0)
+         endif
+      case ('iceumask')
+         if (dir == 0) then
+            buf(:,:,1:max_blocks) = merge(1.0d0, 0.0d0, iceumask)
+         else
+            iceumask = (buf(:,:,1:max_blocks) /= 0.0d0)
+         endif
+      case ('aicen')
+         n = ncat*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ncat
+               m = (iblk-1)*ncat + k
+               if (dir == 0) then
+                  buf(:,:,m) = aicen(:,:,k,iblk)
+               else
+                  aicen(:,:,k,iblk) = buf(:,:,m)
+               endif
+            enddo
+         enddo
+      case ('vicen')
+         n = ncat*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ncat
+               m = (iblk-1)*ncat + k
+               if (dir == 0) then
+                  buf(:,:,m) = vicen(:,:,k,iblk)
+               else
+                  vicen(:,:,k,iblk) = buf(:,:,m)
+               endif
+            enddo
+         enddo
+      case default
+         n = -1
+      end select
+      ref_field = n
+   end function ref_field
+
+end module ref_capi

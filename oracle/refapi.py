@@ -1,0 +1,227 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes loader for the COMPILED REFERENCE
+(oracle/_ref/libcice_ref_<cfg>.so, built by oracle/build_ref.sh from the
+Fortran under /root/reference).  Only tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg may import this module; the product never does.
+
+Array convention everywhere in this repo: a Fortran (nx,ny[,k]) field is a
+C-contiguous numpy array of shape ([k,] ny, nx) -- byte-identical memory.
+Index lists (indxi/indxj) carry Fortran 1-based values.
+"""
+import ctypes as C
+import os
+import resource
+import numpy as np
+
+# evp and thermo_vertical keep large automatic arrays on the stack
+# (ice_dyn_evp.F90:160-184, ice_therm_vertical.F90:261-289): the main thread's
+# stack grows on demand up to the soft limit, so raise it to the hard limit.
+_soft, _hard = resource.getrlimit(resource.RLIMIT_STACK)
+if _soft != _hard:
+    resource.setrlimit(resource.RLIMIT_STACK, (_hard, _hard))
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+
+NCAT, NILYR, NSLYR, MAX_NTRCR = 5, 4, 1, 5
+
+
+def available(cfg="gx3"):
+    return os.path.exists(os.path.join(REFDIR, f"libcice_ref_{cfg}.so"))
+
+
+def _p(a):
+    assert a.flags["C_CONTIGUOUS"], "array must be contiguous"
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def f8(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i4(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Ref:
+    """One loaded reference library (one compile-time grid configuration)."""
+
+    def __init__(self, cfg="gx3"):
+        path = os.path.join(REFDIR, f"libcice_ref_{cfg}.so")
+        # the reference's binary grid/kmt files are big-endian (bld/Macros.*: -convert
+        # big_endian); flang applies -fconvert only from a Fortran main program, so
+        # set the runtime's FORT_CONVERT switch and run its start-up hook (which a
+        # Fortran main would have run) so that it reads the environment.
+        os.environ.setdefault("FORT_CONVERT", "BIG_ENDIAN")
+        self.lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
+        self.cfg = cfg
+        environ = C.POINTER(C.c_char_p).in_dll(C.CDLL(None), "environ")
+        self.lib._FortranAProgramStart(C.c_int(0), None, environ, None)
+        self.lib.ref_boot()
+        d = np.zeros(10, np.int32)
+        self.lib.ref_dims(_p(d))
+        (self.nx_block, self.ny_block, self.max_blocks, self.nx_global,
+         self.ny_global) = (int(x) for x in d[:5])
+        self.lib.ref_init_domain.restype = C.c_int
+        self.lib.ref_field.restype = C.c_int
+        self.nblocks = 0
+
+    # ---- EVP scalars -------------------------------------------------
+    def set_evp_parameters(self, dt, ndte, damping=False):
+        out = np.zeros(6)
+        self.lib.ref_set_evp_parameters(C.c_double(dt), C.c_int(ndte),
+                                        C.c_int(int(damping)), _p(out))
+        return dict(zip(("dtei", "dte2T", "denom1", "denom2", "rcon", "ecci"), out))
+
+    def set_strength_parameters(self, kstrength=1, krdg_partic=1, krdg_redist=1, mu_rdg=4.0):
+        self.lib.ref_set_strength_parameters(C.c_int(kstrength), C.c_int(krdg_partic),
+                                             C.c_int(krdg_redist), C.c_double(mu_rdg))
+
+    # ---- per-routine calls (arrays are modified in place) ------------
+    def stress(self, ksub, icellt, indxti, indxtj, uvel, vvel, grid, strength, sig, diag, str8):
+        ny, nx = uvel.shape
+        g = grid
+        self.lib.ref_stress(C.c_int(nx), C.c_int(ny), C.c_int(ksub), C.c_int(icellt),
+                            _p(indxti), _p(indxtj), _p(uvel), _p(vvel),
+                            _p(g["dxt"]), _p(g["dyt"]), _p(g["dxhy"]), _p(g["dyhx"]),
+                            _p(g["cxp"]), _p(g["cyp"]), _p(g["cxm"]), _p(g["cym"]),
+                            _p(g["tarear"]), _p(g["tinyarea"]), _p(strength),
+                            *[_p(sig[k]) for k in range(12)],
+                            _p(diag["shear"]), _p(diag["divu"]), _p(diag["prs_sig"]),
+                            _p(diag["rdg_conv"]), _p(diag["rdg_shear"]), _p(str8))
+
+    def stepu(self, icellu, indxui, indxuj, aiu, str8, uocn, vocn, waterx, watery, forcex,
+              forcey, umassdtei, fm, uarear, strocnx, strocny, strintx, strinty, uvel, vvel):
+        ny, nx = uvel.shape
+        self.lib.ref_stepu(C.c_int(nx), C.c_int(ny), C.c_int(icellu), _p(indxui), _p(indxuj),
+                           _p(aiu), _p(str8), _p(uocn), _p(vocn), _p(waterx), _p(watery),
+                           _p(forcex), _p(forcey), _p(umassdtei), _p(fm), _p(uarear),
+                           _p(strocnx), _p(strocny), _p(strintx), _p(strinty), _p(uvel), _p(vvel))
+
+    def evp_prep1(self, ilo, ihi, jlo, jhi, aice, vice, vsno, tmask, strairxT, strairyT):
+        ny, nx = aice.shape
+        strairx = np.zeros((ny, nx)); strairy = np.zeros((ny, nx)); tmass = np.zeros((ny, nx))
+        icetmask = np.zeros((ny, nx), np.int32)
+        self.lib.ref_evp_prep1(C.c_int(nx), C.c_int(ny), C.c_int(ilo), C.c_int(ihi), C.c_int(jlo),
+                               C.c_int(jhi), _p(aice), _p(vice), _p(vsno), _p(i4(tmask)),
+                               _p(strairxT), _p(strairyT), _p(strairx), _p(strairy), _p(tmass),
+                               _p(icetmask))
+        return strairx, strairy, tmass, icetmask
+
+    def evp_prep2(self, ilo, ihi, jlo, jhi, a):
+        """a: dict of (ny,nx) arrays, modified in place. Returns icellt, icellu, lists."""
+        ny, nx = a["aiu"].shape
+        icellt = C.c_int(0); icellu = C.c_int(0)
+        lists = [np.zeros(nx * ny, np.int32) for _ in range(4)]
+        sig = a["sig"]
+        self.lib.ref_evp_prep2(C.c_int(nx), C.c_int(ny), C.c_int(ilo), C.c_int(ihi), C.c_int(jlo),
+                               C.c_int(jhi), C.byref(icellt), C.byref(icellu),
+                               *[_p(l) for l in lists], _p(a["aiu"]), _p(a["umass"]),
+                               _p(a["umassdtei"]), _p(a["fcor"]), _p(a["umask"]), _p(a["uocn"]),
+                               _p(a["vocn"]), _p(a["strairx"]), _p(a["strairy"]), _p(a["ss_tltx"]),
+                               _p(a["ss_tlty"]), _p(a["icetmask"]), _p(a["iceumask"]), _p(a["fm"]),
+                               _p(a["strtltx"]), _p(a["strtlty"]), _p(a["strocnx"]),
+                               _p(a["strocny"]), _p(a["strintx"]), _p(a["strinty"]),
+                               _p(a["waterx"]), _p(a["watery"]), _p(a["forcex"]), _p(a["forcey"]),
+                               *[_p(sig[k]) for k in range(12)], _p(a["uvel"]), _p(a["vvel"]))
+        return icellt.value, icellu.value, lists
+
+    def evp_finish(self, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, strocnx, strocny,
+                   strocnxT, strocnyT):
+        ny, nx = uvel.shape
+        self.lib.ref_evp_finish(C.c_int(nx), C.c_int(ny), C.c_int(icellu), _p(indxui), _p(indxuj),
+                                _p(uvel), _p(vvel), _p(uocn), _p(vocn), _p(aiu), _p(strocnx),
+                                _p(strocny), _p(strocnxT), _p(strocnyT))
+
+    def ice_strength(self, ilo, ihi, jlo, jhi, icells, indxi, indxj, aice, vice, aice0, aicen, vicen):
+        ny, nx = aice.shape
+        strength = np.zeros((ny, nx))
+        self.lib.ref_ice_strength(C.c_int(nx), C.c_int(ny), C.c_int(ilo), C.c_int(ihi), C.c_int(jlo),
+                                  C.c_int(jhi), C.c_int(icells), _p(indxi), _p(indxj), _p(aice),
+                                  _p(vice), _p(aice0), _p(aicen), _p(vicen), _p(strength))
+        return strength
+
+    # ---- thermodynamics ---------------------------------------------
+    def init_thermo(self, heat_capacity=True, calc_Tsfc=True, conduct="MU71", ustar_min=0.05):
+        salin = np.zeros(NILYR + 1); tmlt = np.zeros(NILYR + 1)
+        self.lib.ref_init_thermo(C.c_int(int(heat_capacity)), C.c_int(int(calc_Tsfc)),
+                                 C.c_int(0 if conduct == "MU71" else 1), C.c_double(ustar_min),
+                                 _p(salin), _p(tmlt))
+        return salin, tmlt
+
+    THERMO_ARGS = ("aicen", "trcrn", "vicen", "vsnon", "eicen", "esnon", "flw", "potT", "Qa",
+                   "rhoa", "fsnow", "fbot", "Tbot", "lhcoef", "shcoef", "fswsfc", "fswint",
+                   "fswthrun", "Sswabs", "Iswabs", "fsurfn", "fcondtopn", "fsensn", "flatn",
+                   "fswabsn", "flwoutn", "evapn", "freshn", "fsaltn", "fhocnn", "meltt", "melts",
+                   "meltb", "congel", "snoice", "mlt_onset", "frz_onset")
+
+    def thermo_vertical(self, dt, icells, indxi, indxj, a, yday=1.0):
+        """a: dict with every THERMO_ARGS entry ((ny,nx) or (k,ny,nx)), modified in place."""
+        ny, nx = a["aicen"].shape
+        ls = C.c_int(0); istop = C.c_int(0); jstop = C.c_int(0)
+        self.lib.ref_thermo_vertical(C.c_int(nx), C.c_int(ny), C.c_double(dt), C.c_int(icells),
+                                     _p(indxi), _p(indxj), *[_p(a[k]) for k in self.THERMO_ARGS],
+                                     C.c_double(yday), C.byref(ls), C.byref(istop), C.byref(jstop))
+        return ls.value, istop.value, jstop.value
+
+    def frzmlt_bottom_lateral(self, ilo, ihi, jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf,
+                              strocnxT, strocnyT):
+        ny, nx = aice.shape
+        Tbot = np.zeros((ny, nx)); fbot = np.zeros((ny, nx)); rside = np.zeros((ny, nx))
+        self.lib.ref_frzmlt_bottom_lateral(C.c_int(nx), C.c_int(ny), C.c_int(ilo), C.c_int(ihi),
+                                           C.c_int(jlo), C.c_int(jhi), C.c_double(dt), _p(aice),
+                                           _p(frzmlt), _p(eicen), _p(esnon), _p(sst), _p(Tf),
+                                           _p(strocnxT), _p(strocnyT), _p(Tbot), _p(fbot), _p(rside))
+        return Tbot, fbot, rside
+
+    # ---- whole-domain path --------------------------------------------
+    def init_domain(self, workdir, dt=3600.0, ndte=120, damping=False, grid="rectangular",
+                    grid_file="", kmt_file="", ew="cyclic", ns="open", nprocs=1):
+        """Runs the cice_init subset.  ONE call per process per library."""
+        os.makedirs(workdir, exist_ok=True)
+        with open(os.path.join(workdir, "ice_in"), "w") as f:
+            f.write("&domain_nml\n  nprocs = %d\n  processor_shape = 'slenderX2'\n"
+                    "  distribution_type = 'cartesian'\n  distribution_wght = 'latitude'\n"
+                    "  ew_boundary_type = '%s'\n  ns_boundary_type = '%s'\n/\n" % (nprocs, ew, ns))
+        cwd = os.getcwd()
+        os.chdir(workdir)
+        try:
+            self.nblocks = self.lib.ref_init_domain(
+                C.c_int(1 if grid == "displaced_pole" else 0), grid_file.encode() + b"\0",
+                kmt_file.encode() + b"\0", C.c_double(dt), C.c_int(ndte), C.c_int(int(damping)))
+        finally:
+            os.chdir(cwd)
+        return self.nblocks
+
+    def block_info(self, iblk):
+        info = np.zeros(6, np.int32)
+        ig = np.zeros(self.nx_block, np.int32); jg = np.zeros(self.ny_block, np.int32)
+        self.lib.ref_block_info(C.c_int(iblk), _p(info), _p(ig), _p(jg))
+        return dict(ilo=int(info[0]), ihi=int(info[1]), jlo=int(info[2]), jhi=int(info[3]),
+                    block_id=int(info[4]), i_glob=ig, j_glob=jg)
+
+    def _shape(self, nlev):
+        return (nlev, self.ny_block, self.nx_block)
+
+    def get(self, name, nlev=None):
+        if nlev is None:
+            nlev = self.max_blocks * (NCAT if name in ("aicen", "vicen") else 1)
+        buf = np.zeros(self._shape(nlev))
+        n = self.lib.ref_field(name.encode() + b"\0", C.c_int(0), _p(buf))
+        if n < 0:
+            raise KeyError(name)
+        return buf
+
+    def set(self, name, arr):
+        arr = f8(arr)
+        n = self.lib.ref_field(name.encode() + b"\0", C.c_int(1), _p(arr))
+        if n < 0:
+            raise KeyError(name)
+
+    def evp(self, dt):
+        self.lib.ref_evp(C.c_double(dt))
+
+    def halo_r8(self, a, loc=1, kind=1):
+        self.lib.ref_halo_r8(_p(a), C.c_int(loc), C.c_int(kind))
+
+    def halo_i4(self, a, loc=1, kind=1):
+        self.lib.ref_halo_i4(_p(a), C.c_int(loc), C.c_int(kind))
