@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X-native CICE4 hot path (contract: see DESIGN.md section "Measurement").
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload gx1|tenth|gx3]
+
+One "step" = one pass of the EVP hot loop over the whole grid = ndte subcycles of
+stress + stepu + halo update (source/ice_dyn_evp.F90:347-404 of the reference) on
+device-resident state.  `value` = EVP subcycles per second for the whole job.  The same
+JSON line carries the column-thermodynamics rate ((cell,category) updates per second),
+the HBM roofline of the dominant kernel and a CPU baseline timed on this host.
+
+N > 1: launched by torch.distributed.run, one rank per GPU; the grid is cut into N
+j-slabs (strong scaling) and ghost rows travel by RCCL point-to-point inside the library.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cice4_amd import lib, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (nx_global, ny_global, ndte, description)
+    "gx3": (100, 116, 120, "gx3-size 100x116 rectangular synthetic grid, full ice cover, ncat=5, ndte=120"),
+    "gx1": (320, 384, 120, "gx1-size 320x384 rectangular synthetic grid, full ice cover, ncat=5, ndte=120"),
+    "tenth": (3600, 2400, 240, "0.1-degree-size 3600x2400 rectangular synthetic grid, full ice cover, ncat=5, ndte=240"),
+}
+DT = 3600.0
+EVP_BYTES_PER_CELL = 384.0      # compulsory bytes per active cell per subcycle
+THERMO_BYTES_PER_COLUMN = 304.0  # per (cell,category) update (+376 B per cell shared by the categories)
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="gx1", choices=sorted(WORKLOADS))
+    p.add_argument("--tile-rows", type=int, default=0, help="EVP tile height (8/16/32); 0 = auto")
+    p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-thermo", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
+    p.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
+    return p.parse_args()
+
+
+def init_dist(n_gpus):
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {n_gpus}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane (barriers, the ncclUniqueId, max-over-ranks) on gloo; the data path
+        # (ghost rows) is RCCL inside libcice4_amd.so
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    return rank, world, local, dist
+
+
+def build_case(ctx, wl, rank, world):
+    nxg, nyg, ndte, _ = WORKLOADS[wl]
+    if nyg % world:
+        raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg // world, ew=1, ns=0, rank=rank, npx=1, npy=world)
+    gg = synth.global_grid(nxg, nyg)          # uniform 30 km rectangular grid (ice_grid.F90:976)
+    grid = synth.block_fields(gg, dom)
+    state = synth.evp_state(grid, dom, cover="full")
+    return dom, grid, state, ndte
+
+
+def thermo_case(dom, seed=20261003):
+    """Module-array-shaped inputs of the batched thermo step for this rank's blocks."""
+    nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
+    NC, NI, NS = 5, 4, 1
+    z = lambda *s: np.zeros(s)
+    b = dict(aicen=z(nb, NC, ny, nx), trcrn=z(nb, NC, 5, ny, nx), vicen=z(nb, NC, ny, nx),
+             vsnon=z(nb, NC, ny, nx), eicen=z(nb, NC * NI, ny, nx), esnon=z(nb, NC * NS, ny, nx),
+             lhcoef=z(nb, NC, ny, nx), shcoef=z(nb, NC, ny, nx), fswsfc=z(nb, NC, ny, nx),
+             fswint=z(nb, NC, ny, nx), fswthrun=z(nb, NC, ny, nx), Sswabs=z(nb, NC, NS, ny, nx),
+             Iswabs=z(nb, NC, NI, ny, nx), mlt_onset=z(nb, ny, nx), frz_onset=z(nb, ny, nx))
+    for k in lib.THERMO_FORCING:
+        b[k] = z(nb, ny, nx)
+    for k in lib.THERMO_OUT:
+        b[k] = z(nb, NC, ny, nx)
+    cols = {}
+    for ib in range(nb):
+        for n in range(NC):
+            a, icells, ii, jj = synth.thermo_columns(ny, nx, n, regime="mixed",
+                                                     seed=seed + 31 * int(dom["gid"][ib]), ice_frac=1.0)
+            cols[(ib, n)] = (a, icells, ii, jj)
+            for k in ("aicen", "vicen", "vsnon", "lhcoef", "shcoef", "fswsfc", "fswint", "fswthrun"):
+                b[k][ib, n] = a[k]
+            b["trcrn"][ib, n] = a["trcrn"]
+            b["eicen"][ib, n * NI:(n + 1) * NI] = a["eicen"]
+            b["esnon"][ib, n * NS:(n + 1) * NS] = a["esnon"]
+            b["Sswabs"][ib, n] = a["Sswabs"]
+            b["Iswabs"][ib, n] = a["Iswabs"]
+            if n == 0:
+                for k in lib.THERMO_FORCING + ("mlt_onset", "frz_onset"):
+                    b[k][ib] = a[k]
+    return b, cols
+
+
+def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
+    """Time the CPU checker on a bounded sample of the SAME workload, on this host.
+    kind 'reference': the reference's own compiled Fortran (oracle/_ref), single thread;
+    kind 'port': our plain-C restatement (oracle/), single thread."""
+    from oracle import oracle as orc_mod
+    out = {}
+    orc = orc_mod.Oracle()
+    orc.set_evp_parameters(DT, ndte)
+    orc.set_strength_parameters()
+    ref = None
+    try:
+        from oracle import refapi
+        if refapi.available(wl):
+            ref = refapi.Ref(wl)
+    except Exception:
+        ref = None
+    ncpu = os.cpu_count()
+    # --- EVP: subcycle loop
+    if ref is not None:
+        import tempfile
+        ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=ndte)
+        ref.set_strength_parameters()
+        for k in ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
+                  "uarear", "tinyarea", "fcor"):
+            ref.set(k, grid[k])
+        ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
+        for k in ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx",
+                  "ss_tlty", "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx",
+                  "strinty") + synth.SIG_NAMES:
+            ref.set(k, state[k])
+        ref.set("iceumask", state["iceumask"].astype(float))
+        ny, nx = dom["ny"], dom["nx"]
+        ref.set("aicen", state["aicen"].reshape(-1, ny, nx)); ref.set("vicen", state["vicen"].reshape(-1, ny, nx))
+        ncalls, t = 0, 0.0
+        while t < budget_s * 0.5 and ncalls < 50:
+            t0 = time.perf_counter(); ref.evp(DT); t += time.perf_counter() - t0; ncalls += 1
+        out["evp"] = dict(value=ndte * ncalls / t, unit="EVP subcycles/s", cores=1, kind="reference",
+                          sample=f"{ncalls} call(s) of the reference's evp(dt) ({ndte} subcycles each, incl. its "
+                                 f"once-per-step prep/finish ~3%), {wl} full cover, 1 thread of {ncpu} host cores")
+    else:
+        d = orc.make_domain(dom, grid)
+        s = {k: v.copy() for k, v in state.items()}
+        nsub = max(4, int(budget_s * 0.5 * 90 * (320 * 384) / (dom["nxg"] * dom["nyg"])))
+        t = orc.evp_subcycles_only(d, s, nsub)
+        out["evp"] = dict(value=nsub / t, unit="EVP subcycles/s", cores=1, kind="port",
+                          sample=f"{nsub} subcycles of the C restatement (stress+stepu+halo), {wl} full cover, "
+                                 f"1 thread of {ncpu} host cores")
+    # --- thermo: thermo_vertical over the categories of block 0
+    if tcols is not None:
+        impl = ref if ref is not None else orc
+        impl.init_thermo()
+        nupd, t = 0, 0.0
+        passes = 0
+        while t < budget_s * 0.5 and passes < 20:
+            for n in range(5):
+                a, icells, ii, jj = tcols[(0, n)]
+                ac = {k: v.copy() for k, v in a.items()}
+                t0 = time.perf_counter()
+                impl.thermo_vertical(DT, icells, ii, jj, ac)
+                t += time.perf_counter() - t0
+                nupd += icells
+            passes += 1
+        out["thermo"] = dict(value=nupd / t, unit="(cell,category) updates/s", cores=1,
+                             kind="reference" if ref is not None else "port",
+                             sample=f"{passes} pass(es) of thermo_vertical over 5 categories of block 0 "
+                                    f"({nupd} column updates), 1 thread of {ncpu} host cores")
+    return out
+
+
+def cpu_baseline_worker(args):
+    """Child process: no GPU is touched.  Rebuilds the same synthetic case on the host, times
+    the checker, writes JSON to the given file.  Keeps the Fortran runtime's stdout away from
+    the parent's single JSON line."""
+    ctx = lib.Context()                       # host-side domain logic only
+    dom, grid, state, ndte = build_case(ctx, args.workload, 0, 1)
+    tcols = None if args.no_thermo else thermo_case(dom)[1]
+    res = cpu_baseline(args.workload, grid, state, dom, ndte, tcols, args.cpu_seconds)
+    with open(args.cpu_baseline_worker, "w") as f:
+        json.dump(res, f)
+
+
+def run_cpu_baseline(args):
+    import subprocess
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".json", delete=False) as tf:
+        path = tf.name
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--cpu-seconds",
+           str(args.cpu_seconds), "--cpu-baseline-worker", path] + (["--no-thermo"] if args.no_thermo else [])
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, env=env)
+    with open(path) as f:
+        res = json.load(f)
+    os.unlink(path)
+    return res
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args)
+        return
+    rank, world, local, dist = init_dist(args.gpus)
+    try:
+        import torch
+        have_torch_gpu = torch.cuda.is_available()
+        if have_torch_gpu:
+            torch.cuda.set_device(local)
+    except Exception:
+        torch, have_torch_gpu = None, False
+
+    ctx = lib.Context(device=local)
+    ctx.sync()                       # fails loudly without a GPU / HIP library
+    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world)
+    if world > 1:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+    ctx.evp_init(grid, ndte=ndte)
+    nyl = dom["ny"] - 2
+    tile = args.tile_rows or (8 if dom["nxg"] * nyl <= 400 * 400 else 16)
+    ctx.evp_set_option("tile_rows", tile)
+    ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
+    ctx.evp_upload(state)
+    ctx.evp_prepare(DT)
+    nt, nu = ctx.evp_active_cells()
+
+    def sync_all():
+        ctx.sync()
+        if have_torch_gpu:
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        ctx.evp_subcycles(1, ndte)
+    sync_all()
+    t0 = time.perf_counter()
+    dev_ms = 0.0
+    for _ in range(args.steps):
+        dev_ms += ctx.evp_subcycles(1, ndte, timed=True)
+    sync_all()
+    t_evp = time.perf_counter() - t0
+    if dist is not None:
+        import torch as _t
+        tt = _t.tensor([t_evp, dev_ms], dtype=_t.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t_evp, dev_ms = float(tt[0]), float(tt[1])
+        cells = _t.tensor([nt, nu], dtype=_t.int64)
+        dist.all_reduce(cells, op=dist.ReduceOp.SUM)
+        nt_all, nu_all = int(cells[0]), int(cells[1])
+    else:
+        nt_all, nu_all = nt, nu
+    nsub_total = ndte * args.steps
+    value = nsub_total / t_evp
+
+    # ---- thermo (secondary figure): K batched passes, state restored before each (not timed)
+    thermo = None
+    tcols = None
+    if not args.no_thermo:
+        ctx.thermo_init()
+        tb, tcols = thermo_case(dom)
+        ctx.thermo_batch_alloc(dom["nx"], dom["ny"], dom["nblocks"])
+        t_ms, nupd = 0.0, 0
+        npass = max(2, min(args.steps, 10))
+        for p in range(npass + 1):
+            ctx.thermo_batch_upload(tb)
+            st = ctx.thermo_batch_step(DT, yday=150.0, timed=True)
+            if st["l_stop"]:
+                raise SystemExit(f"thermo step failed at i={st['istop']} j={st['jstop']} n={st['nstop']}")
+            if p > 0:   # first pass is warm-up
+                t_ms += st["ms"]; nupd += st["n_updates"]
+        if dist is not None:
+            import torch as _t
+            v = _t.tensor([t_ms / npass], dtype=_t.float64); dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            c = _t.tensor([nupd // npass], dtype=_t.int64); dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            ms_pass, upd_pass = float(v[0]), int(c[0])
+        else:
+            ms_pass, upd_pass = t_ms / npass, nupd // npass
+        rate = upd_pass / (ms_pass * 1e-3)
+        thermo = dict(metric="grid-cell-cat-updates/sec", value=rate, unit="(cell,category) updates/s",
+                      updates_per_pass=upd_pass, ms_per_pass=ms_pass, passes=npass,
+                      roofline=dict(bound="hbm", achieved=rate * THERMO_BYTES_PER_COLUMN / 1e9,
+                                    peak=HBM_PEAK_GBS, unit="GB/s",
+                                    frac=rate * THERMO_BYTES_PER_COLUMN / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                    kernel="k_thermo_dense",
+                                    bytes_per_unit=THERMO_BYTES_PER_COLUMN))
+
+    if rank == 0:
+        # dominant kernel: the fused subcycle kernel, one launch per subcycle over the rank's
+        # active T-cells; HIP-event time of the launches on the library's stream / launches
+        us_per_launch = dev_ms * 1e3 / nsub_total
+        bytes_per_launch = EVP_BYTES_PER_CELL * (nt_all / world)
+        achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+        out = {
+            "metric": "EVP subcycles/sec", "value": value, "unit": "subcycles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_evp / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": WORKLOADS[args.workload][3], "nx_global": dom["nxg"],
+                       "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
+                       "decomposition": f"1x{world} j-slabs, one block per GPU", "tile_rows": tile,
+                       "active_T_cells": nt_all, "active_U_cells": nu_all,
+                       "cell_subcycles_per_s": value * nt_all},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_subcycle (fused stress+stepu) + halo copy",
+                         "us_per_launch": us_per_launch, "bytes_per_unit": EVP_BYTES_PER_CELL,
+                         "units_per_launch": nt_all / world},
+        }
+        if thermo:
+            out["thermo"] = thermo
+        if world == 1 and not args.no_cpu_baseline:
+            cb = run_cpu_baseline(args)
+            out["cpu_baseline"] = dict(cb["evp"])
+            if "thermo" in cb and thermo:
+                out["thermo"]["cpu_baseline"] = cb["thermo"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,551 @@
+// C-ABI of libcice4_amd.so (include/cice4_amd.h).  Exceptions never cross the
+// boundary: every entry returns a status code and records the message.
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "common.h"
+#include "domain.h"
+#include "evp.h"
+#include "halo.h"
+#include "therm.h"
+
+using namespace cice;
+
+struct cice_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  Domain dom;
+  bool have_domain = false;
+  std::unique_ptr<Halo> halo;
+  std::unique_ptr<Evp> evp;
+  // thermo
+  ThermoParams tp{};
+  bool have_thermo = false;
+  DevBuf<unsigned long long> tkey;  // [0] error key, [1] update counter
+  // batched thermo state
+  struct Batch {
+    int nx = 0, ny = 0, nb = 0;
+    DevBuf<int32_t> blk;
+    DevBuf<double> aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot,
+        lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, out15, mlt_onset, frz_onset;
+  } tb;
+  // device is required lazily: domain queries work on a CPU-only host
+  void need_device() {
+    if (stream) return;
+    int cnt = 0;
+    CICE_HIP(hipGetDeviceCount(&cnt));
+    if (cnt < 1) throw Error{CICE_EDEVICE, "no HIP device visible"};
+    if (device >= 0) CICE_HIP(hipSetDevice(device));
+    else CICE_HIP(hipGetDevice(&device));
+    CICE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  }
+  void need_halo() {
+    need_device();
+    if (!halo) {
+      CICE_REQUIRE(have_domain, "cice_domain_create has not been called");
+      halo.reset(new Halo());
+      halo->init(dom, stream);
+    }
+  }
+};
+
+static std::string g_create_err;
+
+#define CICE_TRY(ctx_) \
+  cice_ctx* c_ = (ctx_); \
+  if (!c_) return CICE_EINVAL; \
+  try {
+#define CICE_CATCH                                            \
+  }                                                           \
+  catch (const Error& e) {                                    \
+    c_->err = e.msg;                                          \
+    return e.code;                                            \
+  }                                                           \
+  catch (const std::exception& e) {                           \
+    c_->err = e.what();                                       \
+    return CICE_EINVAL;                                       \
+  }                                                           \
+  return CICE_OK;
+
+template <class T>
+static void halo_host(cice_ctx* c, T* field, int nlev) {
+  c->need_halo();
+  CICE_REQUIRE(field && nlev >= 1, "bad argument");
+  const size_t n = (size_t)c->dom.nblocks() * c->dom.nx_block * c->dom.ny_block;
+  DevBuf<T> d;
+  d.alloc(n * nlev);
+  d.upload(field, c->stream);
+  for (int k = 0; k < nlev; k += 4) {
+    const int nf = std::min(4, nlev - k);
+    if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(d.p) + (size_t)k * n, nf, n);
+    else c->halo->update_i4(reinterpret_cast<int32_t*>(d.p) + (size_t)k * n, nf, n);
+  }
+  d.download(field, c->stream);
+  CICE_HIP(hipStreamSynchronize(c->stream));
+}
+
+extern "C" {
+
+int cice_create(cice_ctx** ctx, int device) {
+  if (!ctx) return CICE_EINVAL;
+  try {
+    *ctx = new cice_ctx();
+    (*ctx)->device = device;
+  } catch (const std::exception& e) {
+    g_create_err = e.what();
+    return CICE_EINVAL;
+  }
+  return CICE_OK;
+}
+
+int cice_destroy(cice_ctx* ctx) {
+  if (!ctx) return CICE_EINVAL;
+  ctx->evp.reset();
+  ctx->halo.reset();
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return CICE_OK;
+}
+
+const char* cice_last_error(const cice_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int cice_device_sync(cice_ctx* ctx) {
+  CICE_TRY(ctx)
+  c_->need_device();
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_CATCH
+}
+
+// ---- domain ---------------------------------------------------------------------------------
+int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew, int ns, int rank,
+                       int npx, int npy) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 2, "boundary type must be 0 (open), 1 (cyclic) or 2 (closed)");
+  const char* msg = c_->dom.create(nxg, nyg, bsx, bsy, ew, ns, rank, npx, npy);
+  if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create: ") + msg};
+  c_->have_domain = true;
+  c_->evp.reset();
+  c_->halo.reset();
+  CICE_CATCH
+}
+
+int cice_domain_info(const cice_ctx* ctx, int info[9]) {
+  if (!ctx || !info || !ctx->have_domain) return CICE_EINVAL;
+  const Domain& d = ctx->dom;
+  int ns = 0, nr = 0;
+  for (const HaloMsg& m : d.send) ns += (int)m.addr.size();
+  for (const HaloMsg& m : d.recv) nr += (int)m.addr.size();
+  const int v[9] = {d.nx_block, d.ny_block, d.nblocks(), (int)d.all.size(), (int)d.hsrc.size(),
+                    (int)d.send.size(), (int)d.recv.size(), ns, nr};
+  std::memcpy(info, v, sizeof(v));
+  return CICE_OK;
+}
+
+int cice_domain_block(const cice_ctx* ctx, int lb, int info[8]) {
+  if (!ctx || !info || !ctx->have_domain || lb < 0 || lb >= ctx->dom.nblocks()) return CICE_EINVAL;
+  const Block& b = ctx->dom.all[ctx->dom.local[lb]];
+  const int v[8] = {b.ilo, b.ihi, b.jlo, b.jhi, b.i0, b.j0, b.gid, b.owner};
+  std::memcpy(info, v, sizeof(v));
+  return CICE_OK;
+}
+
+int cice_domain_halo_local(const cice_ctx* ctx, int32_t* src, int32_t* dst) {
+  if (!ctx || !ctx->have_domain || !src || !dst) return CICE_EINVAL;
+  const Domain& d = ctx->dom;
+  if (!d.hsrc.empty()) {
+    std::memcpy(src, d.hsrc.data(), d.hsrc.size() * 4);
+    std::memcpy(dst, d.hdst.data(), d.hdst.size() * 4);
+  }
+  return CICE_OK;
+}
+
+int cice_domain_halo_msg(const cice_ctx* ctx, int dir, int msg, int* peer, int* count, int32_t* addr) {
+  if (!ctx || !ctx->have_domain) return CICE_EINVAL;
+  const std::vector<HaloMsg>& v = dir ? ctx->dom.recv : ctx->dom.send;
+  if (msg < 0 || msg >= (int)v.size()) return CICE_EINVAL;
+  if (peer) *peer = v[msg].peer;
+  if (count) *count = (int)v[msg].addr.size();
+  if (addr) std::memcpy(addr, v[msg].addr.data(), v[msg].addr.size() * 4);
+  return CICE_OK;
+}
+
+// ---- communication ---------------------------------------------------------------------------
+int cice_comm_unique_id(char uid[128]) {
+  if (!uid) return CICE_EINVAL;
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return CICE_ECOMM;
+  std::memcpy(uid, &id, 128);
+  return CICE_OK;
+}
+
+int cice_comm_init(cice_ctx* ctx, const char uid[128], int rank, int nranks) {
+  CICE_TRY(ctx)
+  c_->need_halo();
+  c_->halo->comm_init(uid, rank, nranks);
+  CICE_CATCH
+}
+
+// ---- EVP -------------------------------------------------------------------------------------
+int cice_evp_init(cice_ctx* ctx, const cice_evp_config* cfg, const cice_evp_grid* grid) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(cfg && grid, "NULL argument");
+  c_->need_halo();
+  c_->evp.reset(new Evp(c_->dom, *c_->halo, c_->stream));
+  c_->evp->init(*cfg, *grid);
+  CICE_CATCH
+}
+
+#define NEED_EVP CICE_REQUIRE(c_->evp != nullptr, "cice_evp_init has not been called")
+
+int cice_evp_upload(cice_ctx* ctx, const cice_evp_fields* f) {
+  CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->upload(*f); CICE_CATCH
+}
+int cice_evp_download(cice_ctx* ctx, cice_evp_fields* f) {
+  CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->download(*f); CICE_CATCH
+}
+int cice_evp_step(cice_ctx* ctx, double dt) { CICE_TRY(ctx) NEED_EVP; c_->evp->step(dt); CICE_CATCH }
+int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(f, "NULL argument");
+  c_->evp->upload(*f);
+  c_->evp->step(dt);
+  c_->evp->download(*f);
+  CICE_CATCH
+}
+int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) NEED_EVP; c_->evp->prepare(dt); CICE_CATCH }
+int cice_evp_subcycles(cice_ctx* ctx, int ksub0, int nsub, float* ms) {
+  CICE_TRY(ctx) NEED_EVP; c_->evp->subcycles(ksub0, nsub, ms); CICE_CATCH
+}
+int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) NEED_EVP; c_->evp->finish(); CICE_CATCH }
+int cice_evp_set_option(cice_ctx* ctx, const char* key, int value) {
+  CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(key, "NULL key"); c_->evp->set_option(key, value); CICE_CATCH
+}
+int cice_evp_active_cells(cice_ctx* ctx, long long* nt, long long* nu) {
+  CICE_TRY(ctx) NEED_EVP; c_->evp->active_cells(nt, nu); CICE_CATCH
+}
+
+int cice_evp_stress(cice_ctx* ctx, double dt, int ndte, int damping, int nx, int ny, int ksub,
+                    int icellt, const int32_t* ti, const int32_t* tj, const double* uvel,
+                    const double* vvel, const double* dxt, const double* dyt, const double* dxhy,
+                    const double* dyhx, const double* cxp, const double* cyp, const double* cxm,
+                    const double* cym, const double* tarear, const double* tinyarea,
+                    const double* strength, double* sp1, double* sp2, double* sp3, double* sp4,
+                    double* sm1, double* sm2, double* sm3, double* sm4, double* s121, double* s122,
+                    double* s123, double* s124, double* shear, double* divu, double* prs_sig,
+                    double* rdg_conv, double* rdg_shear, double* str) {
+  CICE_TRY(ctx)
+  c_->need_device();
+  const double* g10[10] = {dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, tinyarea};
+  double* sg[12] = {sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124};
+  double* dg[5] = {shear, divu, prs_sig, rdg_conv, rdg_shear};
+  CICE_REQUIRE(nx >= 3 && ny >= 3 && ndte >= 1, "bad dimensions");
+  Evp::stress_host(c_->stream, dt, ndte, damping, nx, ny, ksub, icellt, ti, tj, uvel, vvel, g10,
+                   strength, sg, dg, str);
+  CICE_CATCH
+}
+
+int cice_evp_stepu(cice_ctx* ctx, int nx, int ny, int icellu, const int32_t* ui, const int32_t* uj,
+                   const double* aiu, const double* str, const double* uocn, const double* vocn,
+                   const double* waterx, const double* watery, const double* forcex,
+                   const double* forcey, const double* umassdtei, const double* fm,
+                   const double* uarear, double* strocnx, double* strocny, double* strintx,
+                   double* strinty, double* uvel, double* vvel) {
+  CICE_TRY(ctx)
+  c_->need_device();
+  const double* in10[10] = {aiu, uocn, vocn, waterx, watery, forcex, forcey, umassdtei, fm, uarear};
+  double* io6[6] = {strocnx, strocny, strintx, strinty, uvel, vvel};
+  CICE_REQUIRE(nx >= 3 && ny >= 3, "bad dimensions");
+  Evp::stepu_host(c_->stream, nx, ny, icellu, ui, uj, in10, str, io6);
+  CICE_CATCH
+}
+
+int cice_halo_update_r8(cice_ctx* ctx, double* field, int nlev) {
+  CICE_TRY(ctx) halo_host<double>(c_, field, nlev); CICE_CATCH
+}
+int cice_halo_update_i4(cice_ctx* ctx, int32_t* field, int nlev) {
+  CICE_TRY(ctx) halo_host<int32_t>(c_, field, nlev); CICE_CATCH
+}
+
+// ---- thermodynamics --------------------------------------------------------------------------
+int cice_thermo_init(cice_ctx* ctx, const cice_thermo_config* cfg, double* salin, double* Tmlt) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(cfg, "NULL argument");
+  CICE_REQUIRE(cfg->conduct == 0 || cfg->conduct == 1, "conduct must be 0 (MU71) or 1 (bubbly)");
+  CICE_REQUIRE(cfg->nt_Tsfc >= 1 && cfg->nt_Tsfc <= NTRCR, "nt_Tsfc out of range");
+  if (!cfg->heat_capacity || !cfg->calc_Tsfc)
+    throw Error{CICE_EUNSUPPORTED, "only heat_capacity = T, calc_Tsfc = T is implemented on the device"};
+  c_->tp.init(*cfg);
+  c_->have_thermo = true;
+  if (salin) std::memcpy(salin, c_->tp.salin, sizeof(c_->tp.salin));
+  if (Tmlt) std::memcpy(Tmlt, c_->tp.Tmlt, sizeof(c_->tp.Tmlt));
+  CICE_CATCH
+}
+
+static void decode_err(unsigned long long key, int nx, int ncat, const int32_t* indxi,
+                       const int32_t* indxj, int32_t* l_stop, int32_t* istop, int32_t* jstop,
+                       int32_t* nstop, int32_t* bstop) {
+  *l_stop = 0; *istop = 0; *jstop = 0;
+  if (nstop) *nstop = 0;
+  if (bstop) *bstop = 0;
+  if (key == ~0ull) return;
+  *l_stop = 1;
+  const unsigned long long order = key & ((1ull << 40) - 1);
+  const unsigned long long cb = key >> 44;
+  if (indxi) {
+    *istop = indxi[order];
+    *jstop = indxj[order];
+  } else {
+    *jstop = (int32_t)(order / nx) + 1;
+    *istop = (int32_t)(order % nx) + 1;
+  }
+  if (nstop) *nstop = (int32_t)(cb % ncat) + 1;
+  if (bstop) *bstop = (int32_t)(cb / ncat) + 1;
+}
+
+int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, const int32_t* indxi,
+                         const int32_t* indxj, double* aicen, double* trcrn, double* vicen,
+                         double* vsnon, double* eicen, double* esnon, const double* flw,
+                         const double* potT, const double* Qa, const double* rhoa,
+                         const double* fsnow, const double* fbot, const double* Tbot,
+                         const double* lhcoef, const double* shcoef, double* fswsfc, double* fswint,
+                         double* fswthrun, double* Sswabs, double* Iswabs, double* fsurfn,
+                         double* fcondtopn, double* fsensn, double* flatn, double* fswabsn,
+                         double* flwoutn, double* evapn, double* freshn, double* fsaltn,
+                         double* fhocnn, double* meltt, double* melts, double* meltb, double* congel,
+                         double* snoice, double* mlt_onset, double* frz_onset, double yday,
+                         int32_t* l_stop, int32_t* istop, int32_t* jstop) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
+  CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
+  CICE_REQUIRE(nx >= 1 && ny >= 1, "bad dimensions");
+  const size_t np = (size_t)nx * ny;
+  CICE_REQUIRE(icells >= 0 && (size_t)icells <= np, "icells out of range");
+  for (int e = 0; e < icells; ++e)
+    CICE_REQUIRE(indxi[e] >= 1 && indxi[e] <= nx && indxj[e] >= 1 && indxj[e] <= ny,
+                 "thermo_vertical: index outside block");
+  c_->need_device();
+  hipStream_t s = c_->stream;
+  // plane map of the single staging buffer
+  enum { A_AICEN = 0, A_TRCRN = 1, A_VICEN = A_TRCRN + NTRCR, A_VSNON, A_EICEN, A_ESNON = A_EICEN + NILYR,
+         A_FLW = A_ESNON + NSLYR, A_POTT, A_QA, A_RHOA, A_FSNOW, A_FBOT, A_TBOT, A_LH, A_SH, A_FSWSFC,
+         A_FSWINT, A_FSWTHRU, A_SSW, A_ISW = A_SSW + NSLYR, A_OUT = A_ISW + NILYR, A_MLT = A_OUT + 15,
+         A_FRZ, A_END };
+  DevBuf<double> d;
+  d.alloc((size_t)A_END * np);
+  DevBuf<int32_t> li;
+  li.alloc(2 * np);
+  auto up = [&](int plane, const double* h, int planes = 1) {
+    CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
+    CICE_HIP(hipMemcpyAsync(d.p + (size_t)plane * np, h, (size_t)planes * np * 8, hipMemcpyHostToDevice, s));
+  };
+  up(A_AICEN, aicen); up(A_TRCRN, trcrn, NTRCR); up(A_VICEN, vicen); up(A_VSNON, vsnon);
+  up(A_EICEN, eicen, NILYR); up(A_ESNON, esnon, NSLYR);
+  up(A_FLW, flw); up(A_POTT, potT); up(A_QA, Qa); up(A_RHOA, rhoa); up(A_FSNOW, fsnow);
+  up(A_FBOT, fbot); up(A_TBOT, Tbot); up(A_LH, lhcoef); up(A_SH, shcoef);
+  up(A_FSWSFC, fswsfc); up(A_FSWINT, fswint); up(A_FSWTHRU, fswthrun);
+  up(A_SSW, Sswabs, NSLYR); up(A_ISW, Iswabs, NILYR);
+  up(A_MLT, mlt_onset); up(A_FRZ, frz_onset);
+  if (icells) {
+    CICE_HIP(hipMemcpyAsync(li.p, indxi, (size_t)icells * 4, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, s));
+  }
+  c_->tkey.alloc(2);
+  CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
+  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+  ThermoArgs a{};
+  a.p = c_->tp; a.nx = nx; a.ny = ny; a.ncat = 1; a.nblocks = 1; a.dt = dt; a.yday = yday;
+  a.icells = icells; a.indxi = li.p; a.indxj = li.p + np; a.blk = nullptr;
+  auto P = [&](int plane) { return d.p + (size_t)plane * np; };
+  a.aicen = P(A_AICEN); a.trcrn = P(A_TRCRN); a.vicen = P(A_VICEN); a.vsnon = P(A_VSNON);
+  a.eicen = P(A_EICEN); a.esnon = P(A_ESNON); a.flw = P(A_FLW); a.potT = P(A_POTT); a.Qa = P(A_QA);
+  a.rhoa = P(A_RHOA); a.fsnow = P(A_FSNOW); a.fbot = P(A_FBOT); a.Tbot = P(A_TBOT);
+  a.lhcoef = P(A_LH); a.shcoef = P(A_SH); a.fswsfc = P(A_FSWSFC); a.fswint = P(A_FSWINT);
+  a.fswthrun = P(A_FSWTHRU); a.Sswabs = P(A_SSW); a.Iswabs = P(A_ISW);
+  double** outs[15] = {&a.fsurfn, &a.fcondtopn, &a.fsensn, &a.flatn, &a.fswabsn, &a.flwoutn, &a.evapn,
+                       &a.freshn, &a.fsaltn, &a.fhocnn, &a.meltt, &a.melts, &a.meltb, &a.congel,
+                       &a.snoice};
+  for (int k = 0; k < 15; ++k) *outs[k] = P(A_OUT + k);
+  a.mlt_onset = P(A_MLT); a.frz_onset = P(A_FRZ);
+  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+  thermo_launch_list(a, s);
+  auto down = [&](int plane, double* h, int planes = 1) {
+    CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
+    CICE_HIP(hipMemcpyAsync(h, d.p + (size_t)plane * np, (size_t)planes * np * 8, hipMemcpyDeviceToHost, s));
+  };
+  down(A_AICEN, aicen); down(A_TRCRN, trcrn, NTRCR); down(A_VICEN, vicen); down(A_VSNON, vsnon);
+  down(A_EICEN, eicen, NILYR); down(A_ESNON, esnon, NSLYR);
+  down(A_FSWSFC, fswsfc); down(A_FSWINT, fswint); down(A_SSW, Sswabs, NSLYR); down(A_ISW, Iswabs, NILYR);
+  double* houts[15] = {fsurfn, fcondtopn, fsensn, flatn, fswabsn, flwoutn, evapn, freshn, fsaltn,
+                       fhocnn, meltt, melts, meltb, congel, snoice};
+  for (int k = 0; k < 15; ++k) down(A_OUT + k, houts[k]);
+  down(A_MLT, mlt_onset); down(A_FRZ, frz_onset);
+  unsigned long long key = 0;
+  CICE_HIP(hipMemcpyAsync(&key, c_->tkey.p, 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  decode_err(key, nx, 1, indxi, indxj, l_stop, istop, jstop, nullptr, nullptr);
+  CICE_CATCH
+}
+
+int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(nx >= 3 && ny >= 3 && nb >= 1, "bad dimensions");
+  c_->need_device();
+  auto& t = c_->tb;
+  t.nx = nx; t.ny = ny; t.nb = nb;
+  const size_t np = (size_t)nx * ny, n2 = np * nb, nc = n2 * NCAT;
+  std::vector<int32_t> hb;
+  if (c_->have_domain && c_->dom.nblocks() == nb && c_->dom.nx_block == nx && c_->dom.ny_block == ny) {
+    for (int gid : c_->dom.local) {
+      const Block& b = c_->dom.all[gid];
+      hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi});
+    }
+  } else {
+    for (int b = 0; b < nb; ++b) hb.insert(hb.end(), {2, nx - 1, 2, ny - 1});
+  }
+  t.blk.alloc(hb.size());
+  t.blk.upload(hb.data(), c_->stream);
+  t.aicen.alloc(nc); t.trcrn.alloc(nc * NTRCR); t.vicen.alloc(nc); t.vsnon.alloc(nc);
+  t.eicen.alloc(nc * NILYR); t.esnon.alloc(nc * NSLYR);
+  for (DevBuf<double>* d : {&t.flw, &t.potT, &t.Qa, &t.rhoa, &t.fsnow, &t.fbot, &t.Tbot, &t.mlt_onset,
+                            &t.frz_onset})
+    d->alloc(n2);
+  for (DevBuf<double>* d : {&t.lhcoef, &t.shcoef, &t.fswsfc, &t.fswint, &t.fswthrun}) d->alloc(nc);
+  t.Sswabs.alloc(nc * NSLYR); t.Iswabs.alloc(nc * NILYR);
+  t.out15.alloc(nc * 15);
+  t.out15.zero(c_->stream);
+  c_->tkey.alloc(2);
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_CATCH
+}
+
+int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
+  CICE_TRY(ctx)
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
+  struct U { DevBuf<double>* d; const double* h; };
+  U us[] = {{&t.aicen, h->aicen}, {&t.trcrn, h->trcrn}, {&t.vicen, h->vicen}, {&t.vsnon, h->vsnon},
+            {&t.eicen, h->eicen}, {&t.esnon, h->esnon}, {&t.flw, h->flw}, {&t.potT, h->potT},
+            {&t.Qa, h->Qa}, {&t.rhoa, h->rhoa}, {&t.fsnow, h->fsnow}, {&t.fbot, h->fbot},
+            {&t.Tbot, h->Tbot}, {&t.lhcoef, h->lhcoef}, {&t.shcoef, h->shcoef}, {&t.fswsfc, h->fswsfc},
+            {&t.fswint, h->fswint}, {&t.fswthrun, h->fswthrun}, {&t.Sswabs, h->Sswabs},
+            {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset}, {&t.frz_onset, h->frz_onset}};
+  for (U& x : us) {
+    CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
+    x.d->upload(x.h, c_->stream);
+  }
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_CATCH
+}
+
+int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_updates,
+                           int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
+                           int32_t* bstop, float* elapsed_ms) {
+  CICE_TRY(ctx)
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
+  CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
+  CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
+  hipStream_t s = c_->stream;
+  const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
+  CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
+  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+  ThermoArgs a{};
+  a.p = c_->tp; a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.dt = dt; a.yday = yday;
+  a.icells = 0; a.indxi = nullptr; a.indxj = nullptr; a.blk = t.blk.p;
+  a.aicen = t.aicen.p; a.trcrn = t.trcrn.p; a.vicen = t.vicen.p; a.vsnon = t.vsnon.p;
+  a.eicen = t.eicen.p; a.esnon = t.esnon.p; a.flw = t.flw.p; a.potT = t.potT.p; a.Qa = t.Qa.p;
+  a.rhoa = t.rhoa.p; a.fsnow = t.fsnow.p; a.fbot = t.fbot.p; a.Tbot = t.Tbot.p;
+  a.lhcoef = t.lhcoef.p; a.shcoef = t.shcoef.p; a.fswsfc = t.fswsfc.p; a.fswint = t.fswint.p;
+  a.fswthrun = t.fswthrun.p; a.Sswabs = t.Sswabs.p; a.Iswabs = t.Iswabs.p;
+  double** outs[15] = {&a.fsurfn, &a.fcondtopn, &a.fsensn, &a.flatn, &a.fswabsn, &a.flwoutn, &a.evapn,
+                       &a.freshn, &a.fsaltn, &a.fhocnn, &a.meltt, &a.melts, &a.meltb, &a.congel,
+                       &a.snoice};
+  for (int k = 0; k < 15; ++k) *outs[k] = t.out15.p + (size_t)k * nc;
+  a.mlt_onset = t.mlt_onset.p; a.frz_onset = t.frz_onset.p;
+  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (elapsed_ms) {
+    CICE_HIP(hipEventCreate(&e0));
+    CICE_HIP(hipEventCreate(&e1));
+    CICE_HIP(hipEventRecord(e0, s));
+  }
+  thermo_launch_dense(a, s);
+  if (elapsed_ms) CICE_HIP(hipEventRecord(e1, s));
+  unsigned long long h[2];
+  CICE_HIP(hipMemcpyAsync(h, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  if (elapsed_ms) {
+    CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+  if (n_updates) *n_updates = (long long)h[1];
+  decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
+  CICE_CATCH
+}
+
+int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
+  CICE_TRY(ctx)
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
+  hipStream_t s = c_->stream;
+  const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
+  struct D { const DevBuf<double>* d; double* h; };
+  D ds[] = {{&t.aicen, h->aicen}, {&t.trcrn, h->trcrn}, {&t.vicen, h->vicen}, {&t.vsnon, h->vsnon},
+            {&t.eicen, h->eicen}, {&t.esnon, h->esnon}, {&t.fswsfc, h->fswsfc}, {&t.fswint, h->fswint},
+            {&t.Sswabs, h->Sswabs}, {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset},
+            {&t.frz_onset, h->frz_onset}};
+  for (D& x : ds)
+    if (x.h) x.d->download(x.h, s);
+  double* houts[15] = {h->fsurfn, h->fcondtopn, h->fsensn, h->flatn, h->fswabsn, h->flwoutn, h->evapn,
+                       h->freshn, h->fsaltn, h->fhocnn, h->meltt, h->melts, h->meltb, h->congel,
+                       h->snoice};
+  for (int k = 0; k < 15; ++k)
+    if (houts[k])
+      CICE_HIP(hipMemcpyAsync(houts[k], t.out15.p + (size_t)k * nc, nc * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  CICE_CATCH
+}
+
+int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, int jlo, int jhi,
+                               double dt, const double* aice, const double* frzmlt,
+                               const double* eicen, const double* esnon, const double* sst,
+                               const double* Tf, const double* strocnxT, const double* strocnyT,
+                               double* Tbot, double* fbot, double* rside) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
+  CICE_REQUIRE(nx >= 1 && ny >= 1 && ilo >= 1 && ihi <= nx && jlo >= 1 && jhi <= ny, "bad dimensions");
+  c_->need_device();
+  hipStream_t s = c_->stream;
+  const size_t np = (size_t)nx * ny;
+  const int NE = NCAT * NILYR, NSN = NCAT * NSLYR;
+  DevBuf<double> d;
+  d.alloc((size_t)(9 + NE + NSN) * np);
+  auto up = [&](size_t plane, const double* h, size_t planes = 1) {
+    CICE_REQUIRE(h != nullptr, "frzmlt_bottom_lateral: NULL array");
+    CICE_HIP(hipMemcpyAsync(d.p + plane * np, h, planes * np * 8, hipMemcpyHostToDevice, s));
+  };
+  up(0, aice); up(1, frzmlt); up(2, sst); up(3, Tf); up(4, strocnxT); up(5, strocnyT);
+  up(9, eicen, NE); up(9 + NE, esnon, NSN);
+  FrzmltArgs a{};
+  a.nx = nx; a.ny = ny; a.ilo = ilo; a.ihi = ihi; a.jlo = jlo; a.jhi = jhi; a.dt = dt;
+  a.ustar_min = c_->tp.ustar_min;
+  a.aice = d.p; a.frzmlt = d.p + np; a.sst = d.p + 2 * np; a.Tf = d.p + 3 * np;
+  a.strocnxT = d.p + 4 * np; a.strocnyT = d.p + 5 * np;
+  a.Tbot = d.p + 6 * np; a.fbot = d.p + 7 * np; a.rside = d.p + 8 * np;
+  a.eicen = d.p + 9 * np; a.esnon = d.p + (size_t)(9 + NE) * np;
+  frzmlt_launch(a, s);
+  CICE_REQUIRE(Tbot && fbot && rside, "frzmlt_bottom_lateral: NULL output");
+  CICE_HIP(hipMemcpyAsync(Tbot, a.Tbot, np * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipMemcpyAsync(fbot, a.fbot, np * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipMemcpyAsync(rside, a.rside, np * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  CICE_CATCH
+}
+
+}  // extern "C"

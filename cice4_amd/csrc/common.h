@@ -1,0 +1,87 @@
+// Shared definitions for the HIP hot path (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+
+#include "../../include/cice4_amd.h"
+
+namespace cice {
+
+// drivers/cice4/ice_constants.F90:49-121,132-179 (CICE default parameter set)
+namespace K {
+constexpr double rhos = 330.0, rhoi = 917.0, rhow = 1026.0;
+constexpr double cp_ice = 2106.0, cp_ocn = 4218.0, depressT = 0.054, emissivity = 0.95;
+constexpr double dragio = 0.00536, gravit = 9.80616;
+constexpr double pi = 3.14159265358979323846;
+constexpr double stefan_boltzmann = 567.0e-10, Tffresh = 273.15, Lsub = 2.835e6, Lvap = 2.501e6;
+constexpr double Lfresh = Lsub - Lvap;
+constexpr double ice_ref_salinity = 4.0;
+constexpr double kice = 2.03, ksno = 0.30;
+constexpr double qqqice = 11637800.0, TTTice = 5897.8;
+constexpr double puny = 1.0e-11;
+constexpr double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0, p5 = 0.5, p25 = 0.25, p1 = 0.1,
+                 p001 = 0.001;
+constexpr double p166 = 1.0 / 6.0, p333 = 1.0 / 3.0, p111 = 1.0 / 9.0, p222 = 2.0 / 9.0;
+constexpr double p055 = p111 * 0.5, p027 = p055 * 0.5;  // halved, not 1/18, 1/36 (:170-171)
+// source/ice_dyn_evp.F90:76-88
+constexpr double dragw = dragio * rhow, eyc = 0.36, cosw = 1.0, sinw = 0.0, a_min = 0.001,
+                 m_min = 0.01;
+// source/ice_therm_vertical.F90:45-49,64-65
+constexpr double saltmax = 3.2, hs_min = 1.0e-4, betak = 0.13, kimin = 0.10, ferrmax = 1.0e-3;
+}  // namespace K
+
+constexpr int NCAT = CICE_NCAT, NILYR = CICE_NILYR, NSLYR = CICE_NSLYR, NTRCR = CICE_MAX_NTRCR;
+
+struct Error {
+  int code;
+  std::string msg;
+};
+
+#define CICE_HIP(expr)                                                                      \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      throw ::cice::Error{CICE_EDEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)}; \
+  } while (0)
+
+#define CICE_REQUIRE(cond, text) \
+  do {                           \
+    if (!(cond)) throw ::cice::Error{CICE_EINVAL, text}; \
+  } while (0)
+
+// RAII device buffer
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+  }
+  void alloc(size_t count) {
+    if (count == n && p) return;
+    release();
+    if (count == 0) return;
+    CICE_HIP(hipMalloc((void**)&p, count * sizeof(T)));
+    n = count;
+  }
+  void zero(hipStream_t s) {
+    if (p) CICE_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+  }
+  void upload(const T* h, hipStream_t s) {
+    CICE_HIP(hipMemcpyAsync(p, h, n * sizeof(T), hipMemcpyHostToDevice, s));
+  }
+  void download(T* h, hipStream_t s) const {
+    CICE_HIP(hipMemcpyAsync(h, p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+};
+
+}  // namespace cice

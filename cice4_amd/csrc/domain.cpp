@@ -1,0 +1,88 @@
+#include "domain.h"
+
+#include <algorithm>
+#include <map>
+
+namespace cice {
+
+namespace {
+
+// global index of a ghost position, or -1 when it falls outside an open/closed edge
+inline int wrap(int g, int n, int bnd) {
+  if (g >= 0 && g < n) return g;
+  if (bnd != BND_CYCLIC) return -1;
+  return (g + n) % n;
+}
+
+}  // namespace
+
+const char* Domain::create(int nx_global, int ny_global, int block_size_x, int block_size_y,
+                           int ew_bnd, int ns_bnd, int rank_, int npx_, int npy_) {
+  if (nx_global < 1 || ny_global < 1) return "domain size < 1";
+  if (block_size_x < 1 || block_size_y < 1) return "block size < 1";
+  if (npx_ < 1 || npy_ < 1) return "process grid < 1";
+  nxg = nx_global; nyg = ny_global; bsx = block_size_x; bsy = block_size_y;
+  nx_block = bsx + 2; ny_block = bsy + 2;
+  nbx = (nxg - 1) / bsx + 1;  // ice_blocks.F90:158-160
+  nby = (nyg - 1) / bsy + 1;
+  npx = npx_; npy = npy_; nranks = npx * npy; rank = rank_;
+  ew = ew_bnd; ns = ns_bnd;
+  if (rank < 0 || rank >= nranks) return "rank out of range";
+  if (npx > nbx || npy > nby) return "more ranks than blocks along an axis";
+  all.clear(); local.clear(); hsrc.clear(); hdst.clear(); send.clear(); recv.clear();
+
+  std::vector<int> nlocal(nranks, 0);
+  for (int jb = 0; jb < nby; ++jb)
+    for (int ib = 0; ib < nbx; ++ib) {
+      Block b;
+      b.gid = jb * nbx + ib; b.ib = ib; b.jb = jb;
+      b.i0 = ib * bsx; b.j0 = jb * bsy;
+      b.ilo = 2; b.jlo = 2;
+      b.ihi = 1 + std::min(bsx, nxg - b.i0);  // padded last block: ice_blocks.F90:171-178
+      b.jhi = 1 + std::min(bsy, nyg - b.j0);
+      // contiguous rectangles of blocks per rank (cartesian distribution)
+      int px = (int)((long long)ib * npx / nbx), py = (int)((long long)jb * npy / nby);
+      b.owner = py * npx + px;
+      b.local_id = nlocal[b.owner]++;
+      all.push_back(b);
+    }
+  for (const Block& b : all)
+    if (b.owner == rank) local.push_back(b.gid);
+
+  const long long np = (long long)nx_block * ny_block;
+  if (np * (long long)std::max<size_t>(local.size(), 1) > 0x7fffffffLL) return "local array too large for int32 addressing";
+  auto addr = [&](const Block& b, int i, int j) {  // 1-based (i,j)
+    return (int32_t)((long long)b.local_id * np + (long long)(j - 1) * nx_block + (i - 1));
+  };
+
+  std::map<int, HaloMsg> smap, rmap;
+  // Visit every ghost cell of every block in one global order; both ends of a message
+  // therefore agree on element order.
+  for (const Block& d : all) {
+    for (int j = d.jlo - 1; j <= d.jhi + 1; ++j)
+      for (int i = d.ilo - 1; i <= d.ihi + 1; ++i) {
+        const bool ghost = (i < d.ilo || i > d.ihi || j < d.jlo || j > d.jhi);
+        if (!ghost) continue;
+        int ig = wrap(d.i0 + (i - d.ilo), nxg, ew);
+        int jg = wrap(d.j0 + (j - d.jlo), nyg, ns);
+        if (ig < 0 || jg < 0) continue;  // beyond an open/closed edge: never written
+        const Block& s = all[(jg / bsy) * nbx + (ig / bsx)];
+        int is = s.ilo + (ig - s.i0), js = s.jlo + (jg - s.j0);
+        if (d.owner == rank && s.owner == rank) {
+          hsrc.push_back(addr(s, is, js));
+          hdst.push_back(addr(d, i, j));
+        } else if (d.owner == rank) {
+          HaloMsg& m = rmap[s.owner]; m.peer = s.owner;
+          m.addr.push_back(addr(d, i, j));
+        } else if (s.owner == rank) {
+          HaloMsg& m = smap[d.owner]; m.peer = d.owner;
+          m.addr.push_back(addr(s, is, js));
+        }
+      }
+  }
+  for (auto& kv : smap) send.push_back(std::move(kv.second));
+  for (auto& kv : rmap) recv.push_back(std::move(kv.second));
+  return "";
+}
+
+}  // namespace cice

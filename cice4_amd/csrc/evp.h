@@ -1,0 +1,85 @@
+// Device-resident EVP dynamics: state, kernels' launch wrappers.
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "domain.h"
+#include "halo.h"
+
+namespace cice {
+
+struct EvpScalars {  // set_evp_parameters, ice_dyn_evp.F90:535-577
+  double dtei, dte2T, denom1, denom2, rcon, ecci;
+  int ndte, evp_damping;
+  void set(double dt, int ndte_, int damping);
+};
+
+class Evp {
+ public:
+  Evp(const Domain& d, Halo& h, hipStream_t s) : dom(d), halo(h), stream(s) {}
+  ~Evp();
+  void init(const cice_evp_config& cfg, const cice_evp_grid& g);
+  void upload(const cice_evp_fields& f);
+  void download(cice_evp_fields& f);
+  void prepare(double dt);
+  void subcycles(int ksub0, int nsub, float* elapsed_ms);
+  void finish();
+  void step(double dt) {
+    prepare(dt);
+    subcycles(1, sc.ndte, nullptr);
+    finish();
+  }
+  void set_option(const char* key, int value);
+  void active_cells(long long* nt, long long* nu);
+
+  // one-block, host-pointer entries with the reference argument lists
+  static void stress_host(hipStream_t s, double dt, int ndte, int damping, int nx, int ny, int ksub,
+                          int icellt, const int32_t* ti, const int32_t* tj, const double* uvel,
+                          const double* vvel, const double* const grid10[10],
+                          const double* strength, double* const sig[12], double* const diag[5],
+                          double* str);
+  static void stepu_host(hipStream_t s, int nx, int ny, int icellu, const int32_t* ui,
+                         const int32_t* uj, const double* const in10[10], const double* str,
+                         double* const io6[6]);
+
+ private:
+  const Domain& dom;
+  Halo& halo;
+  hipStream_t stream;
+  cice_evp_config cfg{};
+  EvpScalars sc{};
+  bool ready = false, prepared = false;
+  int tile_rows = 8;
+  bool use_graph = true;
+  size_t n = 0;  // nblocks*ny*nx
+  int cur = 0;   // which ping-pong copy of u, v, sigma holds the current values
+
+  // grid
+  DevBuf<double> dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarea, uarea, tarear, uarear, tinyarea,
+      fcor;
+  DevBuf<int32_t> tmask, umask, blk;  // blk: ilo,ihi,jlo,jhi per block
+  // in
+  DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,
+      ss_tlty;
+  // io (u, v, sigma double-buffered)
+  DevBuf<double> uv[2];    // [2*n]: u then v
+  DevBuf<double> sig[2];   // [12*n]
+  DevBuf<int32_t> iceumask;
+  DevBuf<double> fm, strtltx, strtlty, strocnx, strocny, strintx, strinty;
+  // out
+  DevBuf<double> strairx, strairy, strength, divu, shear, rdg_conv, rdg_shear, prs_sig, strocnxT,
+      strocnyT;
+  // work (ice_dyn_evp.F90:170-184)
+  DevBuf<double> tmass, umass, aiu, umassdtei, waterx, watery, forcex, forcey, work1;
+  DevBuf<int32_t> icetmask;
+  DevBuf<unsigned long long> counters;
+
+  // captured subcycle loop (hipGraph), keyed by (cur, ksub0, nsub, tile_rows)
+  hipGraphExec_t graph_exec = nullptr;
+  int graph_key[4] = {-1, -1, -1, -1};
+
+  void launch_subcycle(int ksub);
+  void drop_graph();
+};
+
+}  // namespace cice

@@ -1,0 +1,956 @@
+// EVP dynamics on the device.  Behavioural source: source/ice_dyn_evp.F90 of the
+// reference (file:line cited per kernel).  Layout: every field is the reference's
+// (nx_block,ny_block,nblocks) array, i fastest, so a wavefront reads 64 consecutive
+// i of one row = 512 contiguous bytes.
+//
+// The hot loop (ice_dyn_evp.F90:347-404: stress, stepu, two halo updates, ndte times)
+// is ONE kernel per subcycle: a workgroup takes a tile of 64 x TY T-cells, updates the
+// 12 stress components of the cells it owns, keeps the 8 `str` combinations of the
+// whole tile in LDS (they never touch HBM; the reference's `str(:,:,:) = 0` memset
+// disappears with them) and integrates the momentum equation for the 63 x (TY-1)
+// U-cells whose four surrounding T-cells are in the tile.  u, v and the stresses are
+// double-buffered so that tiles can recompute their neighbours' edge T-cells without
+// racing with the owner's update; the arithmetic per cell is exactly the reference's,
+// in its order, compiled without FMA contraction.
+#include "evp.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace cice {
+
+using namespace K;
+
+void EvpScalars::set(double dt, int ndte_, int damping) {
+  ndte = ndte_;
+  evp_damping = damping;
+  double dte = dt / (double)ndte;
+  dtei = c1 / dte;
+  double ecc = c4;
+  ecci = p25;
+  double tdamp2 = c2 * eyc * dt;
+  dte2T = dte / tdamp2;
+  denom1 = c1 / (c1 + dte2T);
+  denom2 = c1 / (c1 + dte2T * ecc);
+  rcon = 1230.0 * eyc * dt * (dtei * dtei);
+}
+
+namespace {
+
+struct StressOut {
+  double str[8];
+  double divu, rdg_conv, rdg_shear, shear, prs_sig;
+};
+
+// One T-cell of `stress` (ice_dyn_evp.F90:1065-1289).  s[12] = stressp_1..4, stressm_1..4,
+// stress12_1..4, updated in place.
+template <bool LAST, bool DAMP>
+__device__ __forceinline__ void stress_cell(const EvpScalars& sc, double u_ne, double u_nw,
+                                            double u_sw, double u_se, double v_ne, double v_nw,
+                                            double v_sw, double v_se, double Dxt, double Dyt,
+                                            double Dxhy, double Dyhx, double Cxp, double Cyp,
+                                            double Cxm, double Cym, double Tarear, double Tiny,
+                                            double St, double* s, StressOut& o) {
+  // :1065-1092 strain rates * area
+  const double divune = Cyp * u_ne - Dyt * u_nw + Cxp * v_ne - Dxt * v_se;
+  const double divunw = Cym * u_nw + Dyt * u_ne + Cxp * v_nw - Dxt * v_sw;
+  const double divusw = Cym * u_sw + Dyt * u_se + Cxm * v_sw + Dxt * v_nw;
+  const double divuse = Cyp * u_se - Dyt * u_sw + Cxm * v_se + Dxt * v_ne;
+  const double tensionne = -Cym * u_ne - Dyt * u_nw + Cxm * v_ne + Dxt * v_se;
+  const double tensionnw = -Cyp * u_nw + Dyt * u_ne + Cxm * v_nw + Dxt * v_sw;
+  const double tensionsw = -Cyp * u_sw + Dyt * u_se + Cxp * v_sw - Dxt * v_nw;
+  const double tensionse = -Cym * u_se - Dyt * u_sw + Cxp * v_se - Dxt * v_ne;
+  const double shearne = -Cym * v_ne - Dyt * v_nw - Cxm * u_ne - Dxt * u_se;
+  const double shearnw = -Cyp * v_nw + Dyt * v_ne - Cxm * u_nw - Dxt * u_sw;
+  const double shearsw = -Cyp * v_sw + Dyt * v_se - Cxp * u_sw + Dxt * u_nw;
+  const double shearse = -Cym * v_se - Dyt * v_sw - Cxp * u_se + Dxt * u_ne;
+  // :1095-1098
+  const double ecci = sc.ecci;
+  const double Deltane = sqrt(divune * divune + ecci * (tensionne * tensionne + shearne * shearne));
+  const double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
+  const double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
+  const double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
+  if (LAST) {  // :1103-1115
+    o.divu = p25 * (divune + divunw + divuse + divusw) * Tarear;
+    const double tmp = p25 * (Deltane + Deltanw + Deltase + Deltasw) * Tarear;
+    o.rdg_conv = -fmin(o.divu, c0);
+    o.rdg_shear = p5 * (tmp - fabs(o.divu));
+    const double ts = tensionne + tensionnw + tensionse + tensionsw;
+    const double ss = shearne + shearnw + shearse + shearsw;
+    o.shear = p25 * Tarear * sqrt(ts * ts + ss * ss);
+  }
+  double c0ne, c0nw, c0sw, c0se;
+  if (DAMP) {  // :1121-1128
+    c0ne = fmin(St / fmax(Deltane, c4 * Tiny), sc.rcon);
+    c0nw = fmin(St / fmax(Deltanw, c4 * Tiny), sc.rcon);
+    c0sw = fmin(St / fmax(Deltasw, c4 * Tiny), sc.rcon);
+    c0se = fmin(St / fmax(Deltase, c4 * Tiny), sc.rcon);
+    o.prs_sig = St * Deltane / fmax(Deltane, c4 * Tiny);
+  } else {  // :1131-1135
+    c0ne = St / fmax(Deltane, Tiny);
+    c0nw = St / fmax(Deltanw, Tiny);
+    c0sw = St / fmax(Deltasw, Tiny);
+    c0se = St / fmax(Deltase, Tiny);
+    o.prs_sig = c0ne * Deltane;
+  }
+  const double dte2T = sc.dte2T, denom1 = sc.denom1, denom2 = sc.denom2;
+  const double c1ne = c0ne * dte2T, c1nw = c0nw * dte2T, c1sw = c0sw * dte2T, c1se = c0se * dte2T;
+  // :1148-1165
+  const double p1 = s[0] = (s[0] + c1ne * (divune - Deltane)) * denom1;
+  const double p2 = s[1] = (s[1] + c1nw * (divunw - Deltanw)) * denom1;
+  const double p3 = s[2] = (s[2] + c1sw * (divusw - Deltasw)) * denom1;
+  const double p4 = s[3] = (s[3] + c1se * (divuse - Deltase)) * denom1;
+  const double m1 = s[4] = (s[4] + c1ne * tensionne) * denom2;
+  const double m2 = s[5] = (s[5] + c1nw * tensionnw) * denom2;
+  const double m3 = s[6] = (s[6] + c1sw * tensionsw) * denom2;
+  const double m4 = s[7] = (s[7] + c1se * tensionse) * denom2;
+  const double t1 = s[8] = (s[8] + c1ne * shearne * p5) * denom2;
+  const double t2 = s[9] = (s[9] + c1nw * shearnw * p5) * denom2;
+  const double t3 = s[10] = (s[10] + c1sw * shearsw * p5) * denom2;
+  const double t4 = s[11] = (s[11] + c1se * shearse * p5) * denom2;
+  // :1196-1239
+  const double ssigpn = p1 + p2, ssigps = p3 + p4, ssigpe = p1 + p4, ssigpw = p2 + p3;
+  const double ssigp1 = (p1 + p3) * p055, ssigp2 = (p2 + p4) * p055;
+  const double ssigmn = m1 + m2, ssigms = m3 + m4, ssigme = m1 + m4, ssigmw = m2 + m3;
+  const double ssigm1 = (m1 + m3) * p055, ssigm2 = (m2 + m4) * p055;
+  const double ssig12n = t1 + t2, ssig12s = t3 + t4, ssig12e = t1 + t4, ssig12w = t2 + t3;
+  const double ssig121 = (t1 + t3) * p111, ssig122 = (t2 + t4) * p111;
+  const double csigpne = p111 * p1 + ssigp2 + p027 * p3;
+  const double csigpnw = p111 * p2 + ssigp1 + p027 * p4;
+  const double csigpsw = p111 * p3 + ssigp2 + p027 * p1;
+  const double csigpse = p111 * p4 + ssigp1 + p027 * p2;
+  const double csigmne = p111 * m1 + ssigm2 + p027 * m3;
+  const double csigmnw = p111 * m2 + ssigm1 + p027 * m4;
+  const double csigmsw = p111 * m3 + ssigm2 + p027 * m1;
+  const double csigmse = p111 * m4 + ssigm1 + p027 * m2;
+  const double csig12ne = p222 * t1 + ssig122 + p055 * t3;
+  const double csig12nw = p222 * t2 + ssig121 + p055 * t4;
+  const double csig12sw = p222 * t3 + ssig122 + p055 * t1;
+  const double csig12se = p222 * t4 + ssig121 + p055 * t2;
+  const double str12ew = p5 * Dxt * (p333 * ssig12e + p166 * ssig12w);
+  const double str12we = p5 * Dxt * (p333 * ssig12w + p166 * ssig12e);
+  const double str12ns = p5 * Dyt * (p333 * ssig12n + p166 * ssig12s);
+  const double str12sn = p5 * Dyt * (p333 * ssig12s + p166 * ssig12n);
+  // :1244-1289
+  double strp_tmp = p25 * Dyt * (p333 * ssigpn + p166 * ssigps);
+  double strm_tmp = p25 * Dyt * (p333 * ssigmn + p166 * ssigms);
+  o.str[0] = -strp_tmp - strm_tmp - str12ew + Dxhy * (-csigpne + csigmne) + Dyhx * csig12ne;
+  o.str[1] = strp_tmp + strm_tmp - str12we + Dxhy * (-csigpnw + csigmnw) + Dyhx * csig12nw;
+  strp_tmp = p25 * Dyt * (p333 * ssigps + p166 * ssigpn);
+  strm_tmp = p25 * Dyt * (p333 * ssigms + p166 * ssigmn);
+  o.str[2] = -strp_tmp - strm_tmp + str12ew + Dxhy * (-csigpse + csigmse) + Dyhx * csig12se;
+  o.str[3] = strp_tmp + strm_tmp + str12we + Dxhy * (-csigpsw + csigmsw) + Dyhx * csig12sw;
+  strp_tmp = p25 * Dxt * (p333 * ssigpe + p166 * ssigpw);
+  strm_tmp = p25 * Dxt * (p333 * ssigme + p166 * ssigmw);
+  o.str[4] = -strp_tmp + strm_tmp - str12ns - Dyhx * (csigpne + csigmne) + Dxhy * csig12ne;
+  o.str[5] = strp_tmp - strm_tmp - str12sn - Dyhx * (csigpse + csigmse) + Dxhy * csig12se;
+  strp_tmp = p25 * Dxt * (p333 * ssigpw + p166 * ssigpe);
+  strm_tmp = p25 * Dxt * (p333 * ssigmw + p166 * ssigme);
+  o.str[6] = -strp_tmp + strm_tmp + str12ns - Dyhx * (csigpnw + csigmnw) + Dxhy * csig12nw;
+  o.str[7] = strp_tmp - strm_tmp + str12sn - Dyhx * (csigpsw + csigmsw) + Dxhy * csig12sw;
+}
+
+struct StepuOut {
+  double u, v, strintx, strinty, taux, tauy;
+};
+
+// One U-cell of `stepu` (ice_dyn_evp.F90:1390-1435); sx/sy are the four-term sums of :1415-1418.
+__device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu, double Uocn,
+                                           double Vocn, double Waterx, double Watery, double Forcex,
+                                           double Forcey, double Umassdtei, double Fm, double Uarear,
+                                           double sx, double sy, StepuOut& o) {
+  const double du = Uocn - uold, dv = Vocn - vold;
+  const double vrel = Aiu * dragw * sqrt(du * du + dv * dv);
+  o.taux = vrel * Waterx;
+  o.tauy = vrel * Watery;
+  const double cca = Umassdtei + vrel * cosw;
+  const double ccb = Fm + vrel * sinw;
+  const double ab2 = cca * cca + ccb * ccb;
+  o.strintx = Uarear * sx;
+  o.strinty = Uarear * sy;
+  const double cc1 = o.strintx + Forcex + o.taux + Umassdtei * uold;
+  const double cc2 = o.strinty + Forcey + o.tauy + Umassdtei * vold;
+  o.u = (cca * cc1 + ccb * cc2) / ab2;
+  o.v = (cca * cc2 - ccb * cc1) / ab2;
+}
+
+struct SubArgs {
+  EvpScalars sc;
+  int nx, ny, tiles_x, tiles_y;
+  size_t n;  // nblocks*ny*nx
+  const int32_t* blk;
+  const int32_t *icetmask, *iceumask;
+  const double *u_in, *v_in;
+  double *u_out, *v_out;
+  const double* sig_in;
+  double* sig_out;
+  const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym, *tarear, *tinyarea, *strength;
+  const double *aiu, *uocn, *vocn, *waterx, *watery, *forcex, *forcey, *umassdtei, *fm, *uarear;
+  double *divu, *rdg_conv, *rdg_shear, *shear, *prs_sig, *strintx, *strinty, *strocnx, *strocny;
+};
+
+constexpr int TX = 64;  // T-cells per tile row = one wavefront
+
+// One EVP subcycle, fused (ice_dyn_evp.F90:353-395).  256 threads = 4 wavefronts; wavefront w
+// owns tile rows w, w+4, ...; each lane one T-cell per row.
+template <int TY, bool LAST, bool DAMP>
+__global__ __launch_bounds__(256) void k_subcycle(const SubArgs a) {
+  __shared__ double s_str[8][TY][TX];
+  const int b = blockIdx.y;
+  const int tile = blockIdx.x;
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int ilo = a.blk[4 * b + 0], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2],
+            jhi = a.blk[4 * b + 3];
+  const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (TY - 1);  // 1-based
+  const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nx = a.nx;
+  const size_t base = (size_t)b * nx * a.ny;
+  const int i = i0 + lx;
+  // owner of T-cell (i,j) is the tile holding U-cell (min(i,ihi), min(j,jhi))
+  const int oi = min(i, ihi);
+  const bool own_i = (oi - i0) < (TX - 1);
+
+#pragma unroll 1
+  for (int ly = w; ly < TY; ly += 4) {
+    const int j = j0 + ly;
+    StressOut o;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o.str[c] = c0;
+    if (i <= ihi + 1 && j <= jhi + 1) {
+      const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
+      if (a.icetmask[q] == 1) {
+        const size_t qw = q - 1, qs = q - nx, qsw = q - nx - 1;
+        double s[12];
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
+        stress_cell<LAST, DAMP>(a.sc, a.u_in[q], a.u_in[qw], a.u_in[qsw], a.u_in[qs], a.v_in[q],
+                                a.v_in[qw], a.v_in[qsw], a.v_in[qs], a.dxt[q], a.dyt[q], a.dxhy[q],
+                                a.dyhx[q], a.cxp[q], a.cyp[q], a.cxm[q], a.cym[q],
+                                LAST ? a.tarear[q] : 0.0, a.tinyarea[q], a.strength[q], s, o);
+        const int oj = min(j, jhi);
+        if (own_i && (oj - j0) < (TY - 1)) {
+#pragma unroll
+          for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
+          if (LAST) {
+            a.divu[q] = o.divu;
+            a.rdg_conv[q] = o.rdg_conv;
+            a.rdg_shear[q] = o.rdg_shear;
+            a.shear[q] = o.shear;
+            a.prs_sig[q] = o.prs_sig;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s_str[c][ly][lx] = o.str[c];
+  }
+  __syncthreads();
+  if (lx >= TX - 1 || i > ihi) return;
+#pragma unroll 1
+  for (int ly = w; ly < TY - 1; ly += 4) {
+    const int j = j0 + ly;
+    if (j > jhi) break;
+    const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
+    if (!a.iceumask[q]) continue;
+    const double sx = s_str[0][ly][lx] + s_str[1][ly][lx + 1] + s_str[2][ly + 1][lx] +
+                      s_str[3][ly + 1][lx + 1];
+    const double sy = s_str[4][ly][lx] + s_str[5][ly + 1][lx] + s_str[6][ly][lx + 1] +
+                      s_str[7][ly + 1][lx + 1];
+    StepuOut r;
+    stepu_cell(a.u_in[q], a.v_in[q], a.aiu[q], a.uocn[q], a.vocn[q], a.waterx[q], a.watery[q],
+               a.forcex[q], a.forcey[q], a.umassdtei[q], a.fm[q], a.uarear[q], sx, sy, r);
+    a.u_out[q] = r.u;
+    a.v_out[q] = r.v;
+    if (LAST) {
+      a.strintx[q] = r.strintx;
+      a.strinty[q] = r.strinty;
+      a.strocnx[q] = r.taux;
+      a.strocny[q] = r.tauy;
+    }
+  }
+}
+
+// ---- list-driven, unfused forms with the reference's argument lists (tests) --------------
+struct StressListArgs {
+  EvpScalars sc;
+  int nx, ny, ksub, icellt;
+  const int32_t *ti, *tj;
+  const double *uvel, *vvel, *g[10], *strength;  // g: dxt,dyt,dxhy,dyhx,cxp,cyp,cxm,cym,tarear,tinyarea
+  double *sig[12], *diag[5], *str;               // diag: shear,divu,prs_sig,rdg_conv,rdg_shear
+};
+
+template <bool LAST, bool DAMP>
+__global__ __launch_bounds__(256) void k_stress_list(const StressListArgs a) {
+  const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= a.icellt) return;
+  const int i = a.ti[ij], j = a.tj[ij], nx = a.nx;
+  const size_t np = (size_t)nx * a.ny;
+  const size_t q = (size_t)(j - 1) * nx + (i - 1), qw = q - 1, qs = q - nx, qsw = q - nx - 1;
+  double s[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) s[c] = a.sig[c][q];
+  StressOut o;
+  stress_cell<LAST, DAMP>(a.sc, a.uvel[q], a.uvel[qw], a.uvel[qsw], a.uvel[qs], a.vvel[q], a.vvel[qw],
+                          a.vvel[qsw], a.vvel[qs], a.g[0][q], a.g[1][q], a.g[2][q], a.g[3][q],
+                          a.g[4][q], a.g[5][q], a.g[6][q], a.g[7][q], a.g[8][q], a.g[9][q],
+                          a.strength[q], s, o);
+#pragma unroll
+  for (int c = 0; c < 12; ++c) a.sig[c][q] = s[c];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) a.str[(size_t)c * np + q] = o.str[c];
+  a.diag[2][q] = o.prs_sig;
+  if (LAST) {
+    a.diag[0][q] = o.shear;
+    a.diag[1][q] = o.divu;
+    a.diag[3][q] = o.rdg_conv;
+    a.diag[4][q] = o.rdg_shear;
+  }
+}
+
+struct StepuListArgs {
+  int nx, ny, icellu;
+  const int32_t *ui, *uj;
+  const double *in[10], *str;  // in: aiu,uocn,vocn,waterx,watery,forcex,forcey,umassdtei,fm,uarear
+  double* io[6];               // strocnx,strocny,strintx,strinty,uvel,vvel
+};
+
+__global__ __launch_bounds__(256) void k_stepu_list(const StepuListArgs a) {
+  const int ij = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ij >= a.icellu) return;
+  const int i = a.ui[ij], j = a.uj[ij], nx = a.nx;
+  const size_t np = (size_t)nx * a.ny;
+  const size_t q = (size_t)(j - 1) * nx + (i - 1), qe = q + 1, qn = q + nx, qne = q + nx + 1;
+  const double sx = a.str[0 * np + q] + a.str[1 * np + qe] + a.str[2 * np + qn] + a.str[3 * np + qne];
+  const double sy = a.str[4 * np + q] + a.str[5 * np + qn] + a.str[6 * np + qe] + a.str[7 * np + qne];
+  StepuOut r;
+  stepu_cell(a.io[4][q], a.io[5][q], a.in[0][q], a.in[1][q], a.in[2][q], a.in[3][q], a.in[4][q],
+             a.in[5][q], a.in[6][q], a.in[7][q], a.in[8][q], a.in[9][q], sx, sy, r);
+  a.io[4][q] = r.u;
+  a.io[5][q] = r.v;
+  a.io[2][q] = r.strintx;
+  a.io[3][q] = r.strinty;
+  a.io[0][q] = r.taux;
+  a.io[1][q] = r.tauy;
+}
+
+// ---- once-per-step kernels ------------------------------------------------------------------
+struct PrepArgs {
+  EvpScalars sc;
+  int nx, ny, nblocks;
+  size_t n;
+  const int32_t *blk, *tmask, *umask;
+  const double *aice, *vice, *vsno, *aice0, *aicen, *vicen, *strairxT, *strairyT, *uocn, *vocn;
+  const double *tarea, *uarea, *fcor;
+  double *strairx, *strairy, *tmass, *umass, *aiu, *work1;
+  int32_t *icetmask, *iceumask;
+  double *rdg_conv, *rdg_shear, *divu, *shear, *prs_sig;
+  double *umassdtei, *waterx, *watery, *forcex, *forcey, *fm, *strtltx, *strtlty, *strocnx, *strocny,
+      *strintx, *strinty, *strength, *strocnxT, *strocnyT;
+  double *u, *v, *sig;
+  int kstrength, krdg_partic, krdg_redist;
+  double mu_rdg;
+  unsigned long long* counters;
+};
+
+__device__ __forceinline__ bool cell_of(const PrepArgs& a, size_t t, int& b, int& i, int& j) {
+  if (t >= a.n) return false;
+  const size_t np = (size_t)a.nx * a.ny;
+  b = (int)(t / np);
+  const size_t r = t - (size_t)b * np;
+  j = (int)(r / a.nx) + 1;
+  i = (int)(r - (size_t)(j - 1) * a.nx) + 1;
+  return true;
+}
+
+__device__ __forceinline__ bool tmphm_at(const PrepArgs& a, size_t q) {  // :651-661
+  if (!a.tmask[q]) return false;
+  const double tm = rhoi * a.vice[q] + rhos * a.vsno[q];
+  return (a.aice[q] > a_min) && (tm > m_min);
+}
+
+// evp :214-224 + evp_prep1 :586-694
+__global__ __launch_bounds__(256) void k_prep1(const PrepArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  a.rdg_conv[t] = c0; a.rdg_shear[t] = c0; a.divu[t] = c0; a.shear[t] = c0; a.prs_sig[t] = c0;
+  a.tmass[t] = a.tmask[t] ? (rhoi * a.vice[t] + rhos * a.vsno[t]) : c0;
+  a.strairx[t] = a.strairxT[t];
+  a.strairy[t] = a.strairyT[t];
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  int m = 0;
+  if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.tmask[t]) {
+    bool any = false;
+    for (int dj = -1; dj <= 1; ++dj)
+      for (int di = -1; di <= 1; ++di) any = any || tmphm_at(a, t + (ptrdiff_t)dj * a.nx + di);
+    m = any ? 1 : 0;
+  }
+  a.icetmask[t] = m;
+}
+
+// to_ugrid (ice_grid.F90:1580-1633) for two fields at once: work2 = 0 off the physical domain
+__global__ __launch_bounds__(256) void k_to_ugrid2(const PrepArgs a, const double* __restrict__ f1,
+                                                   const double* __restrict__ f2,
+                                                   double* __restrict__ o1, double* __restrict__ o2) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  double r1 = c0, r2 = c0;
+  if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) {
+    const size_t e = t + 1, n = t + a.nx, ne = t + a.nx + 1;
+    const double ta = a.tarea[t], tb = a.tarea[e], tc = a.tarea[n], td = a.tarea[ne], ua = a.uarea[t];
+    r1 = p25 * (f1[t] * ta + f1[e] * tb + f1[n] * tc + f1[ne] * td) / ua;
+    r2 = p25 * (f2[t] * ta + f2[e] * tb + f2[n] * tc + f2[ne] * td) / ua;
+  }
+  o1[t] = r1;
+  o2[t] = r2;
+}
+
+// to_tgrid (ice_grid.F90:1684-1732) for two fields; ghost cells of the outputs are untouched
+__global__ __launch_bounds__(256) void k_to_tgrid2(const PrepArgs a, const double* __restrict__ f1,
+                                                   const double* __restrict__ f2,
+                                                   double* __restrict__ o1, double* __restrict__ o2) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) {
+    const size_t w = t - 1, s = t - a.nx, sw = t - a.nx - 1;
+    const double ua = a.uarea[t], ub = a.uarea[w], uc = a.uarea[s], ud = a.uarea[sw], ta = a.tarea[t];
+    o1[t] = p25 * (f1[t] * ua + f1[w] * ub + f1[s] * uc + f1[sw] * ud) / ta;
+    o2[t] = p25 * (f2[t] * ua + f2[w] * ub + f2[s] * uc + f2[sw] * ud) / ta;
+  }
+}
+
+// evp_prep2 :703-938 (non-coupled, non-AusCOM branches), dense form: the compressed lists
+// become the masks icetmask (T-cells, incl. N/E ghost ring) and iceumask (U-cells)
+__global__ __launch_bounds__(256) void k_prep2(const PrepArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  double wx = c0, wy = c0, fx = c0, fy = c0, umd = c0;
+  if (a.icetmask[t] == 0) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) a.sig[(size_t)c * a.n + t] = c0;
+  }
+  if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) {
+    const bool old = a.iceumask[t] != 0;
+    const bool now = a.umask[t] && (a.aiu[t] > a_min) && (a.umass[t] > m_min);
+    a.iceumask[t] = now ? 1 : 0;
+    if (now) {
+      if (!old) {
+        a.u[t] = a.uocn[t];
+        a.v[t] = a.vocn[t];
+      }
+      umd = a.umass[t] * a.sc.dtei;
+      const double fmv = a.fcor[t] * a.umass[t];
+      a.fm[t] = fmv;
+      wx = a.uocn[t] * cosw - a.vocn[t] * sinw;
+      wy = a.vocn[t] * cosw + a.uocn[t] * sinw;
+      const double tx = -fmv * a.vocn[t], ty = fmv * a.uocn[t];
+      a.strtltx[t] = tx;
+      a.strtlty[t] = ty;
+      fx = a.strairx[t] + tx;
+      fy = a.strairy[t] + ty;
+    } else {
+      a.u[t] = c0; a.v[t] = c0;
+      a.strintx[t] = c0; a.strinty[t] = c0;
+      a.strocnx[t] = c0; a.strocny[t] = c0;
+    }
+  }
+  a.waterx[t] = wx; a.watery[t] = wy; a.forcex[t] = fx; a.forcey[t] = fy; a.umassdtei[t] = umd;
+}
+
+// ice_strength (ice_mechred.F90:1869-2036; asum_ridging :573, ridge_itd :773-1098) on the
+// T-cell list of evp_prep2 (icetmask = 1 on ilo..ihi+1, jlo..jhi+1); zero elsewhere.
+__global__ __launch_bounds__(256) void k_strength(const PrepArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  double st = c0;
+  const bool phys = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
+  if (a.kstrength != 1) {
+    if (phys) st = 2.75e4 * a.vice[t] * exp(-20.0 * (c1 - a.aice[t]));
+  } else if (i >= ilo && i <= ihi + 1 && j >= jlo && j <= jhi + 1 && a.icetmask[t] == 1) {
+    constexpr double Cf = 17.0, Cp = p5 * gravit * (rhow - rhoi) * rhoi / rhow;
+    constexpr double Gstar = 0.15, astar = 0.05, maxraft = 1.0, Hstar = 25.0;
+    constexpr double Gstari = c1 / Gstar, astari = c1 / astar;
+    const size_t np = (size_t)a.nx * a.ny;
+    const size_t qc = (size_t)b * NCAT * np + (t - (size_t)b * np);  // (nx,ny,ncat,nb) layout
+    double Gsum[NCAT + 2], apartic[NCAT + 1], hrmin[NCAT + 1], hrmax[NCAT + 1], hrexp[NCAT + 1],
+        krdg[NCAT + 1], an[NCAT + 1], vn[NCAT + 1];
+    Gsum[0] = c0;
+    Gsum[1] = (a.aice0[t] > puny) ? a.aice0[t] : Gsum[0];
+    apartic[0] = c0;
+#pragma unroll
+    for (int n = 1; n <= NCAT; ++n) {
+      an[n] = a.aicen[qc + (size_t)(n - 1) * np];
+      vn[n] = a.vicen[qc + (size_t)(n - 1) * np];
+      Gsum[n + 1] = (an[n] > puny) ? Gsum[n] + an[n] : Gsum[n];
+      apartic[n] = c0; hrmin[n] = c0; hrmax[n] = c0; hrexp[n] = c0; krdg[n] = c1;
+    }
+    const double work = c1 / Gsum[NCAT + 1];
+#pragma unroll
+    for (int n = 0; n <= NCAT; ++n) Gsum[n + 1] = Gsum[n + 1] * work;
+    if (a.krdg_partic == 0) {
+#pragma unroll
+      for (int n = 0; n <= NCAT; ++n) {
+        const double g = Gsum[n + 1], gm = Gsum[n];
+        if (g < Gstar)
+          apartic[n] = Gstari * (g - gm) * (c2 - (gm + g) * Gstari);
+        else if (gm < Gstar)
+          apartic[n] = Gstari * (Gstar - gm) * (c2 - (gm + Gstar) * Gstari);
+      }
+    } else {
+      const double xtmp = c1 / (c1 - exp(-astari));
+#pragma unroll
+      for (int n = -1; n <= NCAT; ++n) Gsum[n + 1] = exp(-Gsum[n + 1] * astari) * xtmp;
+#pragma unroll
+      for (int n = 0; n <= NCAT; ++n) apartic[n] = Gsum[n] - Gsum[n + 1];
+    }
+#pragma unroll
+    for (int n = 1; n <= NCAT; ++n) {
+      if (an[n] > puny) {
+        double hi = vn[n] / an[n];
+        if (a.krdg_redist == 0) {
+          hrmin[n] = fmin(c2 * hi, hi + maxraft);
+          hrmax[n] = c2 * sqrt(Hstar * hi);
+          hrmax[n] = fmax(hrmax[n], hrmin[n] + puny);
+          const double hrmean = p5 * (hrmin[n] + hrmax[n]);
+          krdg[n] = hrmean / hi;
+        } else {
+          hi = fmax(hi, puny);
+          hrmin[n] = fmin(c2 * hi, hi + maxraft);
+          hrexp[n] = a.mu_rdg * sqrt(hi);
+          krdg[n] = (hrmin[n] + hrexp[n]) / hi;
+        }
+      }
+    }
+    double aksum = apartic[0];
+#pragma unroll
+    for (int n = 1; n <= NCAT; ++n) aksum = aksum + apartic[n] * (c1 - c1 / krdg[n]);
+    double s = c0;
+#pragma unroll
+    for (int n = 1; n <= NCAT; ++n) {
+      if (an[n] > puny && apartic[n] > c0) {
+        const double hi = vn[n] / an[n];
+        double h2rdg;
+        if (a.krdg_redist == 0)
+          h2rdg = p333 * (hrmax[n] * hrmax[n] * hrmax[n] - hrmin[n] * hrmin[n] * hrmin[n]) /
+                  (hrmax[n] - hrmin[n]);
+        else
+          h2rdg = hrmin[n] * hrmin[n] + c2 * hrmin[n] * hrexp[n] + c2 * hrexp[n] * hrexp[n];
+        const double dh2rdg = -hi * hi + h2rdg / krdg[n];
+        s = s + apartic[n] * dh2rdg;
+      }
+    }
+    st = Cf * Cp * s / aksum;
+  }
+  a.strength[t] = st;
+}
+
+// evp_finish :1452-1549 (strocnxT/yT zeroed everywhere first)
+__global__ __launch_bounds__(256) void k_finish(const PrepArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  if (!cell_of(a, t, b, i, j)) return;
+  double xT = c0, yT = c0;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.iceumask[t]) {  // the indxu list
+    const double du = a.uocn[t] - a.u[t], dv = a.vocn[t] - a.v[t];
+    const double vrel = dragw * sqrt(du * du + dv * dv);
+    const double sx = a.strocnx[t] - vrel * (a.u[t] * cosw - a.v[t] * sinw) * a.aiu[t];
+    const double sy = a.strocny[t] - vrel * (a.v[t] * cosw + a.u[t] * sinw) * a.aiu[t];
+    a.strocnx[t] = sx;
+    a.strocny[t] = sy;
+    xT = sx / a.aiu[t];
+    yT = sy / a.aiu[t];
+  }
+  a.strocnxT[t] = xT;
+  a.strocnyT[t] = yT;
+}
+
+__global__ __launch_bounds__(256) void k_count_active(const PrepArgs a) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int b, i, j;
+  unsigned long long nt = 0, nu = 0;
+  if (cell_of(a, t, b, i, j)) {
+    const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+    if (i >= ilo && i <= ihi + 1 && j >= jlo && j <= jhi + 1 && a.icetmask[t] == 1) nt = 1;
+    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.iceumask[t]) nu = 1;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    nt += __shfl_down(nt, off);
+    nu += __shfl_down(nu, off);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    if (nt) atomicAdd(&a.counters[0], nt);
+    if (nu) atomicAdd(&a.counters[1], nu);
+  }
+}
+
+inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+Evp::~Evp() { drop_graph(); }
+
+void Evp::drop_graph() {
+  if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+  graph_exec = nullptr;
+  graph_key[0] = -1;
+}
+
+void Evp::set_option(const char* key, int value) {
+  if (!std::strcmp(key, "tile_rows")) {
+    CICE_REQUIRE(value == 8 || value == 16 || value == 32, "tile_rows must be 8, 16 or 32");
+    tile_rows = value;
+  } else if (!std::strcmp(key, "use_graph")) {
+    use_graph = value != 0;
+  } else {
+    throw Error{CICE_EINVAL, std::string("unknown option ") + key};
+  }
+  drop_graph();
+}
+
+void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
+  CICE_REQUIRE(dom.nblocks() > 0, "cice_evp_init: no local blocks (call cice_domain_create first)");
+  CICE_REQUIRE(c.ndte >= 1, "ndte must be >= 1");
+  cfg = c;
+  n = (size_t)dom.nblocks() * dom.nx_block * dom.ny_block;
+  std::vector<int32_t> hb;
+  for (int gid : dom.local) {
+    const Block& b = dom.all[gid];
+    hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi});
+  }
+  blk.alloc(hb.size());
+  blk.upload(hb.data(), stream);
+  struct G { DevBuf<double>* d; const double* h; };
+  G gs[] = {{&dxt, g.dxt}, {&dyt, g.dyt}, {&dxhy, g.dxhy}, {&dyhx, g.dyhx}, {&cxp, g.cxp},
+            {&cyp, g.cyp}, {&cxm, g.cxm}, {&cym, g.cym}, {&tarea, g.tarea}, {&uarea, g.uarea},
+            {&tarear, g.tarear}, {&uarear, g.uarear}, {&tinyarea, g.tinyarea}, {&fcor, g.fcor}};
+  for (G& x : gs) {
+    CICE_REQUIRE(x.h != nullptr, "cice_evp_init: NULL grid array");
+    x.d->alloc(n);
+    x.d->upload(x.h, stream);
+  }
+  CICE_REQUIRE(g.tmask && g.umask, "cice_evp_init: NULL mask");
+  tmask.alloc(n); tmask.upload(g.tmask, stream);
+  umask.alloc(n); umask.upload(g.umask, stream);
+  for (DevBuf<double>* d : {&aice, &vice, &vsno, &aice0, &strairxT, &strairyT, &uocn, &vocn, &ss_tltx,
+                            &ss_tlty, &fm, &strtltx, &strtlty, &strocnx, &strocny, &strintx, &strinty,
+                            &strairx, &strairy, &strength, &divu, &shear, &rdg_conv, &rdg_shear,
+                            &prs_sig, &strocnxT, &strocnyT, &tmass, &umass, &aiu, &umassdtei, &waterx,
+                            &watery, &forcex, &forcey, &work1}) {
+    d->alloc(n);
+    d->zero(stream);
+  }
+  work1.alloc(2 * n);
+  aicen.alloc(NCAT * n); aicen.zero(stream);
+  vicen.alloc(NCAT * n); vicen.zero(stream);
+  for (int k = 0; k < 2; ++k) {  // init_evp :487-520: velocities, stresses = 0, iceumask = F
+    uv[k].alloc(2 * n); uv[k].zero(stream);
+    sig[k].alloc(12 * n); sig[k].zero(stream);
+  }
+  iceumask.alloc(n); iceumask.zero(stream);
+  icetmask.alloc(n); icetmask.zero(stream);
+  counters.alloc(2);
+  cur = 0;
+  CICE_HIP(hipStreamSynchronize(stream));
+  ready = true;
+  prepared = false;
+  drop_graph();
+}
+
+void Evp::upload(const cice_evp_fields& f) {
+  CICE_REQUIRE(ready, "cice_evp_upload before cice_evp_init");
+  struct U { DevBuf<double>* d; const double* h; };
+  U us[] = {{&aice, f.aice}, {&vice, f.vice}, {&vsno, f.vsno}, {&aice0, f.aice0}, {&aicen, f.aicen},
+            {&vicen, f.vicen}, {&strairxT, f.strairxT}, {&strairyT, f.strairyT}, {&uocn, f.uocn},
+            {&vocn, f.vocn}, {&ss_tltx, f.ss_tltx}, {&ss_tlty, f.ss_tlty}, {&fm, f.fm},
+            {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx}, {&strocny, f.strocny},
+            {&strintx, f.strintx}, {&strinty, f.strinty}};
+  for (U& x : us) {
+    CICE_REQUIRE(x.h != nullptr, "cice_evp_upload: NULL field");
+    x.d->upload(x.h, stream);
+  }
+  CICE_REQUIRE(f.uvel && f.vvel && f.iceumask, "cice_evp_upload: NULL field");
+  CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, stream));
+  const double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
+                          f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3,
+                          f.stress12_4};
+  for (int c = 0; c < 12; ++c) {
+    CICE_REQUIRE(hs[c] != nullptr, "cice_evp_upload: NULL stress");
+    CICE_HIP(hipMemcpyAsync(sig[cur].p + (size_t)c * n, hs[c], n * 8, hipMemcpyHostToDevice, stream));
+  }
+  iceumask.upload(f.iceumask, stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+  prepared = false;
+}
+
+void Evp::download(cice_evp_fields& f) {
+  CICE_REQUIRE(ready, "cice_evp_download before cice_evp_init");
+  CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, stream));
+  CICE_HIP(hipMemcpyAsync(f.vvel, uv[cur].p + n, n * 8, hipMemcpyDeviceToHost, stream));
+  double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
+                    f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3, f.stress12_4};
+  for (int c = 0; c < 12; ++c)
+    CICE_HIP(hipMemcpyAsync(hs[c], sig[cur].p + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, stream));
+  iceumask.download(f.iceumask, stream);
+  struct D { const DevBuf<double>* d; double* h; };
+  D ds[] = {{&fm, f.fm}, {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx},
+            {&strocny, f.strocny}, {&strintx, f.strintx}, {&strinty, f.strinty}, {&strairx, f.strairx},
+            {&strairy, f.strairy}, {&strength, f.strength}, {&divu, f.divu}, {&shear, f.shear},
+            {&rdg_conv, f.rdg_conv}, {&rdg_shear, f.rdg_shear}, {&prs_sig, f.prs_sig},
+            {&strocnxT, f.strocnxT}, {&strocnyT, f.strocnyT}};
+  for (D& x : ds)
+    if (x.h) x.d->download(x.h, stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+}
+
+void Evp::prepare(double dt) {
+  CICE_REQUIRE(ready, "cice_evp_prepare before cice_evp_init");
+  EvpScalars nsc;
+  nsc.set(dt, cfg.ndte, cfg.evp_damping);
+  if (std::memcmp(&nsc, &sc, sizeof(sc)) != 0) drop_graph();  // scalars are baked into the graph
+  sc = nsc;
+  PrepArgs a{};
+  a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.nblocks = dom.nblocks(); a.n = n;
+  a.blk = blk.p; a.tmask = tmask.p; a.umask = umask.p;
+  a.aice = aice.p; a.vice = vice.p; a.vsno = vsno.p; a.aice0 = aice0.p; a.aicen = aicen.p;
+  a.vicen = vicen.p; a.strairxT = strairxT.p; a.strairyT = strairyT.p; a.uocn = uocn.p; a.vocn = vocn.p;
+  a.tarea = tarea.p; a.uarea = uarea.p; a.fcor = fcor.p;
+  a.strairx = strairx.p; a.strairy = strairy.p; a.tmass = tmass.p; a.umass = umass.p; a.aiu = aiu.p;
+  a.work1 = work1.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
+  a.rdg_conv = rdg_conv.p; a.rdg_shear = rdg_shear.p; a.divu = divu.p; a.shear = shear.p;
+  a.prs_sig = prs_sig.p; a.umassdtei = umassdtei.p; a.waterx = waterx.p; a.watery = watery.p;
+  a.forcex = forcex.p; a.forcey = forcey.p; a.fm = fm.p; a.strtltx = strtltx.p; a.strtlty = strtlty.p;
+  a.strocnx = strocnx.p; a.strocny = strocny.p; a.strintx = strintx.p; a.strinty = strinty.p;
+  a.strength = strength.p; a.strocnxT = strocnxT.p; a.strocnyT = strocnyT.p;
+  a.u = uv[cur].p; a.v = uv[cur].p + n; a.sig = sig[cur].p;
+  a.kstrength = cfg.kstrength; a.krdg_partic = cfg.krdg_partic; a.krdg_redist = cfg.krdg_redist;
+  a.mu_rdg = cfg.mu_rdg; a.counters = counters.p;
+  const dim3 g = grid1(n), blk256(256);
+  hipLaunchKernelGGL(k_prep1, g, blk256, 0, stream, a);                       // :214-244
+  halo.update_i4(icetmask.p, 1, n);                                           // :250-253
+  hipLaunchKernelGGL(k_to_ugrid2, g, blk256, 0, stream, a, (const double*)tmass.p,
+                     (const double*)aice.p, umass.p, aiu.p);                  // :259-260
+  // t2ugrid_vector(strairx), (strairy) :276-277 = copy, halo update, to_ugrid
+  CICE_HIP(hipMemcpyAsync(work1.p, strairx.p, n * 8, hipMemcpyDeviceToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(work1.p + n, strairy.p, n * 8, hipMemcpyDeviceToDevice, stream));
+  halo.update_r8(work1.p, 2, n);
+  hipLaunchKernelGGL(k_to_ugrid2, g, blk256, 0, stream, a, (const double*)work1.p,
+                     (const double*)(work1.p + n), strairx.p, strairy.p);
+  hipLaunchKernelGGL(k_prep2, g, blk256, 0, stream, a);                       // :280-316
+  hipLaunchKernelGGL(k_strength, g, blk256, 0, stream, a);                    // :322-332
+  halo.update_r8(strength.p, 1, n);                                           // :337
+  halo.update_r8(uv[cur].p, 2, n);                                            // :340-343
+  // both copies of the double-buffered fields start out identical: cells the subcycle
+  // kernel never writes (outside the masks) then hold the same value in either copy
+  CICE_HIP(hipMemcpyAsync(uv[1 - cur].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(sig[1 - cur].p, sig[cur].p, 12 * n * 8, hipMemcpyDeviceToDevice, stream));
+  counters.zero(stream);
+  hipLaunchKernelGGL(k_count_active, g, blk256, 0, stream, a);
+  CICE_HIP(hipGetLastError());
+  prepared = true;
+}
+
+void Evp::active_cells(long long* nt, long long* nu) {
+  CICE_REQUIRE(prepared, "cice_evp_active_cells before cice_evp_prepare");
+  unsigned long long h[2];
+  counters.download(h, stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+  if (nt) *nt = (long long)h[0];
+  if (nu) *nu = (long long)h[1];
+}
+
+template <int TY>
+static void launch_ty(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+  if (last) {
+    if (damp) hipLaunchKernelGGL((k_subcycle<TY, true, true>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<TY, true, false>), g, dim3(256), 0, s, a);
+  } else {
+    if (damp) hipLaunchKernelGGL((k_subcycle<TY, false, true>), g, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<TY, false, false>), g, dim3(256), 0, s, a);
+  }
+}
+
+void Evp::launch_subcycle(int ksub) {
+  SubArgs a{};
+  a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.n = n;
+  const int TY = tile_rows;
+  a.tiles_x = (dom.bsx + (TX - 1) - 1) / (TX - 1);
+  a.tiles_y = (dom.bsy + (TY - 1) - 1) / (TY - 1);
+  a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
+  a.u_in = uv[cur].p; a.v_in = uv[cur].p + n; a.u_out = uv[1 - cur].p; a.v_out = uv[1 - cur].p + n;
+  a.sig_in = sig[cur].p; a.sig_out = sig[1 - cur].p;
+  a.dxt = dxt.p; a.dyt = dyt.p; a.dxhy = dxhy.p; a.dyhx = dyhx.p; a.cxp = cxp.p; a.cyp = cyp.p;
+  a.cxm = cxm.p; a.cym = cym.p; a.tarear = tarear.p; a.tinyarea = tinyarea.p; a.strength = strength.p;
+  a.aiu = aiu.p; a.uocn = uocn.p; a.vocn = vocn.p; a.waterx = waterx.p; a.watery = watery.p;
+  a.forcex = forcex.p; a.forcey = forcey.p; a.umassdtei = umassdtei.p; a.fm = fm.p; a.uarear = uarear.p;
+  a.divu = divu.p; a.rdg_conv = rdg_conv.p; a.rdg_shear = rdg_shear.p; a.shear = shear.p;
+  a.prs_sig = prs_sig.p; a.strintx = strintx.p; a.strinty = strinty.p; a.strocnx = strocnx.p;
+  a.strocny = strocny.p;
+  const dim3 g(a.tiles_x * a.tiles_y, dom.nblocks());
+  const bool last = (ksub == sc.ndte), damp = sc.evp_damping != 0;
+  if (TY == 8) launch_ty<8>(a, last, damp, g, stream);
+  else if (TY == 16) launch_ty<16>(a, last, damp, g, stream);
+  else launch_ty<32>(a, last, damp, g, stream);
+  cur = 1 - cur;
+  halo.update_r8(uv[cur].p, 2, n);  // :397-402, uvel and vvel in one pass
+}
+
+void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
+  CICE_REQUIRE(prepared, "cice_evp_subcycles before cice_evp_prepare");
+  CICE_REQUIRE(ksub0 >= 1 && nsub >= 0, "bad subcycle range");
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (elapsed_ms) {
+    CICE_HIP(hipEventCreate(&e0));
+    CICE_HIP(hipEventCreate(&e1));
+    CICE_HIP(hipEventRecord(e0, stream));
+  }
+  // RCCL calls are not captured: graphs only on a single rank
+  const bool graph_ok = use_graph && !halo.multi_rank() && nsub > 1;
+  if (graph_ok) {
+    const int key[4] = {cur, ksub0, nsub, tile_rows};
+    if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
+      drop_graph();
+      hipGraph_t gph = nullptr;
+      const int cur0 = cur;
+      CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+      for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+      CICE_HIP(hipStreamEndCapture(stream, &gph));
+      CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
+      CICE_HIP(hipGraphDestroy(gph));
+      std::memcpy(graph_key, key, sizeof(key));
+      cur = cur0;
+    }
+    CICE_HIP(hipGraphLaunch(graph_exec, stream));
+    if (nsub & 1) cur = 1 - cur;
+  } else {
+    for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+  }
+  CICE_HIP(hipGetLastError());
+  if (elapsed_ms) {
+    CICE_HIP(hipEventRecord(e1, stream));
+    CICE_HIP(hipEventSynchronize(e1));
+    CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+  }
+}
+
+void Evp::finish() {
+  CICE_REQUIRE(prepared, "cice_evp_finish before cice_evp_prepare");
+  PrepArgs a{};
+  a.nx = dom.nx_block; a.ny = dom.ny_block; a.nblocks = dom.nblocks(); a.n = n; a.blk = blk.p;
+  a.iceumask = iceumask.p; a.uocn = uocn.p; a.vocn = vocn.p; a.u = uv[cur].p; a.v = uv[cur].p + n;
+  a.aiu = aiu.p; a.strocnx = strocnx.p; a.strocny = strocny.p; a.strocnxT = strocnxT.p;
+  a.strocnyT = strocnyT.p; a.tarea = tarea.p; a.uarea = uarea.p;
+  const dim3 g = grid1(n), blk256(256);
+  hipLaunchKernelGGL(k_finish, g, blk256, 0, stream, a);  // :410-425
+  // u2tgrid_vector :427-428 = copy, halo update (NE corner), to_tgrid
+  CICE_HIP(hipMemcpyAsync(work1.p, strocnxT.p, n * 8, hipMemcpyDeviceToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(work1.p + n, strocnyT.p, n * 8, hipMemcpyDeviceToDevice, stream));
+  halo.update_r8(work1.p, 2, n);
+  hipLaunchKernelGGL(k_to_tgrid2, g, blk256, 0, stream, a, (const double*)work1.p,
+                     (const double*)(work1.p + n), strocnxT.p, strocnyT.p);
+  CICE_HIP(hipGetLastError());
+  CICE_HIP(hipStreamSynchronize(stream));
+}
+
+// ---- per-routine host-pointer entries ---------------------------------------------------------
+void Evp::stress_host(hipStream_t s, double dt, int ndte, int damping, int nx, int ny, int ksub,
+                      int icellt, const int32_t* ti, const int32_t* tj, const double* uvel,
+                      const double* vvel, const double* const grid10[10], const double* strength,
+                      double* const sg[12], double* const diag[5], double* str) {
+  const size_t np = (size_t)nx * ny;
+  CICE_REQUIRE(icellt >= 0 && (size_t)icellt <= np, "icellt out of range");
+  for (int e = 0; e < icellt; ++e)
+    CICE_REQUIRE(ti[e] >= 2 && ti[e] <= nx && tj[e] >= 2 && tj[e] <= ny, "stress: index outside block");
+  DevBuf<double> d;       // uvel,vvel,10 grid,strength,12 sig,5 diag,8 str = 38 planes
+  d.alloc(38 * np);
+  DevBuf<int32_t> li;
+  li.alloc(2 * np);
+  auto up = [&](int plane, const double* h) {
+    CICE_HIP(hipMemcpyAsync(d.p + plane * np, h, np * 8, hipMemcpyHostToDevice, s));
+  };
+  up(0, uvel); up(1, vvel);
+  for (int k = 0; k < 10; ++k) up(2 + k, grid10[k]);
+  up(12, strength);
+  for (int k = 0; k < 12; ++k) up(13 + k, sg[k]);
+  for (int k = 0; k < 5; ++k) up(25 + k, diag[k]);
+  CICE_HIP(hipMemsetAsync(d.p + 30 * np, 0, 8 * np * 8, s));  // str(:,:,:) = c0, :1051
+  if (icellt) {
+    CICE_HIP(hipMemcpyAsync(li.p, ti, (size_t)icellt * 4, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p + np, tj, (size_t)icellt * 4, hipMemcpyHostToDevice, s));
+  }
+  StressListArgs a{};
+  a.sc.set(dt, ndte, damping);
+  a.nx = nx; a.ny = ny; a.ksub = ksub; a.icellt = icellt; a.ti = li.p; a.tj = li.p + np;
+  a.uvel = d.p; a.vvel = d.p + np;
+  for (int k = 0; k < 10; ++k) a.g[k] = d.p + (2 + k) * np;
+  a.strength = d.p + 12 * np;
+  for (int k = 0; k < 12; ++k) a.sig[k] = d.p + (13 + k) * np;
+  for (int k = 0; k < 5; ++k) a.diag[k] = d.p + (25 + k) * np;
+  a.str = d.p + 30 * np;
+  if (icellt) {
+    const dim3 g = grid1(icellt);
+    const bool last = ksub == ndte;
+    if (last) {
+      if (damping) hipLaunchKernelGGL((k_stress_list<true, true>), g, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_stress_list<true, false>), g, dim3(256), 0, s, a);
+    } else {
+      if (damping) hipLaunchKernelGGL((k_stress_list<false, true>), g, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((k_stress_list<false, false>), g, dim3(256), 0, s, a);
+    }
+    CICE_HIP(hipGetLastError());
+  }
+  auto down = [&](int plane, double* h, size_t planes = 1) {
+    CICE_HIP(hipMemcpyAsync(h, d.p + plane * np, planes * np * 8, hipMemcpyDeviceToHost, s));
+  };
+  for (int k = 0; k < 12; ++k) down(13 + k, sg[k]);
+  for (int k = 0; k < 5; ++k) down(25 + k, diag[k]);
+  down(30, str, 8);
+  CICE_HIP(hipStreamSynchronize(s));
+}
+
+void Evp::stepu_host(hipStream_t s, int nx, int ny, int icellu, const int32_t* ui, const int32_t* uj,
+                     const double* const in10[10], const double* str, double* const io6[6]) {
+  const size_t np = (size_t)nx * ny;
+  CICE_REQUIRE(icellu >= 0 && (size_t)icellu <= np, "icellu out of range");
+  for (int e = 0; e < icellu; ++e)
+    CICE_REQUIRE(ui[e] >= 1 && ui[e] < nx && uj[e] >= 1 && uj[e] < ny, "stepu: index outside block");
+  DevBuf<double> d;  // 10 in, 8 str, 6 io
+  d.alloc(24 * np);
+  DevBuf<int32_t> li;
+  li.alloc(2 * np);
+  for (int k = 0; k < 10; ++k)
+    CICE_HIP(hipMemcpyAsync(d.p + k * np, in10[k], np * 8, hipMemcpyHostToDevice, s));
+  CICE_HIP(hipMemcpyAsync(d.p + 10 * np, str, 8 * np * 8, hipMemcpyHostToDevice, s));
+  for (int k = 0; k < 6; ++k)
+    CICE_HIP(hipMemcpyAsync(d.p + (18 + k) * np, io6[k], np * 8, hipMemcpyHostToDevice, s));
+  if (icellu) {
+    CICE_HIP(hipMemcpyAsync(li.p, ui, (size_t)icellu * 4, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p + np, uj, (size_t)icellu * 4, hipMemcpyHostToDevice, s));
+  }
+  StepuListArgs a{};
+  a.nx = nx; a.ny = ny; a.icellu = icellu; a.ui = li.p; a.uj = li.p + np;
+  for (int k = 0; k < 10; ++k) a.in[k] = d.p + k * np;
+  a.str = d.p + 10 * np;
+  for (int k = 0; k < 6; ++k) a.io[k] = d.p + (18 + k) * np;
+  if (icellu) {
+    hipLaunchKernelGGL(k_stepu_list, grid1(icellu), dim3(256), 0, s, a);
+    CICE_HIP(hipGetLastError());
+  }
+  for (int k = 0; k < 6; ++k)
+    CICE_HIP(hipMemcpyAsync(io6[k], d.p + (18 + k) * np, np * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+}
+
+}  // namespace cice

@@ -1,0 +1,44 @@
+// Ghost-cell update on the device: on-rank copies by address list, off-rank
+// rows/columns packed and exchanged with RCCL point-to-point over xGMI.
+// Replaces ice_HaloUpdate2DR8 / 2DI4 (mpi/ice_boundary.F90:1028-1417, 1820-...)
+// for non-tripole grids.  Several fields (e.g. uvel and vvel) travel in ONE
+// message per neighbour: the exchange is latency-bound (2.6-29 KB per field).
+#pragma once
+#include <vector>
+
+#include "common.h"
+#include "domain.h"
+
+struct ncclComm;
+
+namespace cice {
+
+class Halo {
+ public:
+  Halo() = default;
+  ~Halo();
+  void init(const Domain& d, hipStream_t s);
+  void comm_init(const char uid[128], int rank, int nranks);
+  bool multi_rank() const { return nranks_ > 1; }
+  // nfields fields of element type T, field k starting at base + k*stride (elements)
+  void update_r8(double* base, int nfields, size_t stride);
+  void update_i4(int32_t* base, int nfields, size_t stride);
+  // Device pointers to the on-rank copy list, for kernels that fold it in.
+  const int32_t* d_src() const { return src_.p; }
+  const int32_t* d_dst() const { return dst_.p; }
+  int ncopy() const { return ncopy_; }
+
+ private:
+  template <class T>
+  void update(T* base, int nfields, size_t stride);
+  hipStream_t stream_ = nullptr;
+  int ncopy_ = 0, rank_ = 0, nranks_ = 1;
+  DevBuf<int32_t> src_, dst_, send_addr_, recv_addr_;
+  std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
+  int nsend_ = 0, nrecv_ = 0;
+  DevBuf<double> sendbuf_, recvbuf_;  // sized for MAXF fields of 8-byte elements
+  ncclComm* comm_ = nullptr;
+  static constexpr int MAXF = 4;
+};
+
+}  // namespace cice

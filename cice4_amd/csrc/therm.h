@@ -1,0 +1,50 @@
+// Column thermodynamics on the device (source/ice_therm_vertical.F90).
+#pragma once
+#include "common.h"
+
+namespace cice {
+
+struct ThermoParams {  // module state of ice_therm_vertical (:45-79) after init_thermo_vertical
+  double salin[NILYR + 1], Tmlt[NILYR + 1];
+  double ustar_min;
+  int l_brine, heat_capacity, calc_Tsfc, conduct;
+  int tr_iage, nt_Tsfc, nt_iage;
+  void init(const cice_thermo_config& c);
+};
+
+// Pointers of one launch.  Index of category n, block b, plane k, cell q (0-based):
+//   per-category 2-D:   ((b*ncat + n)*np + q)
+//   trcrn:              (((b*ncat + n)*NTRCR + it)*np + q)
+//   eicen / esnon:      ((b*ncat*NILYR + n*NILYR + k)*np + q)   (NSLYR for esnon)
+//   Sswabs / Iswabs:    (((b*ncat + n)*NSLYR + k)*np + q)       (NILYR for Iswabs)
+//   forcing, onsets:    (b*np + q)
+// The single-call form uses ncat = 1, nblocks = 1 and an index list.
+struct ThermoArgs {
+  ThermoParams p;
+  int nx, ny, ncat, nblocks;
+  double dt, yday;
+  // list mode (reference signature): icells entries; dense mode: list == nullptr
+  int icells;
+  const int32_t *indxi, *indxj;
+  const int32_t* blk;  // dense mode: ilo,ihi,jlo,jhi per block
+  double *aicen, *trcrn, *vicen, *vsnon, *eicen, *esnon;
+  const double *flw, *potT, *Qa, *rhoa, *fsnow, *fbot, *Tbot, *lhcoef, *shcoef;
+  double *fswsfc, *fswint, *fswthrun, *Sswabs, *Iswabs;
+  double *fsurfn, *fcondtopn, *fsensn, *flatn, *fswabsn, *flwoutn, *evapn, *freshn, *fsaltn, *fhocnn,
+      *meltt, *melts, *meltb, *congel, *snoice, *mlt_onset, *frz_onset;
+  unsigned long long* errkey;   // atomicMin target, initialised to ~0
+  unsigned long long* nupdates; // dense mode: number of columns updated
+};
+
+void thermo_launch_list(const ThermoArgs& a, hipStream_t s);
+void thermo_launch_dense(const ThermoArgs& a, hipStream_t s);
+
+struct FrzmltArgs {
+  int nx, ny, ilo, ihi, jlo, jhi;
+  double dt, ustar_min;
+  const double *aice, *frzmlt, *eicen, *esnon, *sst, *Tf, *strocnxT, *strocnyT;
+  double *Tbot, *fbot, *rside;
+};
+void frzmlt_launch(const FrzmltArgs& a, hipStream_t s);
+
+}  // namespace cice

@@ -1,0 +1,315 @@
+"""ctypes binding of libcice4_amd.so (C-ABI in include/cice4_amd.h).
+
+This is the Python stand-in for the Fortran ISO_C_BINDING shim
+(cice4_amd/fortran/): same entry points, same argument order.  There is NO
+CPU fallback: if the HIP library is missing or a device call fails, the call
+raises.  Arrays are C-contiguous numpy arrays whose memory is the reference's
+column-major layout: Fortran (nx,ny[,k][,nblocks]) <-> numpy ([nblocks,][k,] ny, nx).
+"""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, "libcice4_amd.so")
+NCAT, NILYR, NSLYR, MAX_NTRCR = 5, 4, 1, 5
+
+SIG_NAMES = ("stressp_1", "stressp_2", "stressp_3", "stressp_4", "stressm_1", "stressm_2",
+             "stressm_3", "stressm_4", "stress12_1", "stress12_2", "stress12_3", "stress12_4")
+EVP_GRID = ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
+            "uarear", "tinyarea", "fcor", "tmask", "umask")
+EVP_IN = ("aice", "vice", "vsno", "aice0", "aicen", "vicen", "strairxT", "strairyT", "uocn", "vocn",
+          "ss_tltx", "ss_tlty")
+EVP_IO = ("uvel", "vvel") + SIG_NAMES + ("iceumask", "fm", "strtltx", "strtlty", "strocnx", "strocny",
+                                          "strintx", "strinty")
+EVP_OUT = ("strairx", "strairy", "strength", "divu", "shear", "rdg_conv", "rdg_shear", "prs_sig",
+           "strocnxT", "strocnyT")
+THERMO_STATE = ("aicen", "trcrn", "vicen", "vsnon", "eicen", "esnon")
+THERMO_FORCING = ("flw", "potT", "Qa", "rhoa", "fsnow", "fbot", "Tbot")
+THERMO_CAT_IN = ("lhcoef", "shcoef")
+THERMO_SW = ("fswsfc", "fswint", "fswthrun", "Sswabs", "Iswabs")
+THERMO_OUT = ("fsurfn", "fcondtopn", "fsensn", "flatn", "fswabsn", "flwoutn", "evapn", "freshn",
+              "fsaltn", "fhocnn", "meltt", "melts", "meltb", "congel", "snoice")
+THERMO_ONSET = ("mlt_onset", "frz_onset")
+THERMO_ARGS = THERMO_STATE + ("flw", "potT", "Qa", "rhoa", "fsnow", "fbot", "Tbot", "lhcoef",
+                              "shcoef") + THERMO_SW + THERMO_OUT + THERMO_ONSET
+
+
+class CiceError(RuntimeError):
+    pass
+
+
+class EvpGrid(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in EVP_GRID]
+
+
+class EvpConfig(C.Structure):
+    _fields_ = [("ndte", C.c_int), ("evp_damping", C.c_int), ("kstrength", C.c_int),
+                ("krdg_partic", C.c_int), ("krdg_redist", C.c_int), ("mu_rdg", C.c_double)]
+
+
+class EvpFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in EVP_IN + EVP_IO + EVP_OUT]
+
+
+class ThermoConfig(C.Structure):
+    _fields_ = [("heat_capacity", C.c_int), ("calc_Tsfc", C.c_int), ("conduct", C.c_int),
+                ("ustar_min", C.c_double), ("tr_iage", C.c_int), ("nt_Tsfc", C.c_int),
+                ("nt_iage", C.c_int)]
+
+
+class ThermoFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in THERMO_STATE + THERMO_FORCING + THERMO_CAT_IN + THERMO_SW
+                + THERMO_OUT + THERMO_ONSET]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (python -c 'import
+    __graft_entry__ as g; g.build()' or make -C cice4_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise CiceError(f"{LIBPATH} not found: build the HIP extension first (make -C cice4_amd/csrc)")
+        _lib = C.CDLL(LIBPATH)
+        _lib.cice_last_error.restype = C.c_char_p
+        _lib.cice_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a, dtype=None):
+    if a is None:
+        return None
+    if dtype is not None and a.dtype != dtype:
+        raise TypeError(f"expected {dtype}, got {a.dtype}")
+    if not a.flags["C_CONTIGUOUS"]:
+        raise ValueError("array must be C-contiguous")
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f8(a):
+    return _p(a, np.float64)
+
+
+def _i4(a):
+    return _p(a, np.int32)
+
+
+class Context:
+    """One rank = one GPU (cice_ctx)."""
+
+    def __init__(self, device=-1):
+        self.lib = load()
+        self.h = C.c_void_p()
+        rc = self.lib.cice_create(C.byref(self.h), C.c_int(device))
+        if rc:
+            raise CiceError("cice_create failed")
+        self.nx = self.ny = self.nblocks = 0
+        self._keep = []
+
+    def close(self):
+        if self.h:
+            self.lib.cice_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            msg = self.lib.cice_last_error(self.h)
+            raise CiceError(f"cice4_amd error {rc}: {msg.decode() if msg else ''}")
+
+    def sync(self):
+        self._ck(self.lib.cice_device_sync(self.h))
+
+    # ---- domain -------------------------------------------------------
+    def domain_create(self, nxg, nyg, bsx, bsy, ew=1, ns=0, rank=0, npx=1, npy=1):
+        self._ck(self.lib.cice_domain_create(self.h, nxg, nyg, bsx, bsy, ew, ns, rank, npx, npy))
+        info = (C.c_int * 9)()
+        self._ck(self.lib.cice_domain_info(self.h, info))
+        self.nx, self.ny, self.nblocks = info[0], info[1], info[2]
+        self.dinfo = dict(nx=info[0], ny=info[1], nblocks=info[2], nblocks_tot=info[3], ncopy=info[4],
+                          nsend=info[5], nrecv=info[6], nsend_elems=info[7], nrecv_elems=info[8],
+                          nxg=nxg, nyg=nyg)
+        return self.domain()
+
+    def domain(self):
+        """dict describing the local blocks + on-rank halo list (host logic, no GPU needed)."""
+        d = dict(self.dinfo)
+        cols = {k: [] for k in ("ilo", "ihi", "jlo", "jhi", "i0", "j0", "gid", "owner")}
+        for b in range(self.nblocks):
+            info = (C.c_int * 8)()
+            self._ck(self.lib.cice_domain_block(self.h, b, info))
+            for k, v in zip(cols, info):
+                cols[k].append(v)
+        d.update({k: np.array(v, np.int32) for k, v in cols.items()})
+        src = np.zeros(d["ncopy"], np.int32); dst = np.zeros(d["ncopy"], np.int32)
+        if d["ncopy"]:
+            self._ck(self.lib.cice_domain_halo_local(self.h, _i4(src), _i4(dst)))
+        d["hsrc"], d["hdst"] = src, dst
+        return d
+
+    def halo_msgs(self, direction):
+        out = []
+        n = self.dinfo["nrecv" if direction else "nsend"]
+        for m in range(n):
+            peer = C.c_int(); cnt = C.c_int()
+            self._ck(self.lib.cice_domain_halo_msg(self.h, direction, m, C.byref(peer), C.byref(cnt), None))
+            addr = np.zeros(cnt.value, np.int32)
+            self._ck(self.lib.cice_domain_halo_msg(self.h, direction, m, None, None, _i4(addr)))
+            out.append((peer.value, addr))
+        return out
+
+    # ---- communication --------------------------------------------------
+    def comm_unique_id(self):
+        buf = C.create_string_buffer(128)
+        rc = self.lib.cice_comm_unique_id(buf)
+        if rc:
+            raise CiceError(f"cice_comm_unique_id failed ({rc})")
+        return buf.raw
+
+    def comm_init(self, uid, rank, nranks):
+        self._ck(self.lib.cice_comm_init(self.h, C.c_char_p(uid), rank, nranks))
+
+    # ---- EVP -----------------------------------------------------------------
+    def evp_init(self, grid, ndte=120, evp_damping=False, kstrength=1, krdg_partic=1, krdg_redist=1,
+                 mu_rdg=4.0):
+        g = EvpGrid()
+        for n in EVP_GRID:
+            a = grid[n]
+            setattr(g, n, (_i4(a) if n in ("tmask", "umask") else _f8(a)))
+        cfg = EvpConfig(ndte, int(evp_damping), kstrength, krdg_partic, krdg_redist, mu_rdg)
+        self._ck(self.lib.cice_evp_init(self.h, C.byref(cfg), C.byref(g)))
+
+    @staticmethod
+    def _evp_fields(s, need_out=True):
+        f = EvpFields()
+        for n in EVP_IN + EVP_IO:
+            setattr(f, n, (_i4(s[n]) if n == "iceumask" else _f8(s[n])))
+        for n in EVP_OUT:
+            setattr(f, n, _f8(s[n]) if (n in s) else None)
+        return f
+
+    def evp(self, dt, s):
+        """Drop-in evp(dt): s holds the module arrays (modified in place)."""
+        f = self._evp_fields(s)
+        self._ck(self.lib.cice_evp(self.h, C.c_double(dt), C.byref(f)))
+
+    def evp_upload(self, s):
+        f = self._evp_fields(s)
+        self._ck(self.lib.cice_evp_upload(self.h, C.byref(f)))
+
+    def evp_download(self, s):
+        f = self._evp_fields(s)
+        self._ck(self.lib.cice_evp_download(self.h, C.byref(f)))
+
+    def evp_step(self, dt):
+        self._ck(self.lib.cice_evp_step(self.h, C.c_double(dt)))
+
+    def evp_prepare(self, dt):
+        self._ck(self.lib.cice_evp_prepare(self.h, C.c_double(dt)))
+
+    def evp_subcycles(self, ksub0, nsub, timed=False):
+        ms = C.c_float(0.0)
+        self._ck(self.lib.cice_evp_subcycles(self.h, ksub0, nsub, C.byref(ms) if timed else None))
+        return ms.value
+
+    def evp_finish(self):
+        self._ck(self.lib.cice_evp_finish(self.h))
+
+    def evp_set_option(self, key, value):
+        self._ck(self.lib.cice_evp_set_option(self.h, key.encode(), int(value)))
+
+    def evp_active_cells(self):
+        nt = C.c_longlong(); nu = C.c_longlong()
+        self._ck(self.lib.cice_evp_active_cells(self.h, C.byref(nt), C.byref(nu)))
+        return nt.value, nu.value
+
+    def evp_stress(self, dt, ndte, damping, ksub, icellt, indxti, indxtj, uvel, vvel, g, strength,
+                   sig, diag, str8):
+        ny, nx = uvel.shape
+        self._ck(self.lib.cice_evp_stress(
+            self.h, C.c_double(dt), ndte, int(damping), nx, ny, ksub, icellt, _i4(indxti), _i4(indxtj),
+            _f8(uvel), _f8(vvel), _f8(g["dxt"]), _f8(g["dyt"]), _f8(g["dxhy"]), _f8(g["dyhx"]),
+            _f8(g["cxp"]), _f8(g["cyp"]), _f8(g["cxm"]), _f8(g["cym"]), _f8(g["tarear"]),
+            _f8(g["tinyarea"]), _f8(strength), *[_f8(sig[k]) for k in range(12)], _f8(diag["shear"]),
+            _f8(diag["divu"]), _f8(diag["prs_sig"]), _f8(diag["rdg_conv"]), _f8(diag["rdg_shear"]),
+            _f8(str8)))
+
+    def evp_stepu(self, icellu, indxui, indxuj, aiu, str8, uocn, vocn, waterx, watery, forcex, forcey,
+                  umassdtei, fm, uarear, strocnx, strocny, strintx, strinty, uvel, vvel):
+        ny, nx = uvel.shape
+        self._ck(self.lib.cice_evp_stepu(
+            self.h, nx, ny, icellu, _i4(indxui), _i4(indxuj), _f8(aiu), _f8(str8), _f8(uocn), _f8(vocn),
+            _f8(waterx), _f8(watery), _f8(forcex), _f8(forcey), _f8(umassdtei), _f8(fm), _f8(uarear),
+            _f8(strocnx), _f8(strocny), _f8(strintx), _f8(strinty), _f8(uvel), _f8(vvel)))
+
+    def halo_update(self, field):
+        """field: (nlev?, nblocks, ny, nx) float64 or int32, updated in place."""
+        n = self.nblocks * self.ny * self.nx
+        nlev = field.size // n
+        if field.dtype == np.float64:
+            self._ck(self.lib.cice_halo_update_r8(self.h, _f8(field), nlev))
+        else:
+            self._ck(self.lib.cice_halo_update_i4(self.h, _i4(field), nlev))
+
+    # ---- thermodynamics ----------------------------------------------------------
+    def thermo_init(self, heat_capacity=True, calc_Tsfc=True, conduct="MU71", ustar_min=0.05,
+                    tr_iage=True, nt_Tsfc=1, nt_iage=2):
+        cfg = ThermoConfig(int(heat_capacity), int(calc_Tsfc), 0 if conduct == "MU71" else 1, ustar_min,
+                           int(tr_iage), nt_Tsfc, nt_iage)
+        salin = np.zeros(NILYR + 1); tmlt = np.zeros(NILYR + 1)
+        self._ck(self.lib.cice_thermo_init(self.h, C.byref(cfg), _f8(salin), _f8(tmlt)))
+        return salin, tmlt
+
+    def thermo_vertical(self, dt, icells, indxi, indxj, a, yday=1.0):
+        ny, nx = a["aicen"].shape
+        ls = C.c_int32(0); istop = C.c_int32(0); jstop = C.c_int32(0)
+        self._ck(self.lib.cice_thermo_vertical(
+            self.h, nx, ny, C.c_double(dt), icells, _i4(indxi), _i4(indxj),
+            *[_f8(a[k]) for k in THERMO_ARGS], C.c_double(yday), C.byref(ls), C.byref(istop),
+            C.byref(jstop)))
+        return ls.value, istop.value, jstop.value
+
+    def thermo_batch_alloc(self, nx, ny, nblocks):
+        self._ck(self.lib.cice_thermo_batch_alloc(self.h, nx, ny, nblocks))
+
+    @staticmethod
+    def _thermo_fields(a, outputs=True):
+        f = ThermoFields()
+        for n, _t in ThermoFields._fields_:
+            setattr(f, n, _f8(a[n]) if n in a else None)
+        return f
+
+    def thermo_batch_upload(self, a):
+        f = self._thermo_fields(a)
+        self._ck(self.lib.cice_thermo_batch_upload(self.h, C.byref(f)))
+
+    def thermo_batch_step(self, dt, yday=1.0, timed=False):
+        nupd = C.c_longlong(0); ms = C.c_float(0.0)
+        st = [C.c_int32(0) for _ in range(5)]
+        self._ck(self.lib.cice_thermo_batch_step(self.h, C.c_double(dt), C.c_double(yday), C.byref(nupd),
+                                                 *[C.byref(x) for x in st],
+                                                 C.byref(ms) if timed else None))
+        return dict(n_updates=nupd.value, l_stop=st[0].value, istop=st[1].value, jstop=st[2].value,
+                    nstop=st[3].value, bstop=st[4].value, ms=ms.value)
+
+    def thermo_batch_download(self, a):
+        f = self._thermo_fields(a)
+        self._ck(self.lib.cice_thermo_batch_download(self.h, C.byref(f)))
+
+    def frzmlt_bottom_lateral(self, ilo, ihi, jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf,
+                              strocnxT, strocnyT):
+        ny, nx = aice.shape
+        Tbot = np.zeros((ny, nx)); fbot = np.zeros((ny, nx)); rside = np.zeros((ny, nx))
+        self._ck(self.lib.cice_frzmlt_bottom_lateral(
+            self.h, nx, ny, ilo, ihi, jlo, jhi, C.c_double(dt), _f8(aice), _f8(frzmlt), _f8(eicen),
+            _f8(esnon), _f8(sst), _f8(Tf), _f8(strocnxT), _f8(strocnyT), _f8(Tbot), _f8(fbot),
+            _f8(rside)))
+        return Tbot, fbot, rside

@@ -1,0 +1,228 @@
+/* cice4_amd -- C-ABI of the MI355X-native EVP-dynamics + column-thermodynamics
+ * hot path of CICE4 (COSIMA/cice4).  Plain pointers and sizes only: this is
+ * what a Fortran `bind(C)` interface block (cice4_amd/fortran/) binds to.
+ *
+ * Array convention (= the reference's): every field is a contiguous
+ * column-major Fortran array, i fastest, dimensioned (nx_block,ny_block) or
+ * (nx_block,ny_block,nblocks) with one ghost cell on each side
+ * (source/ice_blocks.F90:56-62); 3-D/4-D fields put the extra dimension(s)
+ * between (nx_block,ny_block) and the block index exactly as
+ * source/ice_state.F90:55-148 does.  `logical` masks are 4-byte (non-zero =
+ * .true.).  Index lists hold 1-based indices.  All reals are double.
+ *
+ * Every function returns 0 on success or a negative CICE_E* code; the text
+ * is available from cice_last_error().  Nothing here ever calls exit()/abort():
+ * physics failures come back as (l_stop, istop, jstop) for the caller's
+ * abort_ice, as in drivers/cice4/CICE_RunMod.F90:532-544.
+ *
+ * Citations are file:line under the reference checkout.
+ */
+#ifndef CICE4_AMD_H
+#define CICE4_AMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CICE_NCAT 5       /* source/ice_domain_size.F90:37-47 */
+#define CICE_NILYR 4
+#define CICE_NSLYR 1
+#define CICE_MAX_NTRCR 5
+
+enum {
+  CICE_OK = 0,
+  CICE_EINVAL = -1,   /* bad argument / call order */
+  CICE_EDEVICE = -2,  /* HIP runtime error (no GPU, out of memory, launch failure) */
+  CICE_ECOMM = -3,    /* RCCL error */
+  CICE_EUNSUPPORTED = -4
+};
+
+typedef struct cice_ctx cice_ctx;
+
+/* ---- lifecycle --------------------------------------------------------- */
+/* One context = one rank = one GPU (the reference is one MPI task, no threads:
+ * mpi/ice_communicate.F90:109-136).  device < 0: use HIP's current device. */
+int cice_create(cice_ctx **ctx, int device);
+int cice_destroy(cice_ctx *ctx);
+const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
+int cice_device_sync(cice_ctx *ctx);
+
+/* ---- domain: replaces init_domain_blocks + init_domain_distribution +
+ * ice_HaloCreate (source/ice_domain.F90:96,258; mpi/ice_boundary.F90:153).
+ * Host logic only -- usable without a GPU. boundary: 0 open, 1 cyclic, 2 closed.
+ * Blocks are dealt to an (npx x npy) process grid in contiguous rectangles
+ * (cartesian distribution, source/ice_distribution.F90:78). */
+int cice_domain_create(cice_ctx *ctx, int nx_global, int ny_global, int block_size_x,
+                       int block_size_y, int ew_boundary, int ns_boundary, int rank, int npx,
+                       int npy);
+/* info: nx_block, ny_block, nblocks(local), nblocks_tot, n_local_copies, n_send_msgs,
+ *       n_recv_msgs, n_send_elems, n_recv_elems */
+int cice_domain_info(const cice_ctx *ctx, int info[9]);
+/* info: ilo, ihi, jlo, jhi (1-based, = type block, source/ice_blocks.F90:32-45),
+ *       i0, j0 (0-based global index of cell ilo/jlo), global block id, owner rank */
+int cice_domain_block(const cice_ctx *ctx, int local_block, int info[8]);
+/* on-rank halo copy list (0-based linear addresses into the (nx_block,ny_block,nblocks)
+ * array): a[dst[n]] = a[src[n]]; = srcLocalAddr/dstLocalAddr of serial/ice_boundary.F90:49-62 */
+int cice_domain_halo_local(const cice_ctx *ctx, int32_t *src, int32_t *dst);
+/* msg-th send (dir=0) / recv (dir=1) message: peer rank, element count, addresses */
+int cice_domain_halo_msg(const cice_ctx *ctx, int dir, int msg, int *peer, int *count,
+                         int32_t *addr);
+
+/* ---- inter-GPU halo transport (RCCL over xGMI; replaces mpi/ice_boundary.F90's
+ * MPI_ISEND/IRECV).  uid: 128-byte ncclUniqueId from cice_comm_unique_id on rank 0,
+ * distributed by the caller (MPI_Bcast in a Fortran driver, torch.distributed here). */
+int cice_comm_unique_id(char uid[128]);
+int cice_comm_init(cice_ctx *ctx, const char uid[128], int rank, int nranks);
+
+/* ---- EVP dynamics (source/ice_dyn_evp.F90) ----------------------------- */
+typedef struct { /* source/ice_grid.F90:58-133; each (nx_block,ny_block,nblocks) */
+  const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym, *tarea, *uarea, *tarear,
+      *uarear, *tinyarea;
+  const double *fcor;           /* fcor_blk, ice_dyn_evp.F90:105,503 */
+  const int32_t *tmask, *umask; /* logical */
+} cice_evp_grid;
+
+typedef struct { /* namelist + ridging switches read by evp (ice_dyn_evp.F90:64-74; ice_mechred.F90:64-79) */
+  int ndte, evp_damping;
+  int kstrength, krdg_partic, krdg_redist;
+  double mu_rdg;
+} cice_evp_config;
+
+/* init_evp (ice_dyn_evp.F90:441): allocates device state, uploads the grid, zeroes
+ * uvel/vvel/stresses/iceumask on the device.  Requires cice_domain_create. */
+int cice_evp_init(cice_ctx *ctx, const cice_evp_config *cfg, const cice_evp_grid *grid);
+
+/* The module arrays evp(dt) reads and writes (ice_state.F90:55-148, ice_flux.F90:42-99).
+ * All host pointers, (nx_block,ny_block,nblocks) unless noted.  in = read by evp,
+ * io = read and written, out = written. */
+typedef struct {
+  /* in */
+  const double *aice, *vice, *vsno, *aice0;
+  const double *aicen, *vicen; /* (nx_block,ny_block,ncat,nblocks) */
+  const double *strairxT, *strairyT, *uocn, *vocn, *ss_tltx, *ss_tlty;
+  /* io */
+  double *uvel, *vvel;
+  double *stressp_1, *stressp_2, *stressp_3, *stressp_4, *stressm_1, *stressm_2, *stressm_3,
+      *stressm_4, *stress12_1, *stress12_2, *stress12_3, *stress12_4;
+  int32_t *iceumask; /* logical */
+  double *fm, *strtltx, *strtlty, *strocnx, *strocny, *strintx, *strinty;
+  /* out */
+  double *strairx, *strairy, *strength, *divu, *shear, *rdg_conv, *rdg_shear, *prs_sig,
+      *strocnxT, *strocnyT;
+} cice_evp_fields;
+
+/* Drop-in for `call evp(dt)` (ice_dyn_evp.F90:119-432): upload, run on the GPU,
+ * download.  Equivalent to cice_evp_upload + cice_evp_step + cice_evp_download. */
+int cice_evp(cice_ctx *ctx, double dt, cice_evp_fields *f);
+int cice_evp_upload(cice_ctx *ctx, const cice_evp_fields *f);   /* in + io fields -> HBM */
+int cice_evp_step(cice_ctx *ctx, double dt);                    /* evp(dt) on resident state */
+int cice_evp_download(cice_ctx *ctx, cice_evp_fields *f);       /* io + out fields -> host */
+
+/* Pieces of evp on the resident state, for tests and measurement:
+ * prepare = ice_dyn_evp.F90:214-344 (prep1, masks, T->U, prep2, strength, halos);
+ * subcycles = nsub passes of :347-404 starting at subcycle ksub0 (1-based; the pass with
+ * ksub == ndte also writes divu, shear, rdg_conv, rdg_shear, prs_sig, strint, strocn); finish = :410-428.
+ * elapsed_ms (may be NULL) is the HIP-event time of the launches on the library's stream. */
+int cice_evp_prepare(cice_ctx *ctx, double dt);
+int cice_evp_subcycles(cice_ctx *ctx, int ksub0, int nsub, float *elapsed_ms);
+int cice_evp_finish(cice_ctx *ctx);
+/* tuning / A-B switches: key "tile_rows" (rows of T-cells per workgroup tile: 8,16,32),
+ * "use_graph" (0/1).  Results never depend on them. */
+int cice_evp_set_option(cice_ctx *ctx, const char *key, int value);
+/* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
+ * (= sum of icellt / icellu, ice_dyn_evp.F90:160-162) */
+int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucells);
+
+/* Per-routine entries with the reference's own argument lists (host pointers, one
+ * (nx_block,ny_block) block), for parity tests: stress ice_dyn_evp.F90:947-966,
+ * stepu :1302-1313.  Scalars come from the cice_evp_config/dt given here. */
+int cice_evp_stress(cice_ctx *ctx, double dt, int ndte, int evp_damping, int nx_block,
+                    int ny_block, int ksub, int icellt, const int32_t *indxti,
+                    const int32_t *indxtj, const double *uvel, const double *vvel,
+                    const double *dxt, const double *dyt, const double *dxhy, const double *dyhx,
+                    const double *cxp, const double *cyp, const double *cxm, const double *cym,
+                    const double *tarear, const double *tinyarea, const double *strength,
+                    double *stressp_1, double *stressp_2, double *stressp_3, double *stressp_4,
+                    double *stressm_1, double *stressm_2, double *stressm_3, double *stressm_4,
+                    double *stress12_1, double *stress12_2, double *stress12_3,
+                    double *stress12_4, double *shear, double *divu, double *prs_sig,
+                    double *rdg_conv, double *rdg_shear, double *str /* (nx,ny,8) */);
+int cice_evp_stepu(cice_ctx *ctx, int nx_block, int ny_block, int icellu, const int32_t *indxui,
+                   const int32_t *indxuj, const double *aiu, const double *str,
+                   const double *uocn, const double *vocn, const double *waterx,
+                   const double *watery, const double *forcex, const double *forcey,
+                   const double *umassdtei, const double *fm, const double *uarear,
+                   double *strocnx, double *strocny, double *strintx, double *strinty,
+                   double *uvel, double *vvel);
+
+/* Generic halo update of a host field through the device path (ice_HaloUpdate2DR8 /
+ * 2DI4, mpi/ice_boundary.F90:1028,1820): nlev slabs of (nx_block,ny_block,nblocks). */
+int cice_halo_update_r8(cice_ctx *ctx, double *field, int nlev);
+int cice_halo_update_i4(cice_ctx *ctx, int32_t *field, int nlev);
+
+/* ---- column thermodynamics (source/ice_therm_vertical.F90) -------------- */
+typedef struct { /* module variables :56-79 + tracer slots (ice_state.F90 nt_Tsfc, nt_iage) */
+  int heat_capacity, calc_Tsfc; /* logical */
+  int conduct;                  /* 0 = 'MU71', 1 = 'bubbly' */
+  double ustar_min;
+  int tr_iage, nt_Tsfc, nt_iage; /* 1-based */
+} cice_thermo_config;
+
+/* init_thermo_vertical (:533): salinity / melting-temperature profile; returns them
+ * (nilyr+1 values each) when the pointers are non-NULL. */
+int cice_thermo_init(cice_ctx *ctx, const cice_thermo_config *cfg, double *salin, double *Tmlt);
+
+/* Drop-in for `call thermo_vertical(...)` (:108-132), same argument order, host pointers;
+ * trcrn is (nx,ny,max_ntrcr), eicen (nx,ny,nilyr), esnon (nx,ny,nslyr). */
+int cice_thermo_vertical(cice_ctx *ctx, int nx_block, int ny_block, double dt, int icells,
+                         const int32_t *indxi, const int32_t *indxj, double *aicen,
+                         double *trcrn, double *vicen, double *vsnon, double *eicen,
+                         double *esnon, const double *flw, const double *potT, const double *Qa,
+                         const double *rhoa, const double *fsnow, const double *fbot,
+                         const double *Tbot, const double *lhcoef, const double *shcoef,
+                         double *fswsfc, double *fswint, double *fswthrun, double *Sswabs,
+                         double *Iswabs, double *fsurfn, double *fcondtopn, double *fsensn,
+                         double *flatn, double *fswabsn, double *flwoutn, double *evapn,
+                         double *freshn, double *fsaltn, double *fhocnn, double *meltt,
+                         double *melts, double *meltb, double *congel, double *snoice,
+                         double *mlt_onset, double *frz_onset, double yday, int32_t *l_stop,
+                         int32_t *istop, int32_t *jstop);
+
+/* Batched, device-resident form: every category of every local block in one launch
+ * (the n = 1..ncat loop of step_therm1, drivers/cice4/CICE_RunMod.F90:374-591, around
+ * thermo_vertical; cells with aicen(i,j,n) > puny on the physical domain are updated).
+ * Field shapes: state aicen/vicen/vsnon (nx,ny,ncat,nb), trcrn (nx,ny,max_ntrcr,ncat,nb),
+ * eicen (nx,ny,ncat*nilyr,nb), esnon (nx,ny,ncat*nslyr,nb); forcing (nx,ny,nb);
+ * per-category fields (nx,ny,ncat,nb); Sswabs (nx,ny,nslyr,ncat,nb); Iswabs (nx,ny,nilyr,ncat,nb). */
+typedef struct {
+  double *aicen, *trcrn, *vicen, *vsnon, *eicen, *esnon;
+  const double *flw, *potT, *Qa, *rhoa, *fsnow, *fbot, *Tbot;
+  const double *lhcoef, *shcoef;                      /* per category */
+  double *fswsfc, *fswint, *fswthrun, *Sswabs, *Iswabs; /* per category */
+  double *fsurfn, *fcondtopn, *fsensn, *flatn, *fswabsn, *flwoutn, *evapn, *freshn, *fsaltn,
+      *fhocnn, *meltt, *melts, *meltb, *congel, *snoice; /* per category, out */
+  double *mlt_onset, *frz_onset;                         /* (nx,ny,nb) io */
+} cice_thermo_fields;
+
+int cice_thermo_batch_alloc(cice_ctx *ctx, int nx_block, int ny_block, int nblocks);
+int cice_thermo_batch_upload(cice_ctx *ctx, const cice_thermo_fields *host);
+/* One pass over all (cell,category) columns.  n_updates: number of columns updated;
+ * l_stop/istop/jstop/nstop/bstop: first failing column in (block, category, list) order. */
+int cice_thermo_batch_step(cice_ctx *ctx, double dt, double yday, long long *n_updates,
+                           int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop,
+                           int32_t *bstop, float *elapsed_ms);
+int cice_thermo_batch_download(cice_ctx *ctx, cice_thermo_fields *host);
+
+/* frzmlt_bottom_lateral (:605-824), one block, host pointers;
+ * eicen (nx,ny,ntilyr), esnon (nx,ny,ntslyr). */
+int cice_frzmlt_bottom_lateral(cice_ctx *ctx, int nx_block, int ny_block, int ilo, int ihi,
+                               int jlo, int jhi, double dt, const double *aice,
+                               const double *frzmlt, const double *eicen, const double *esnon,
+                               const double *sst, const double *Tf, const double *strocnxT,
+                               const double *strocnyT, double *Tbot, double *fbot,
+                               double *rside);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

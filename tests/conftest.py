@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """CPU checker (plain-C restatement, oracle/)."""
+    from oracle import oracle
+    oracle.build()
+    return oracle.Oracle()
+
+
+def _ref(cfg):
+    from oracle import refapi
+    if not refapi.available(cfg):
+        pytest.skip(f"compiled reference oracle/_ref/libcice_ref_{cfg}.so not built")
+    return refapi.Ref(cfg)
+
+
+@pytest.fixture(scope="session")
+def ref_gx3():
+    return _ref("gx3")
+
+
+@pytest.fixture(scope="session")
+def ref_gx3b4():
+    return _ref("gx3b4")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """Device context of the product library.  No fallback: fails if there is no GPU."""
+    from cice4_amd import lib
+    c = lib.Context()
+    c.sync()  # raises CiceError without a device
+    return c
+
+
+def single_block_domain(c, nxg, nyg, ew=1, ns=0):
+    return c.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=ns)
+
+
+def relerr(a, b):
+    """max |a-b| / max|b| over the field (field-level relative error of BASELINE.json)."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    den = np.abs(b).max()
+    if den == 0.0:
+        return np.abs(a).max()
+    return np.abs(a - b).max() / den

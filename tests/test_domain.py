@@ -1,0 +1,82 @@
+"""Host-side block decomposition / halo topology (cice4_amd/csrc/domain.cpp) against a
+brute-force global-index model, for one and several ranks, cyclic / open / closed edges and
+block sizes that do not divide the grid."""
+import numpy as np
+import pytest
+
+from cice4_amd import lib
+
+
+def brute_halo(nxg, nyg, bsx, bsy, ew, ns, dom):
+    """Expected ghost values for a field holding each cell's global id."""
+    nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
+    f = -np.ones((nb, ny, nx), np.int64)
+    for b in range(nb):
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                ig = dom["i0"][b] + (i - dom["ilo"][b]); jg = dom["j0"][b] + (j - dom["jlo"][b])
+                phys = dom["ilo"][b] <= i <= dom["ihi"][b] and dom["jlo"][b] <= j <= dom["jhi"][b]
+                if not phys:
+                    if not (dom["ilo"][b] - 1 <= i <= dom["ihi"][b] + 1 and dom["jlo"][b] - 1 <= j <= dom["jhi"][b] + 1):
+                        continue
+                    if ig < 0 or ig >= nxg:
+                        if ew != 1:
+                            continue
+                        ig %= nxg
+                    if jg < 0 or jg >= nyg:
+                        if ns != 1:
+                            continue
+                        jg %= nyg
+                f[b, j - 1, i - 1] = jg * nxg + ig
+    return f
+
+
+@pytest.mark.parametrize("nxg,nyg,bsx,bsy,ew,ns", [(24, 20, 24, 20, 1, 0), (24, 20, 12, 10, 1, 0),
+                                                   (24, 20, 8, 5, 1, 1), (25, 19, 8, 5, 1, 0),
+                                                   (24, 20, 12, 10, 0, 0), (24, 20, 6, 20, 2, 2)])
+def test_local_halo_lists(nxg, nyg, bsx, bsy, ew, ns):
+    c = lib.Context()
+    dom = c.domain_create(nxg, nyg, bsx, bsy, ew=ew, ns=ns)
+    want = brute_halo(nxg, nyg, bsx, bsy, ew, ns, dom)
+    f = want.copy()
+    ghost = np.ones_like(f, bool)
+    for b in range(dom["nblocks"]):
+        ghost[b, dom["jlo"][b] - 1:dom["jhi"][b], dom["ilo"][b] - 1:dom["ihi"][b]] = False
+    f[ghost] = -1
+    f = f.reshape(-1)
+    # sources are physical cells, destinations ghost cells, no destination twice
+    assert not ghost.reshape(-1)[dom["hsrc"]].any() and ghost.reshape(-1)[dom["hdst"]].all()
+    assert len(np.unique(dom["hdst"])) == len(dom["hdst"])
+    f[dom["hdst"]] = f[dom["hsrc"]]
+    assert np.array_equal(f.reshape(want.shape), want)
+
+
+@pytest.mark.parametrize("npx,npy", [(1, 2), (2, 2), (1, 4), (2, 1)])
+def test_multi_rank_messages_reproduce_single_rank_halo(npx, npy):
+    nxg, nyg, bsx, bsy = 24, 20, 6, 5
+    nr = npx * npy
+    ctxs = [lib.Context() for _ in range(nr)]
+    doms = [c.domain_create(nxg, nyg, bsx, bsy, ew=1, ns=0, rank=r, npx=npx, npy=npy) for r, c in enumerate(ctxs)]
+    assert sum(d["nblocks"] for d in doms) == doms[0]["nblocks_tot"]
+    fields, wants = [], []
+    for d in doms:
+        w = brute_halo(nxg, nyg, bsx, bsy, 1, 0, d)
+        f = w.copy()
+        for b in range(d["nblocks"]):
+            g = np.ones(f[b].shape, bool); g[d["jlo"][b] - 1:d["jhi"][b], d["ilo"][b] - 1:d["ihi"][b]] = False
+            f[b][g] = -1
+        fields.append(f.reshape(-1)); wants.append(w)
+    sends = [dict(c.halo_msgs(0)) for c in ctxs]
+    recvs = [dict(c.halo_msgs(1)) for c in ctxs]
+    for r in range(nr):
+        for peer, addr in recvs[r].items():
+            src = sends[peer][r]
+            assert len(src) == len(addr)
+            fields[r][addr] = fields[peer][src]      # both ends list elements in the same order
+    for r, d in enumerate(doms):
+        fields[r][d["hdst"]] = fields[r][d["hsrc"]]
+        assert np.array_equal(fields[r].reshape(wants[r].shape), wants[r]), r
+    # 1xN j-slabs: two peers at most, full rows incl. E/W ghost columns are NOT needed
+    if npx == 1:
+        for r in range(nr):
+            assert len(sends[r]) <= 2

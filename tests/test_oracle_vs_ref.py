@@ -1,0 +1,188 @@
+"""Pins the CPU checker (oracle/*.c) to the COMPILED REFERENCE (oracle/_ref, the Fortran
+under /root/reference built in place): bit-for-bit on every routine of the hot path.
+Skipped where oracle/_ref has not been built (it is built by __graft_entry__.build()
+wherever /root/reference exists and travels to the GPU box as a binary)."""
+import tempfile
+
+import numpy as np
+import pytest
+
+from cice4_amd import lib, synth
+
+DT, NDTE = 3600.0, 120
+GRIDK = ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear", "uarear",
+         "tinyarea", "fcor")
+STATE_IN = ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty",
+            "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty") + synth.SIG_NAMES
+EVP_OUT = ("uvel", "vvel", "strength", "divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strocnxT",
+           "strocnyT", "strocnx", "strocny", "strintx", "strinty", "strairx", "strairy", "fm", "strtltx",
+           "strtlty") + synth.SIG_NAMES
+
+
+def inject(ref, grid, s, dom):
+    for k in GRIDK:
+        ref.set(k, grid[k])
+    ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
+    for k in STATE_IN:
+        ref.set(k, s[k])
+    ref.set("iceumask", s["iceumask"].astype(float))
+    ny, nx = dom["ny"], dom["nx"]
+    ref.set("aicen", s["aicen"].reshape(-1, ny, nx)); ref.set("vicen", s["vicen"].reshape(-1, ny, nx))
+
+
+@pytest.mark.parametrize("cfg,bs", [("gx3", (100, 116)), ("gx3b4", (50, 58))])
+def test_whole_evp_bit_exact(cfg, bs, orc, request):
+    """evp(dt), 120 subcycles, on the reference's own blocks and halo (1 block and 2x2 blocks),
+    non-uniform synthetic grid with islands injected into the reference's module arrays."""
+    ref = request.getfixturevalue("ref_" + cfg)
+    nb = ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
+    ctx = lib.Context()
+    dom = ctx.domain_create(100, 116, bs[0], bs[1], ew=1, ns=0)
+    assert nb == dom["nblocks"]
+    gg = synth.global_grid(100, 116, perturb=0.15, land_frac=0.05)
+    grid = synth.block_fields(gg, dom)
+    for cover, damping in (("full", False), ("patchy", False), ("patchy", True)):
+        s = synth.evp_state(grid, dom, cover=cover)
+        ref.set_evp_parameters(DT, NDTE, damping); ref.set_strength_parameters()
+        orc.set_evp_parameters(DT, NDTE, damping); orc.set_strength_parameters()
+        inject(ref, grid, s, dom)
+        ref.evp(DT)
+        so = {k: v.copy() for k, v in s.items()}
+        orc.evp(orc.make_domain(dom, grid), so)
+        for k in EVP_OUT:
+            assert np.array_equal(ref.get(k), so[k]), (cover, damping, k)
+        assert np.array_equal(ref.get("iceumask"), so["iceumask"])
+        assert np.abs(so["uvel"]).max() > 0.01
+
+
+def test_halo_lists_equal_reference_halo(ref_gx3b4):
+    ref = ref_gx3b4
+    ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
+    dom = lib.Context().domain_create(100, 116, 50, 58, ew=1, ns=0)
+    rng = np.random.default_rng(1)
+    a = rng.uniform(1, 2, (4, ref.ny_block, ref.nx_block))
+    want = a.copy(); ref.halo_r8(want, 2, 2)
+    got = a.copy().reshape(-1); got[dom["hdst"]] = got[dom["hsrc"]]
+    assert np.array_equal(got.reshape(a.shape), want)
+    ai = rng.integers(0, 99, a.shape).astype(np.int32)
+    wi = ai.copy(); ref.halo_i4(wi, 1, 1)
+    gi = ai.copy().reshape(-1); gi[dom["hdst"]] = gi[dom["hsrc"]]
+    assert np.array_equal(gi.reshape(a.shape), wi)
+
+
+@pytest.mark.parametrize("kpartic,kredist,kstrength", [(1, 1, 1), (0, 0, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)])
+def test_ice_strength_variants(ref_gx3, orc, kpartic, kredist, kstrength):
+    ny, nx = 30, 40
+    dom = dict(nx=nx, ny=ny, nblocks=1, ilo=[2], ihi=[nx - 1], jlo=[2], jhi=[ny - 1], i0=[0], j0=[0],
+               nxg=nx - 2, nyg=ny - 2)
+    grid = synth.block_fields(synth.global_grid(nx - 2, ny - 2), dom)
+    s = synth.evp_state(grid, dom, cover="patchy")
+    m = np.zeros((ny, nx), bool); m[1:, 1:] = s["aice"][0, 1:, 1:] > 0.01
+    jj, ii = np.nonzero(m); n = len(ii)
+    li = np.zeros(nx * ny, np.int32); lj = np.zeros(nx * ny, np.int32); li[:n] = ii + 1; lj[:n] = jj + 1
+    args = (2, nx - 1, 2, ny - 1, n, li, lj, s["aice"][0], s["vice"][0], s["aice0"][0],
+            np.ascontiguousarray(s["aicen"][0]), np.ascontiguousarray(s["vicen"][0]))
+    ref_gx3.set_strength_parameters(kstrength, kpartic, kredist, 3.0)
+    orc.set_strength_parameters(kstrength, kpartic, kredist, 3.0)
+    assert np.array_equal(ref_gx3.ice_strength(*args), orc.ice_strength(*args))
+    ref_gx3.set_strength_parameters(); orc.set_strength_parameters()
+
+
+def test_prep_and_finish_routines(ref_gx3, orc):
+    ny, nx = 30, 40
+    dom = dict(nx=nx, ny=ny, nblocks=1, ilo=[2], ihi=[nx - 1], jlo=[2], jhi=[ny - 1], i0=[0], j0=[0],
+               nxg=nx - 2, nyg=ny - 2)
+    grid = synth.block_fields(synth.global_grid(nx - 2, ny - 2, perturb=0.1, land_frac=0.05), dom)
+    s = synth.evp_state(grid, dom, cover="patchy")
+    a1 = (2, nx - 1, 2, ny - 1, s["aice"][0], s["vice"][0], s["vsno"][0], grid["tmask"][0],
+          s["strairxT"][0], s["strairyT"][0])
+    for x, y in zip(ref_gx3.evp_prep1(*a1), orc.evp_prep1(*a1)):
+        assert np.array_equal(x, y)
+    ref_gx3.set_evp_parameters(DT, NDTE); orc.set_evp_parameters(DT, NDTE)
+    rng = np.random.default_rng(0)
+    icetmask = orc.evp_prep1(*a1)[3]
+
+    def mk():
+        r = np.random.default_rng(5)
+        U = lambda lo, hi: np.ascontiguousarray(r.uniform(lo, hi, (ny, nx)))
+        return dict(aiu=U(0, 1) * (U(0, 1) > 0.2), umass=U(0, 900), umassdtei=U(0, 1), fcor=U(-1e-4, 1e-4),
+                    umask=np.ascontiguousarray(grid["umask"][0]), uocn=U(-.1, .1), vocn=U(-.1, .1),
+                    strairx=U(-.1, .1), strairy=U(-.1, .1), ss_tltx=U(0, 1e-5), ss_tlty=U(0, 1e-5),
+                    icetmask=icetmask.copy(), iceumask=(U(0, 1) > 0.5).astype(np.int32), fm=U(-1, 1),
+                    strtltx=U(-1, 1), strtlty=U(-1, 1), strocnx=U(-1, 1), strocny=U(-1, 1), strintx=U(-1, 1),
+                    strinty=U(-1, 1), waterx=U(-1, 1), watery=U(-1, 1), forcex=U(-1, 1), forcey=U(-1, 1),
+                    sig=[U(-1e3, 1e3) for _ in range(12)], uvel=U(-.2, .2), vvel=U(-.2, .2))
+    ar, ao = mk(), mk()
+    rr = ref_gx3.evp_prep2(2, nx - 1, 2, ny - 1, ar); ro = orc.evp_prep2(2, nx - 1, 2, ny - 1, ao)
+    assert rr[0] == ro[0] and rr[1] == ro[1]
+    for x, y in zip(rr[2], ro[2]):
+        assert np.array_equal(x[:max(rr[0], rr[1])], y[:max(rr[0], rr[1])])
+    for k in ar:
+        if k == "sig":
+            for x, y in zip(ar[k], ao[k]):
+                assert np.array_equal(x, y)
+        else:
+            assert np.array_equal(ar[k], ao[k]), k
+    icellu, ui, uj = rr[1], rr[2][2], rr[2][3]
+    fr = [ar[k].copy() for k in ("strocnx", "strocny")] + [np.ones((ny, nx)), np.ones((ny, nx))]
+    fo = [a.copy() for a in fr]
+    aiu = np.maximum(ar["aiu"], 0.01)
+    ref_gx3.evp_finish(icellu, ui, uj, ar["uvel"], ar["vvel"], ar["uocn"], ar["vocn"], aiu, *fr)
+    orc.evp_finish(icellu, ui, uj, ar["uvel"], ar["vvel"], ar["uocn"], ar["vocn"], aiu, *fo)
+    for x, y in zip(fr, fo):
+        assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("conduct", ["MU71", "bubbly"])
+def test_thermo_vertical_bit_exact(ref_gx3, orc, conduct):
+    sr, tr = ref_gx3.init_thermo(conduct=conduct); so, to = orc.init_thermo(conduct=conduct)
+    assert np.array_equal(sr, so) and np.array_equal(tr, to)
+    assert np.array_equal(sr, synth.salinity_profile()[0])
+    for regime in ("winter", "summer", "mixed"):
+        for n in range(5):
+            a, icells, ii, jj = synth.thermo_columns(40, 50, n, regime=regime)
+            a1 = {k: v.copy() for k, v in a.items()}; a2 = {k: v.copy() for k, v in a.items()}
+            l1 = ref_gx3.thermo_vertical(DT, icells, ii, jj, a1, yday=123.0)
+            l2 = orc.thermo_vertical(DT, icells, ii, jj, a2, yday=123.0)
+            assert l1 == l2 == (0, 0, 0)
+            for k in a1:
+                assert np.array_equal(a1[k], a2[k]), (regime, n, k)
+    ref_gx3.init_thermo(); orc.init_thermo()
+
+
+def test_thermo_error_reporting(ref_gx3, orc):
+    """Which failing cell comes back in (l_stop, istop, jstop)."""
+    ref_gx3.init_thermo(); orc.init_thermo()
+    a, icells, ii, jj = synth.thermo_columns(20, 30, 2, regime="winter", seed=5)
+    q = lambda e: (jj[e] - 1, ii[e] - 1)
+    cases = []
+    b = {k: v.copy() for k, v in a.items()}            # Tin > Tmlt in layer 3 of one cell, layer 1 of a later one
+    b["eicen"][2][q(icells // 3)] *= 1e-3; b["eicen"][0][q(icells - 2)] *= 1e-3
+    cases.append(b)
+    b = {k: v.copy() for k, v in b.items()}            # + snow colder than Tmin further down the list
+    e = icells // 2
+    b["vsnon"][q(e)] = 0.05 * b["aicen"][q(e)]
+    b["esnon"][0][q(e)] = -330.0 * (3.34e5 + 2106.0 * 150.0) * b["vsnon"][q(e)]
+    cases.append(b)
+    b = {k: v.copy() for k, v in a.items()}            # snow warmer than allowed
+    b["vsnon"][q(5)] = 0.05 * b["aicen"][q(5)]; b["esnon"][0][q(5)] = -330.0 * 3.0e5 * b["vsnon"][q(5)]
+    cases.append(b)
+    b = {k: v.copy() for k, v in a.items()}            # energy-conservation failure is not reachable by inputs
+    b["eicen"][1][q(7)] *= 40.0                        # Tin < Tmin
+    cases.append(b)
+    for c in cases:
+        c1 = {k: v.copy() for k, v in c.items()}; c2 = {k: v.copy() for k, v in c.items()}
+        l1 = ref_gx3.thermo_vertical(DT, icells, ii, jj, c1); l2 = orc.thermo_vertical(DT, icells, ii, jj, c2)
+        assert l1[0] == 1 and l1 == l2, (l1, l2)
+
+
+def test_frzmlt_bottom_lateral(ref_gx3, orc):
+    ref_gx3.init_thermo(); orc.init_thermo()
+    ny, nx = 30, 44
+    rng = np.random.default_rng(8)
+    aice = np.where(rng.uniform(0, 1, (ny, nx)) < 0.8, rng.uniform(0.01, 1, (ny, nx)), 0.0)
+    args = (2, nx - 1, 2, ny - 1, DT, aice, rng.uniform(-60, 20, (ny, nx)), -rng.uniform(1e6, 3e8, (20, ny, nx)),
+            -rng.uniform(0, 5e7, (5, ny, nx)), np.full((ny, nx), -1.8) + rng.uniform(0, 1.5, (ny, nx)),
+            np.full((ny, nx), -1.8), rng.uniform(-0.2, 0.2, (ny, nx)), rng.uniform(-0.2, 0.2, (ny, nx)))
+    for x, y in zip(ref_gx3.frzmlt_bottom_lateral(*args), orc.frzmlt_bottom_lateral(*args)):
+        assert np.array_equal(x, y)
