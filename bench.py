@@ -43,8 +43,11 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="gx1", choices=sorted(WORKLOADS))
-    p.add_argument("--tile-rows", type=int, default=0, help="EVP tile height (8/16/32); 0 = auto")
+    p.add_argument("--waves", type=int, default=0, help="wavefronts per EVP workgroup (4/8/16); 0 = auto")
+    p.add_argument("--rows", type=int, default=0, help="T-rows per wavefront (1/2/4/8); 0 = auto")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--calibrate", action="store_true",
+                   help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
     p.add_argument("--no-thermo", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
@@ -228,6 +231,12 @@ def main():
 
     ctx = lib.Context(device=local)
     ctx.sync()                       # fails loudly without a GPU / HIP library
+    calib = None
+    if args.calibrate:
+        nd = 32 * 1024 * 1024        # 256 MiB read + 256 MiB written per launch
+        ms = ctx.diag_stream_copy(nd)
+        calib = {"kernel": "k_diag_copy8", "bytes_read": nd * 8, "bytes_written": nd * 8, "ms": ms,
+                 "GBps": 2 * nd * 8 / (ms * 1e-3) / 1e9}
     dom, grid, state, ndte = build_case(ctx, args.workload, rank, world)
     if world > 1:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
@@ -235,8 +244,12 @@ def main():
         ctx.comm_init(uid[0], rank, world)
     ctx.evp_init(grid, ndte=ndte)
     nyl = dom["ny"] - 2
-    tile = args.tile_rows or (8 if dom["nxg"] * nyl <= 400 * 400 else 16)
-    ctx.evp_set_option("tile_rows", tile)
+    small = dom["nxg"] * nyl <= 400 * 400     # too few cells to fill 1024 SIMDs: one row per wavefront
+    waves = args.waves or (8 if small else 4)
+    rows = args.rows or (1 if small else 4)
+    ctx.evp_set_option("waves", waves)
+    ctx.evp_set_option("rows_per_wave", rows)
+    tile = f"64x{waves * rows} T-cells ({waves} wavefronts x {rows} rows)"
     ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
@@ -316,17 +329,19 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][3], "nx_global": dom["nxg"],
                        "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
-                       "decomposition": f"1x{world} j-slabs, one block per GPU", "tile_rows": tile,
+                       "decomposition": f"1x{world} j-slabs, one block per GPU", "tile": tile,
                        "active_T_cells": nt_all, "active_U_cells": nu_all,
                        "cell_subcycles_per_s": value * nt_all},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_subcycle (fused stress+stepu) + halo copy",
+                         "kernel": "k_subcycle (fused stress + stepu + on-rank halo)",
                          "us_per_launch": us_per_launch, "bytes_per_unit": EVP_BYTES_PER_CELL,
                          "units_per_launch": nt_all / world},
         }
         if thermo:
             out["thermo"] = thermo
+        if calib:
+            out["calibration"] = calib
         if world == 1 and not args.no_cpu_baseline:
             cb = run_cpu_baseline(args)
             out["cpu_baseline"] = dict(cb["evp"])

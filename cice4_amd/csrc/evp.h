@@ -49,7 +49,7 @@ class Evp {
   cice_evp_config cfg{};
   EvpScalars sc{};
   bool ready = false, prepared = false;
-  int tile_rows = 8;
+  int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
   size_t n = 0;  // nblocks*ny*nx
   int cur = 0;   // which ping-pong copy of u, v, sigma holds the current values
@@ -74,7 +74,7 @@ class Evp {
   DevBuf<int32_t> icetmask;
   DevBuf<unsigned long long> counters;
 
-  // captured subcycle loop (hipGraph), keyed by (cur, ksub0, nsub, tile_rows)
+  // captured subcycle loop (hipGraph), keyed by (cur, ksub0, nsub, tile shape)
   hipGraphExec_t graph_exec = nullptr;
   int graph_key[4] = {-1, -1, -1, -1};
 

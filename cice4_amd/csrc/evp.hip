@@ -176,97 +176,215 @@ __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu,
 
 struct SubArgs {
   EvpScalars sc;
-  int nx, ny, tiles_x, tiles_y;
+  int nx, ny, tiles_x, tiles_y, nblocks;
   size_t n;  // nblocks*ny*nx
-  const int32_t* blk;
-  const int32_t *icetmask, *iceumask;
-  const double *u_in, *v_in;
-  double *u_out, *v_out;
-  const double* sig_in;
-  double* sig_out;
-  const double *dxt, *dyt, *dxhy, *dyhx, *cxp, *cyp, *cxm, *cym, *tarear, *tinyarea, *strength;
-  const double *aiu, *uocn, *vocn, *waterx, *watery, *forcex, *forcey, *umassdtei, *fm, *uarear;
-  double *divu, *rdg_conv, *rdg_shear, *shear, *prs_sig, *strintx, *strinty, *strocnx, *strocny;
+  // no two of these arrays overlap (inputs and outputs of the double-buffered fields are
+  // different allocations), which lets the compiler issue loads ahead of stores
+  const int32_t* __restrict__ ring_slot;  // on-rank ghost forwarding (Halo)
+  const int32_t* __restrict__ fwd;
+  const int32_t* __restrict__ blk;
+  const int32_t* __restrict__ icetmask;
+  const int32_t* __restrict__ iceumask;
+  const double* __restrict__ u_in;
+  const double* __restrict__ v_in;
+  double* __restrict__ u_out;
+  double* __restrict__ v_out;
+  const double* __restrict__ sig_in;
+  double* __restrict__ sig_out;
+  const double *__restrict__ dxt, *__restrict__ dyt, *__restrict__ dxhy, *__restrict__ dyhx,
+      *__restrict__ cxp, *__restrict__ cyp, *__restrict__ cxm, *__restrict__ cym,
+      *__restrict__ tarear, *__restrict__ tinyarea, *__restrict__ strength;
+  const double *__restrict__ aiu, *__restrict__ uocn, *__restrict__ vocn, *__restrict__ waterx,
+      *__restrict__ watery, *__restrict__ forcex, *__restrict__ forcey, *__restrict__ umassdtei,
+      *__restrict__ fm, *__restrict__ uarear;
+  double *__restrict__ divu, *__restrict__ rdg_conv, *__restrict__ rdg_shear, *__restrict__ shear,
+      *__restrict__ prs_sig, *__restrict__ strintx, *__restrict__ strinty, *__restrict__ strocnx,
+      *__restrict__ strocny;
 };
 
 constexpr int TX = 64;  // T-cells per tile row = one wavefront
 
-// One EVP subcycle, fused (ice_dyn_evp.F90:353-395).  256 threads = 4 wavefronts; wavefront w
-// owns tile rows w, w+4, ...; each lane one T-cell per row.
-template <int TY, bool LAST, bool DAMP>
-__global__ __launch_bounds__(256) void k_subcycle(const SubArgs a) {
-  __shared__ double s_str[8][TY][TX];
-  const int b = blockIdx.y;
-  const int tile = blockIdx.x;
-  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+// Momentum update of one U-cell inside the fused kernel + forwarding of the new velocity to
+// the ghost cells that mirror this cell on this rank (the on-rank part of the two
+// ice_HaloUpdate calls at ice_dyn_evp.F90:397-402, folded into the producing kernel).
+struct UIn {  // the ten read-only U-cell fields of stepu (ice_dyn_evp.F90:1339-1349)
+  double aiu, uocn, vocn, waterx, watery, forcex, forcey, umassdtei, fm, uarear;
+};
+
+__device__ __forceinline__ void load_uin(const SubArgs& a, size_t q, UIn& x) {
+  x.aiu = a.aiu[q]; x.uocn = a.uocn[q]; x.vocn = a.vocn[q]; x.waterx = a.waterx[q];
+  x.watery = a.watery[q]; x.forcex = a.forcex[q]; x.forcey = a.forcey[q];
+  x.umassdtei = a.umassdtei[q]; x.fm = a.fm[q]; x.uarear = a.uarear[q];
+}
+
+// Momentum update of one U-cell inside the fused kernel + forwarding of the new velocity to
+// the ghost cells that mirror this cell on this rank (the on-rank part of the two
+// ice_HaloUpdate calls at ice_dyn_evp.F90:397-402, folded into the producing kernel).
+template <bool LAST>
+__device__ __forceinline__ void stepu_store(const SubArgs& a, const UIn& x, size_t q, int i, int j,
+                                            int ilo, int ihi, int jlo, int jhi, double uold,
+                                            double vold, double sx, double sy) {
+  StepuOut r;
+  stepu_cell(uold, vold, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei,
+             x.fm, x.uarear, sx, sy, r);
+  a.u_out[q] = r.u;
+  a.v_out[q] = r.v;
+  if (LAST) {
+    a.strintx[q] = r.strintx;
+    a.strinty[q] = r.strinty;
+    a.strocnx[q] = r.taux;
+    a.strocny[q] = r.tauy;
+  }
+  if (a.ring_slot && (i == ilo || i == ihi || j == jlo || j == jhi)) {
+    const int slot = a.ring_slot[q];
+    if (slot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int d = a.fwd[3 * slot + k];
+        if (d >= 0) {
+          a.u_out[d] = r.u;
+          a.v_out[d] = r.v;
+        }
+      }
+    }
+  }
+}
+
+// One EVP subcycle, fused (ice_dyn_evp.F90:353-402).
+//
+// Workgroup = W wavefronts, tile = 64 x (W*R) T-cells.  Wavefront w walks R consecutive
+// T-rows upwards; a lane keeps one column.  For every row it updates the 12 stresses of its
+// T-cell and forms the 8 `str` combinations in registers; the momentum equation of the U-row
+// below needs str of (i,j), (i+1,j), (i,j+1), (i+1,j+1): the i+1 values come from the next
+// lane by a wavefront shuffle, the j values are carried in registers from the previous row,
+// so `str` never exists in memory.  Only the first row of each wavefront is handed to the
+// wavefront below through LDS (4 doubles per lane, one barrier per workgroup).  The u, v
+// stencil is served the same way: the row below is carried, the west neighbour is a shuffle
+// (lane 0 reloads it).  Tiles overlap by one T-row / T-column; the overlap is recomputed and
+// only the owner stores it (u, v, sigma are double-buffered).
+// Consecutive blockIdx values are dealt round-robin to the 8 XCDs, so blockIdx is remapped
+// to give every XCD one contiguous run of tiles: the re-read overlap rows then hit that
+// XCD's own L2.  (Pure performance: any placement gives the same results.)
+template <int W, int R, bool LAST, bool DAMP>
+__global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
+  constexpr int TROWS = W * R;
+  __shared__ double s_edge[W][4][TX];
+  const int per_blk = a.tiles_x * a.tiles_y;
+  const int nt = per_blk * a.nblocks;
+  const int chunk = (nt + 7) >> 3;
+  const int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile_lin >= nt) return;  // whole workgroup
+  const int b = tile_lin / per_blk;
+  const int rem = tile_lin - b * per_blk;
+  const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
   const int ilo = a.blk[4 * b + 0], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2],
             jhi = a.blk[4 * b + 3];
-  const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (TY - 1);  // 1-based
+  const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (TROWS - 1);  // 1-based
   const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nx = a.nx;
   const size_t base = (size_t)b * nx * a.ny;
   const int i = i0 + lx;
+  const bool in_i = i <= ihi + 1;
   // owner of T-cell (i,j) is the tile holding U-cell (min(i,ihi), min(j,jhi))
-  const int oi = min(i, ihi);
-  const bool own_i = (oi - i0) < (TX - 1);
+  const bool own_i = (min(i, ihi) - i0) < (TX - 1);
+  const bool u_lane = lx < TX - 1 && i <= ihi;
+  const int jfirst = j0 + w * R;
 
-#pragma unroll 1
-  for (int ly = w; ly < TY; ly += 4) {
-    const int j = j0 + ly;
+  // carried row below the first T-row of this wavefront
+  double us = c0, vs = c0, usw = c0, vsw = c0;
+  {
+    const int j = jfirst - 1;
+    const bool ok = in_i && j <= jhi + 1;
+    const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
+    if (ok) {
+      us = a.u_in[q];
+      vs = a.v_in[q];
+    }
+    usw = __shfl_up(us, 1);
+    vsw = __shfl_up(vs, 1);
+    if (lx == 0 && ok) {
+      usw = a.u_in[q - 1];
+      vsw = a.v_in[q - 1];
+    }
+  }
+  double p0 = c0, pe1 = c0, p4 = c0, pe6 = c0;  // str of the row below: (i,j,1) (i+1,j,2) (i,j,5) (i+1,j,7)
+  // The wavefront's last U-row is finished after the barrier; fetch its read-only inputs now so
+  // that their latency overlaps the stress arithmetic.
+  const int ju_last = jfirst + R - 1;
+  const size_t qu_last = base + (size_t)(ju_last - 1) * nx + (i - 1);
+  const bool do_last = (w < W - 1) && u_lane && ju_last <= jhi && a.iceumask[qu_last];
+  // (only in the one-row-per-wavefront shapes used for small grids, which are latency-bound;
+  // the multi-row shapes are bandwidth-bound and need the registers for occupancy)
+  constexpr bool PREFETCH = (R == 1);
+  UIn xl{};
+  if (PREFETCH && do_last) load_uin(a, qu_last, xl);
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int j = jfirst + r;
+    const bool ok = in_i && j <= jhi + 1;
+    const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
+    double un = c0, vn = c0;
+    if (ok) {
+      un = a.u_in[q];
+      vn = a.v_in[q];
+    }
+    double uw = __shfl_up(un, 1), vw = __shfl_up(vn, 1);
+    if (lx == 0 && ok) {
+      uw = a.u_in[q - 1];
+      vw = a.v_in[q - 1];
+    }
     StressOut o;
 #pragma unroll
     for (int c = 0; c < 8; ++c) o.str[c] = c0;
-    if (i <= ihi + 1 && j <= jhi + 1) {
-      const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
-      if (a.icetmask[q] == 1) {
-        const size_t qw = q - 1, qs = q - nx, qsw = q - nx - 1;
-        double s[12];
+    if (ok && a.icetmask[q] == 1) {
+      double s[12];
 #pragma unroll
-        for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
-        stress_cell<LAST, DAMP>(a.sc, a.u_in[q], a.u_in[qw], a.u_in[qsw], a.u_in[qs], a.v_in[q],
-                                a.v_in[qw], a.v_in[qsw], a.v_in[qs], a.dxt[q], a.dyt[q], a.dxhy[q],
-                                a.dyhx[q], a.cxp[q], a.cyp[q], a.cxm[q], a.cym[q],
-                                LAST ? a.tarear[q] : 0.0, a.tinyarea[q], a.strength[q], s, o);
-        const int oj = min(j, jhi);
-        if (own_i && (oj - j0) < (TY - 1)) {
+      for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
+      stress_cell<LAST, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, a.dxt[q], a.dyt[q], a.dxhy[q],
+                              a.dyhx[q], a.cxp[q], a.cyp[q], a.cxm[q], a.cym[q],
+                              LAST ? a.tarear[q] : 0.0, a.tinyarea[q], a.strength[q], s, o);
+      if (own_i && (min(j, jhi) - j0) < (TROWS - 1)) {
 #pragma unroll
-          for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
-          if (LAST) {
-            a.divu[q] = o.divu;
-            a.rdg_conv[q] = o.rdg_conv;
-            a.rdg_shear[q] = o.rdg_shear;
-            a.shear[q] = o.shear;
-            a.prs_sig[q] = o.prs_sig;
-          }
+        for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
+        if (LAST) {
+          a.divu[q] = o.divu;
+          a.rdg_conv[q] = o.rdg_conv;
+          a.rdg_shear[q] = o.rdg_shear;
+          a.shear[q] = o.shear;
+          a.prs_sig[q] = o.prs_sig;
         }
       }
     }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) s_str[c][ly][lx] = o.str[c];
+    const double e1 = __shfl_down(o.str[1], 1), e3 = __shfl_down(o.str[3], 1),
+                 e6 = __shfl_down(o.str[6], 1), e7 = __shfl_down(o.str[7], 1);
+    if (r == 0) {
+      if (w > 0) {  // complete the last U-row of the wavefront below
+        s_edge[w][0][lx] = o.str[2];
+        s_edge[w][1][lx] = e3;
+        s_edge[w][2][lx] = o.str[5];
+        s_edge[w][3][lx] = e7;
+      }
+    } else {
+      const int ju = j - 1;  // U-row between the carried row and this one
+      const size_t qu = q - nx;
+      if (u_lane && ju <= jhi && a.iceumask[qu]) {
+        UIn x;
+        load_uin(a, qu, x);
+        const double sx = p0 + pe1 + o.str[2] + e3;      // :1415-1416 order
+        const double sy = p4 + o.str[5] + pe6 + e7;      // :1417-1418 order
+        stepu_store<LAST>(a, x, qu, i, ju, ilo, ihi, jlo, jhi, us, vs, sx, sy);
+      }
+    }
+    p0 = o.str[0]; pe1 = e1; p4 = o.str[4]; pe6 = e6;
+    us = un; vs = vn; usw = uw; vsw = vw;
   }
   __syncthreads();
-  if (lx >= TX - 1 || i > ihi) return;
-#pragma unroll 1
-  for (int ly = w; ly < TY - 1; ly += 4) {
-    const int j = j0 + ly;
-    if (j > jhi) break;
-    const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
-    if (!a.iceumask[q]) continue;
-    const double sx = s_str[0][ly][lx] + s_str[1][ly][lx + 1] + s_str[2][ly + 1][lx] +
-                      s_str[3][ly + 1][lx + 1];
-    const double sy = s_str[4][ly][lx] + s_str[5][ly + 1][lx] + s_str[6][ly][lx + 1] +
-                      s_str[7][ly + 1][lx + 1];
-    StepuOut r;
-    stepu_cell(a.u_in[q], a.v_in[q], a.aiu[q], a.uocn[q], a.vocn[q], a.waterx[q], a.watery[q],
-               a.forcex[q], a.forcey[q], a.umassdtei[q], a.fm[q], a.uarear[q], sx, sy, r);
-    a.u_out[q] = r.u;
-    a.v_out[q] = r.v;
-    if (LAST) {
-      a.strintx[q] = r.strintx;
-      a.strinty[q] = r.strinty;
-      a.strocnx[q] = r.taux;
-      a.strocny[q] = r.tauy;
-    }
+  if (do_last) {
+    if (!PREFETCH) load_uin(a, qu_last, xl);
+    const double sx = p0 + pe1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];
+    const double sy = p4 + s_edge[w + 1][2][lx] + pe6 + s_edge[w + 1][3][lx];
+    stepu_store<LAST>(a, xl, qu_last, i, ju_last, ilo, ihi, jlo, jhi, us, vs, sx, sy);
   }
 }
 
@@ -606,9 +724,12 @@ void Evp::drop_graph() {
 }
 
 void Evp::set_option(const char* key, int value) {
-  if (!std::strcmp(key, "tile_rows")) {
-    CICE_REQUIRE(value == 8 || value == 16 || value == 32, "tile_rows must be 8, 16 or 32");
-    tile_rows = value;
+  if (!std::strcmp(key, "waves")) {
+    CICE_REQUIRE(value == 4 || value == 8 || value == 16, "waves must be 4, 8 or 16");
+    waves = value;
+  } else if (!std::strcmp(key, "rows_per_wave")) {
+    CICE_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "rows_per_wave must be 1, 2, 4 or 8");
+    rows_per_wave = value;
   } else if (!std::strcmp(key, "use_graph")) {
     use_graph = value != 0;
   } else {
@@ -769,23 +890,26 @@ void Evp::active_cells(long long* nt, long long* nu) {
   if (nu) *nu = (long long)h[1];
 }
 
-template <int TY>
-static void launch_ty(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+template <int W, int R>
+static void launch_wr(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+  const dim3 blk(64 * W);
   if (last) {
-    if (damp) hipLaunchKernelGGL((k_subcycle<TY, true, true>), g, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_subcycle<TY, true, false>), g, dim3(256), 0, s, a);
+    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, true, true>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<W, R, true, false>), g, blk, 0, s, a);
   } else {
-    if (damp) hipLaunchKernelGGL((k_subcycle<TY, false, true>), g, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_subcycle<TY, false, false>), g, dim3(256), 0, s, a);
+    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, false, true>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<W, R, false, false>), g, blk, 0, s, a);
   }
 }
 
 void Evp::launch_subcycle(int ksub) {
   SubArgs a{};
-  a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.n = n;
-  const int TY = tile_rows;
+  a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.n = n; a.nblocks = dom.nblocks();
+  const int trows = waves * rows_per_wave;
   a.tiles_x = (dom.bsx + (TX - 1) - 1) / (TX - 1);
-  a.tiles_y = (dom.bsy + (TY - 1) - 1) / (TY - 1);
+  a.tiles_y = (dom.bsy + (trows - 1) - 1) / (trows - 1);
+  const bool fwd = halo.fwd_ok();
+  a.ring_slot = fwd ? halo.d_ring_slot() : nullptr; a.fwd = halo.d_fwd();
   a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
   a.u_in = uv[cur].p; a.v_in = uv[cur].p + n; a.u_out = uv[1 - cur].p; a.v_out = uv[1 - cur].p + n;
   a.sig_in = sig[cur].p; a.sig_out = sig[1 - cur].p;
@@ -796,13 +920,25 @@ void Evp::launch_subcycle(int ksub) {
   a.divu = divu.p; a.rdg_conv = rdg_conv.p; a.rdg_shear = rdg_shear.p; a.shear = shear.p;
   a.prs_sig = prs_sig.p; a.strintx = strintx.p; a.strinty = strinty.p; a.strocnx = strocnx.p;
   a.strocny = strocny.p;
-  const dim3 g(a.tiles_x * a.tiles_y, dom.nblocks());
+  const int nt = a.tiles_x * a.tiles_y * a.nblocks;
+  const dim3 g(8 * ((nt + 7) / 8));
   const bool last = (ksub == sc.ndte), damp = sc.evp_damping != 0;
-  if (TY == 8) launch_ty<8>(a, last, damp, g, stream);
-  else if (TY == 16) launch_ty<16>(a, last, damp, g, stream);
-  else launch_ty<32>(a, last, damp, g, stream);
+  const int key = waves * 100 + rows_per_wave;
+  switch (key) {
+    case 801: launch_wr<8, 1>(a, last, damp, g, stream); break;
+    case 802: launch_wr<8, 2>(a, last, damp, g, stream); break;
+    case 804: launch_wr<8, 4>(a, last, damp, g, stream); break;
+    case 401: launch_wr<4, 1>(a, last, damp, g, stream); break;
+    case 402: launch_wr<4, 2>(a, last, damp, g, stream); break;
+    case 404: launch_wr<4, 4>(a, last, damp, g, stream); break;
+    case 408: launch_wr<4, 8>(a, last, damp, g, stream); break;
+    case 1601: launch_wr<16, 1>(a, last, damp, g, stream); break;
+    case 1602: launch_wr<16, 2>(a, last, damp, g, stream); break;
+    default: throw Error{CICE_EINVAL, "unsupported (waves, rows_per_wave) combination"};
+  }
   cur = 1 - cur;
-  halo.update_r8(uv[cur].p, 2, n);  // :397-402, uvel and vvel in one pass
+  // on-rank ghost cells were written by the kernel itself; other ranks' rows travel by RCCL
+  if (halo.multi_rank() || !fwd) halo.update_r8(uv[cur].p, 2, n, /*local=*/!fwd);  // :397-402
 }
 
 void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
@@ -817,7 +953,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   // RCCL calls are not captured: graphs only on a single rank
   const bool graph_ok = use_graph && !halo.multi_rank() && nsub > 1;
   if (graph_ok) {
-    const int key[4] = {cur, ksub0, nsub, tile_rows};
+    const int key[4] = {cur, ksub0, nsub, waves * 100 + rows_per_wave};
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();
       hipGraph_t gph = nullptr;

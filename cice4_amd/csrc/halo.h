@@ -21,19 +21,26 @@ class Halo {
   void comm_init(const char uid[128], int rank, int nranks);
   bool multi_rank() const { return nranks_ > 1; }
   // nfields fields of element type T, field k starting at base + k*stride (elements)
-  void update_r8(double* base, int nfields, size_t stride);
+  // local = false: only the off-rank part (the caller has written the on-rank ghosts itself)
+  void update_r8(double* base, int nfields, size_t stride, bool local = true);
   void update_i4(int32_t* base, int nfields, size_t stride);
   // Device pointers to the on-rank copy list, for kernels that fold it in.
   const int32_t* d_src() const { return src_.p; }
   const int32_t* d_dst() const { return dst_.p; }
   int ncopy() const { return ncopy_; }
+  // Forwarding form of the same list, for producers that write ghosts themselves:
+  // ring_slot[cell] = slot or -1; fwd[3*slot + k] = k-th ghost address mirroring that cell or -1.
+  const int32_t* d_ring_slot() const { return ring_slot_.p; }
+  const int32_t* d_fwd() const { return fwd_.p; }
+  bool fwd_ok() const { return fwd_ok_; }
 
  private:
   template <class T>
-  void update(T* base, int nfields, size_t stride);
+  void update(T* base, int nfields, size_t stride, bool local);
   hipStream_t stream_ = nullptr;
   int ncopy_ = 0, rank_ = 0, nranks_ = 1;
-  DevBuf<int32_t> src_, dst_, send_addr_, recv_addr_;
+  bool fwd_ok_ = true;
+  DevBuf<int32_t> src_, dst_, send_addr_, recv_addr_, ring_slot_, fwd_;
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;
   DevBuf<double> sendbuf_, recvbuf_;  // sized for MAXF fields of 8-byte elements

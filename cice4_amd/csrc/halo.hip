@@ -71,6 +71,30 @@ void Halo::init(const Domain& d, hipStream_t s) {
     src_.upload(d.hsrc.data(), s);
     dst_.upload(d.hdst.data(), s);
   }
+  {  // forwarding form: source cell -> the (at most 3: edge, edge, corner) ghosts mirroring it
+    const size_t n = (size_t)d.nblocks() * d.nx_block * d.ny_block;
+    std::vector<int32_t> slot(n, -1), fwd;
+    for (int e = 0; e < ncopy_; ++e) {
+      int32_t& sl = slot[d.hsrc[e]];
+      if (sl < 0) {
+        sl = (int32_t)(fwd.size() / 3);
+        fwd.insert(fwd.end(), {-1, -1, -1});
+      }
+      int k = 0;
+      while (k < 3 && fwd[3 * sl + k] >= 0) ++k;
+      if (k == 3) {  // blocks only 1 cell wide: keep the separate copy kernel
+        fwd_ok_ = false;
+        break;
+      }
+      fwd[3 * sl + k] = d.hdst[e];
+    }
+    if (fwd.empty()) fwd.assign(3, -1);
+    ring_slot_.alloc(n);
+    ring_slot_.upload(slot.data(), s);
+    fwd_.alloc(fwd.size());
+    fwd_.upload(fwd.data(), s);
+    CICE_HIP(hipStreamSynchronize(s));
+  }
   auto flatten = [&](const std::vector<HaloMsg>& msgs, std::vector<int>& peer,
                      std::vector<int>& off, std::vector<int>& cnt, DevBuf<int32_t>& dev, int& nmsg) {
     std::vector<int32_t> flat;
@@ -114,7 +138,7 @@ void Halo::comm_init(const char uid[128], int rank, int nranks) {
 }
 
 template <class T>
-void Halo::update(T* base, int nfields, size_t stride) {
+void Halo::update(T* base, int nfields, size_t stride, bool local) {
   CICE_REQUIRE(nfields >= 1 && nfields <= MAXF, "halo: too many fields in one update");
   const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
   const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
@@ -137,7 +161,7 @@ void Halo::update(T* base, int nfields, size_t stride) {
                          send_peer_[m], (ncclComm_t)comm_, stream_));
     CICE_NCCL(ncclGroupEnd());
   }
-  if (ncopy_) {
+  if (ncopy_ && local) {
     int t = ncopy_ * nfields;
     hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, src_.p, dst_.p, ncopy_);
@@ -151,7 +175,7 @@ void Halo::update(T* base, int nfields, size_t stride) {
   CICE_HIP(hipGetLastError());
 }
 
-void Halo::update_r8(double* base, int nfields, size_t stride) { update<double>(base, nfields, stride); }
-void Halo::update_i4(int32_t* base, int nfields, size_t stride) { update<int32_t>(base, nfields, stride); }
+void Halo::update_r8(double* base, int nfields, size_t stride, bool local) { update<double>(base, nfields, stride, local); }
+void Halo::update_i4(int32_t* base, int nfields, size_t stride) { update<int32_t>(base, nfields, stride, true); }
 
 }  // namespace cice

@@ -128,6 +128,11 @@ class Context:
     def sync(self):
         self._ck(self.lib.cice_device_sync(self.h))
 
+    def diag_stream_copy(self, n_doubles):
+        ms = C.c_float(0.0)
+        self._ck(self.lib.cice_diag_stream_copy(self.h, C.c_longlong(n_doubles), C.byref(ms)))
+        return ms.value
+
     # ---- domain -------------------------------------------------------
     def domain_create(self, nxg, nyg, bsx, bsy, ew=1, ns=0, rank=0, npx=1, npy=1):
         self._ck(self.lib.cice_domain_create(self.h, nxg, nyg, bsx, bsy, ew, ns, rank, npx, npy))

@@ -46,6 +46,10 @@ int cice_create(cice_ctx **ctx, int device);
 int cice_destroy(cice_ctx *ctx);
 const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
 int cice_device_sync(cice_ctx *ctx);
+/* Diagnostics: streams n_doubles 8-byte loads + stores through HBM twice (kernel
+ * k_diag_copy8) and returns the second launch's time; used to calibrate the rocprofv3
+ * FETCH_SIZE / WRITE_SIZE counters for the 8-byte-per-lane access width of the kernels. */
+int cice_diag_stream_copy(cice_ctx *ctx, long long n_doubles, float *elapsed_ms);
 
 /* ---- domain: replaces init_domain_blocks + init_domain_distribution +
  * ice_HaloCreate (source/ice_domain.F90:96,258; mpi/ice_boundary.F90:153).

@@ -120,12 +120,13 @@ def test_evp_damping_and_small_ndte(ctx, orc):
         assert relerr(sg[k], so[k]) <= tol_of(k), k
 
 
-def test_whole_evp_bit_exact_without_transcendentals(ctx, orc):
+@pytest.mark.parametrize("bs,shape", [((48, 35), (8, 1)), ((96, 70), (4, 4)), ((32, 24), (4, 2)), ((96, 7), (16, 1))])
+def test_whole_evp_bit_exact_without_transcendentals(ctx, orc, bs, shape):
     """With krdg_partic = 0 and krdg_redist = 0 (Thorndike 75 / Hibler 80: ice_mechred.F90
     :881-895, :937-952) ice_strength needs no exp(), so the WHOLE evp(dt) -- prep, masks,
     T<->U averaging, strength, 120 fused subcycles with halos, finish -- must agree with the
-    checker BIT FOR BIT, on 4 blocks."""
-    dom, grid, s = _setup(ctx, 96, 70, 48, 35, cover="patchy", seed=9)
+    checker BIT FOR BIT (1, 4, 9 and 10 blocks; several tile shapes)."""
+    dom, grid, s = _setup(ctx, 96, 70, bs[0], bs[1], cover="patchy", seed=9)
     orc.set_evp_parameters(DT, NDTE, False)
     orc.set_strength_parameters(1, 0, 0, 4.0)
     d = orc.make_domain(dom, grid)
@@ -133,6 +134,7 @@ def test_whole_evp_bit_exact_without_transcendentals(ctx, orc):
     orc.evp(d, so)
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("waves", shape[0]); ctx.evp_set_option("rows_per_wave", shape[1])
     ctx.evp(DT, sg)
     orc.set_strength_parameters()
     for k in EVP_OUT_FIELDS + ("iceumask",):
@@ -140,22 +142,23 @@ def test_whole_evp_bit_exact_without_transcendentals(ctx, orc):
 
 
 def test_results_independent_of_tile_shape_and_graph(ctx, orc):
-    """Tile height (8/16/32 rows) and hipGraph replay are pure scheduling choices: results
-    must be bit-identical across all of them."""
+    """Tile shape (wavefronts per workgroup x rows per wavefront) and hipGraph replay are pure
+    scheduling choices: results must be bit-identical across all of them."""
     dom, grid, s = _setup(ctx, 96, 70, 48, 35, cover="patchy", seed=9)
     first = None
-    for tile in (8, 16, 32):
-        for graph in (1, 0):
+    for waves, rows in ((8, 1), (4, 2), (4, 4), (4, 8), (8, 2), (8, 4), (4, 1), (16, 1), (16, 2)):
+        for graph in ((1, 0) if (waves, rows) == (8, 1) else (1,)):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=NDTE)
-            ctx.evp_set_option("tile_rows", tile)
+            ctx.evp_set_option("waves", waves)
+            ctx.evp_set_option("rows_per_wave", rows)
             ctx.evp_set_option("use_graph", graph)
             ctx.evp(DT, sg)
             if first is None:
                 first = sg
             else:
                 for k in EVP_OUT_FIELDS:
-                    assert np.array_equal(sg[k], first[k]), (tile, graph, k)
+                    assert np.array_equal(sg[k], first[k]), (waves, rows, graph, k)
 
 
 def test_stepwise_api_equals_dropin(ctx, orc):
@@ -178,19 +181,24 @@ def test_stepwise_api_equals_dropin(ctx, orc):
         assert np.array_equal(a[k], b[k]), k
 
 
-def test_second_step_reuses_state(ctx, orc):
-    """Two consecutive evp(dt) calls (iceumask / velocities / stresses carried over)."""
+def test_three_steps_carry_state_bit_exact(ctx, orc):
+    """Three consecutive evp(dt) calls from rest (iceumask, velocities, stresses and the
+    ping-pong buffers carried from step to step), in the exp-free strength configuration so
+    that the comparison is bit for bit.  (With the default strength the 1-ulp exp() difference
+    is amplified by this spin-up case to ~1e-10 after two steps -- any other libm would do
+    the same to the reference itself -- so that variant is checked for one step only.)"""
     dom, grid, s = _setup(ctx, 64, 40, 64, 40, cover="patchy", seed=4, moving=False)
-    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters()
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     d = orc.make_domain(dom, grid)
     so = {k: v.copy() for k, v in s.items()}
     sg = {k: v.copy() for k, v in s.items()}
-    ctx.evp_init(grid, ndte=NDTE)
-    for step in range(2):
+    ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    for step in range(3):
         orc.evp(d, so)
         ctx.evp(DT, sg)
-        for k in EVP_OUT_FIELDS:
-            assert relerr(sg[k], so[k]) <= tol_of(k), (step, k, relerr(sg[k], so[k]))
+        for k in EVP_OUT_FIELDS + ("iceumask",):
+            assert np.array_equal(sg[k], so[k]), (step, k)
+    orc.set_strength_parameters()
 
 
 def test_halo_update_through_device(ctx):
