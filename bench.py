@@ -50,6 +50,7 @@ def parse():
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
     p.add_argument("--no-thermo", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-dropin-timing", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     p.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
     return p.parse_args()
@@ -284,6 +285,18 @@ def main():
     nsub_total = ndte * args.steps
     value = nsub_total / t_evp
 
+    # ---- the drop-in form evp(dt) with host arrays on both sides (PCIe-inclusive; never `value`)
+    pcie = None
+    if world == 1 and not args.no_dropin_timing:
+        st2 = {k: v.copy() for k, v in state.items()}
+        ctx.evp(DT, st2)
+        t1 = time.perf_counter()
+        for _ in range(2):
+            ctx.evp(DT, st2)
+        t1 = (time.perf_counter() - t1) / 2
+        pcie = {"what": "cice_evp(dt): H2D of 33 fields + prepare + ndte subcycles + finish + D2H of 38 fields, "
+                        "pageable host memory", "ms_per_call": 1e3 * t1, "subcycles_per_s": ndte / t1}
+
     # ---- thermo (secondary figure): K batched passes, state restored before each (not timed)
     thermo = None
     tcols = None
@@ -342,6 +355,8 @@ def main():
             out["thermo"] = thermo
         if calib:
             out["calibration"] = calib
+        if pcie:
+            out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
             cb = run_cpu_baseline(args)
             out["cpu_baseline"] = dict(cb["evp"])

@@ -80,6 +80,16 @@ __global__ __launch_bounds__(256) void k_diag_copy8(const double* __restrict__ s
   if (t < n) dst[t] = src[t] + 1.0;
 }
 
+__global__ __launch_bounds__(256) void k_diag_copy16(const double2* __restrict__ src,
+                                                     double2* __restrict__ dst, size_t n2) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n2) {
+    double2 v = src[t];
+    v.x += 1.0;
+    dst[t] = v;
+  }
+}
+
 template <class T>
 static void halo_host(cice_ctx* c, T* field, int nlev) {
   c->need_halo();
@@ -138,6 +148,12 @@ int cice_diag_stream_copy(cice_ctx* ctx, long long n_doubles, float* elapsed_ms)
   CICE_HIP(hipEventRecord(e0, c_->stream));
   hipLaunchKernelGGL(k_diag_copy8, g, dim3(256), 0, c_->stream, (const double*)a.p, b.p, (size_t)n_doubles);
   CICE_HIP(hipEventRecord(e1, c_->stream));
+  {  // same bytes with 16-byte lanes, for comparison in the kernel trace only
+    const size_t n2 = (size_t)n_doubles / 2;
+    const dim3 g2((unsigned)((n2 + 255) / 256));
+    for (int r = 0; r < 2; ++r)
+      hipLaunchKernelGGL(k_diag_copy16, g2, dim3(256), 0, c_->stream, (const double2*)a.p, (double2*)b.p, n2);
+  }
   CICE_HIP(hipEventSynchronize(e1));
   if (elapsed_ms) CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
   (void)hipEventDestroy(e0);

@@ -1,0 +1,178 @@
+!=======================================================================
+! ISO_C_BINDING shim: Fortran interfaces to libcice4_amd.so
+! (include/cice4_amd.h).  Host code stays Fortran; these are the only
+! declarations a CICE4 build needs in order to call the MI355X hot path.
+! The derived types mirror the C structs member for member.
+!=======================================================================
+module cice4_amd_c
+   use iso_c_binding
+   implicit none
+   public
+
+   integer(c_int), parameter :: CICE_OK = 0
+
+   type, bind(C) :: cice_evp_grid      ! source/ice_grid.F90:58-133 arrays
+      type(c_ptr) :: dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarea, uarea, tarear, &
+                     uarear, tinyarea, fcor, tmask, umask
+   end type
+
+   type, bind(C) :: cice_evp_config    ! ice_dyn_evp.F90:64-74, ice_mechred.F90:64-79
+      integer(c_int) :: ndte, evp_damping, kstrength, krdg_partic, krdg_redist
+      real(c_double) :: mu_rdg
+   end type
+
+   type, bind(C) :: cice_evp_fields    ! ice_state.F90:55-148, ice_flux.F90:42-99
+      type(c_ptr) :: aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, &
+                     ss_tltx, ss_tlty
+      type(c_ptr) :: uvel, vvel
+      type(c_ptr) :: stressp_1, stressp_2, stressp_3, stressp_4, stressm_1, stressm_2, &
+                     stressm_3, stressm_4, stress12_1, stress12_2, stress12_3, stress12_4
+      type(c_ptr) :: iceumask
+      type(c_ptr) :: fm, strtltx, strtlty, strocnx, strocny, strintx, strinty
+      type(c_ptr) :: strairx, strairy, strength, divu, shear, rdg_conv, rdg_shear, prs_sig, &
+                     strocnxT, strocnyT
+   end type
+
+   type, bind(C) :: cice_thermo_config ! ice_therm_vertical.F90:56-79
+      integer(c_int) :: heat_capacity, calc_Tsfc, conduct
+      real(c_double) :: ustar_min
+      integer(c_int) :: tr_iage, nt_Tsfc, nt_iage
+   end type
+
+   interface
+      integer(c_int) function cice_create(ctx, device) bind(C, name='cice_create')
+         import
+         type(c_ptr), intent(out) :: ctx
+         integer(c_int), value :: device
+      end function
+      integer(c_int) function cice_destroy(ctx) bind(C, name='cice_destroy')
+         import
+         type(c_ptr), value :: ctx
+      end function
+      type(c_ptr) function cice_last_error(ctx) bind(C, name='cice_last_error')
+         import
+         type(c_ptr), value :: ctx
+      end function
+      integer(c_int) function cice_domain_create(ctx, nx_global, ny_global, block_size_x, &
+            block_size_y, ew_boundary, ns_boundary, rank, npx, npy) bind(C, name='cice_domain_create')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_global, ny_global, block_size_x, block_size_y, ew_boundary, &
+                                  ns_boundary, rank, npx, npy
+      end function
+      integer(c_int) function cice_domain_info(ctx, info) bind(C, name='cice_domain_info')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), intent(out) :: info(9)
+      end function
+      integer(c_int) function cice_comm_unique_id(uid) bind(C, name='cice_comm_unique_id')
+         import
+         character(kind=c_char), intent(out) :: uid(128)
+      end function
+      integer(c_int) function cice_comm_init(ctx, uid, rank, nranks) bind(C, name='cice_comm_init')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: uid(128)
+         integer(c_int), value :: rank, nranks
+      end function
+      integer(c_int) function cice_evp_init(ctx, cfg, grid) bind(C, name='cice_evp_init')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_evp_config), intent(in) :: cfg
+         type(cice_evp_grid), intent(in) :: grid
+      end function
+      integer(c_int) function cice_evp(ctx, dt, f) bind(C, name='cice_evp')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: dt
+         type(cice_evp_fields), intent(in) :: f
+      end function
+      integer(c_int) function cice_thermo_init(ctx, cfg, salin, Tmlt) bind(C, name='cice_thermo_init')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_thermo_config), intent(in) :: cfg
+         real(c_double), intent(out) :: salin(*), Tmlt(*)
+      end function
+      integer(c_int) function cice_thermo_vertical(ctx, nx_block, ny_block, dt, icells, indxi, &
+            indxj, aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, &
+            Tbot, lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, fsurfn, fcondtopn, &
+            fsensn, flatn, fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, meltt, melts, meltb, &
+            congel, snoice, mlt_onset, frz_onset, yday, l_stop, istop, jstop) &
+            bind(C, name='cice_thermo_vertical')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_block, ny_block, icells
+         real(c_double), value :: dt, yday
+         integer(c_int), intent(in) :: indxi(*), indxj(*)
+         real(c_double) :: aicen(*), trcrn(*), vicen(*), vsnon(*), eicen(*), esnon(*)
+         real(c_double), intent(in) :: flw(*), potT(*), Qa(*), rhoa(*), fsnow(*), fbot(*), Tbot(*), &
+                                       lhcoef(*), shcoef(*)
+         real(c_double) :: fswsfc(*), fswint(*), fswthrun(*), Sswabs(*), Iswabs(*), fsurfn(*), &
+                           fcondtopn(*), fsensn(*), flatn(*), fswabsn(*), flwoutn(*), evapn(*), &
+                           freshn(*), fsaltn(*), fhocnn(*), meltt(*), melts(*), meltb(*), congel(*), &
+                           snoice(*), mlt_onset(*), frz_onset(*)
+         integer(c_int), intent(out) :: l_stop, istop, jstop
+      end function
+      integer(c_int) function cice_frzmlt_bottom_lateral(ctx, nx_block, ny_block, ilo, ihi, jlo, jhi, &
+            dt, aice, frzmlt, eicen, esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside) &
+            bind(C, name='cice_frzmlt_bottom_lateral')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_block, ny_block, ilo, ihi, jlo, jhi
+         real(c_double), value :: dt
+         real(c_double), intent(in) :: aice(*), frzmlt(*), eicen(*), esnon(*), sst(*), Tf(*), &
+                                       strocnxT(*), strocnyT(*)
+         real(c_double), intent(out) :: Tbot(*), fbot(*), rside(*)
+      end function
+   end interface
+
+   ! one context per MPI task (= per GPU), shared by the drop-in modules
+   type(c_ptr), save :: cice_gpu_ctx = c_null_ptr
+
+contains
+
+   ! address of a (contiguous) array that is not declared TARGET in its home module
+   function addr_r8(a) result(p)
+      real(c_double), target, intent(in) :: a(*)
+      type(c_ptr) :: p
+      p = c_loc(a)
+   end function addr_r8
+
+   function addr_i4(a) result(p)
+      integer(c_int), target, intent(in) :: a(*)
+      type(c_ptr) :: p
+      p = c_loc(a)
+   end function addr_i4
+
+   function addr_l4(a) result(p)       ! default logical is 4 bytes (ice_kinds_mod.F90:31)
+      logical(c_int), target, intent(in) :: a(*)
+      type(c_ptr) :: p
+      p = c_loc(a)
+   end function addr_l4
+
+   subroutine cice_gpu_check(rc, where)
+      integer(c_int), intent(in) :: rc
+      character(len=*), intent(in) :: where
+      character(kind=c_char), pointer :: msg(:)
+      integer :: n
+      if (rc == CICE_OK) return
+      write(*,*) 'cice4_amd error ', rc, ' in ', where
+      call c_f_pointer(cice_last_error(cice_gpu_ctx), msg, [512])
+      n = 1
+      do while (n < 512 .and. msg(n) /= c_null_char)
+         n = n + 1
+      enddo
+      write(*,*) msg(1:n-1)
+      error stop 'cice4_amd'
+   end subroutine cice_gpu_check
+
+   subroutine cice_gpu_ensure(device)
+      integer(c_int), intent(in), optional :: device
+      integer(c_int) :: dev
+      if (c_associated(cice_gpu_ctx)) return
+      dev = -1
+      if (present(device)) dev = device
+      call cice_gpu_check(cice_create(cice_gpu_ctx, dev), 'cice_create')
+   end subroutine cice_gpu_ensure
+
+end module cice4_amd_c

@@ -41,14 +41,38 @@ SRCS="source/ice_kinds_mod.F90 serial/ice_communicate.F90 source/ice_domain_size
  serial/ice_timers.F90 source/ice_grid.F90 source/ice_itd.F90 source/ice_mechred.F90
  source/ice_dyn_evp.F90 source/ice_calendar.F90 source/ice_atmo.F90 source/ice_ocean.F90
  source/ice_restart.F90 source/ice_age.F90 source/ice_therm_vertical.F90"
+# DROPIN=1: the same closure, but with OUR drop-in module (cice4_amd/fortran/ice_dyn_evp.F90,
+# which forwards evp(dt) to the GPU library through the ISO_C_BINDING shim) in place of the
+# reference's source/ice_dyn_evp.F90 -> libcice_dropin_<cfg>.so.  Every caller of evp in the
+# closure and the capture wrapper are the reference's / the same: this is the drop-in test.
+DROPIN=${DROPIN:-0}
+KIND=ref
+if [ "$DROPIN" = "1" ]; then
+  KIND=dropin
+  OBJ=$OUT/obj_${CFG}_dropin
+  mkdir -p "$OBJ"
+  FFLAGS="${FFLAGS//obj_$CFG/obj_${CFG}_dropin}"
+fi
 OBJS=""
 for s in $SRCS; do
+  src="$REF/$s"
   o=$OBJ/$(basename "${s%.F90}").o
-  if [ ! -f "$o" ] || [ "$REF/$s" -nt "$o" ]; then
-    $FC $FFLAGS -c "$REF/$s" -o "$o"
+  if [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_dyn_evp.F90" ]; then
+    $FC $FFLAGS -c "$HERE/../cice4_amd/fortran/cice4_amd_c.F90" -o "$OBJ/cice4_amd_c.o"
+    OBJS="$OBJS $OBJ/cice4_amd_c.o"
+    src="$HERE/../cice4_amd/fortran/ice_dyn_evp.F90"
+    $FC $FFLAGS -c "$src" -o "$o"
+  elif [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
+    $FC $FFLAGS -c "$src" -o "$o"
   fi
   OBJS="$OBJS $o"
 done
-$FC $FFLAGS -c "$HERE/ref_capi.F90" -o "$OBJ/ref_capi.o"
-$FC -shared -Wl,-Bsymbolic -o "$OUT/libcice_ref_$CFG.so" $OBJS "$OBJ/ref_capi.o"
-echo "built $OUT/libcice_ref_$CFG.so"
+EXTRA=""
+if [ "$DROPIN" = "1" ]; then EXTRA="-DDROPIN"; fi
+$FC $FFLAGS $EXTRA -c "$HERE/ref_capi.F90" -o "$OBJ/ref_capi.o"
+LINK=""
+if [ "$DROPIN" = "1" ]; then
+  LINK="-L$HERE/../cice4_amd -lcice4_amd -Wl,-rpath,\$ORIGIN/../../cice4_amd"
+fi
+$FC -shared -Wl,-Bsymbolic -o "$OUT/libcice_${KIND}_$CFG.so" $OBJS "$OBJ/ref_capi.o" $LINK
+echo "built $OUT/libcice_${KIND}_$CFG.so"

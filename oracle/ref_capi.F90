@@ -86,6 +86,8 @@ contains
    !--------------------------------------------------------------------
    ! per-routine pass-throughs, any (nx,ny)
    !--------------------------------------------------------------------
+#ifndef DROPIN
+   ! routines internal to the reference's ice_dyn_evp (absent from the drop-in module)
    subroutine ref_stress(nx, ny, ksub, icellt, indxti, indxtj, uvel, vvel, &
          dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarear, tinyarea, strength, &
          sp1, sp2, sp3, sp4, sm1, sm2, sm3, sm4, s121, s122, s123, s124, &
@@ -179,6 +181,7 @@ contains
          strocnx, strocny, strocnxT, strocnyT)
    end subroutine ref_evp_finish
 
+#endif
    subroutine ref_ice_strength(nx, ny, ilo, ihi, jlo, jhi, icells, indxi, indxj, &
          aice, vice, aice0, aicen, vicen, strength) bind(C, name='ref_ice_strength')
       use ice_mechred, only: ice_strength
@@ -327,6 +330,14 @@ contains
       iglob = b%i_glob
       jglob = b%j_glob
    end subroutine ref_block_info
+
+#ifdef DROPIN
+   ! drop-in build only: push the (possibly injected) host grid to the device again
+   subroutine ref_evp_gpu_setup() bind(C, name='ref_evp_gpu_setup')
+      use ice_dyn_evp, only: evp_gpu_setup
+      call evp_gpu_setup
+   end subroutine ref_evp_gpu_setup
+#endif
 
    subroutine ref_evp(dt) bind(C, name='ref_evp')
       use ice_dyn_evp, only: evp

@@ -25,8 +25,8 @@ REFDIR = os.path.join(HERE, "_ref")
 NCAT, NILYR, NSLYR, MAX_NTRCR = 5, 4, 1, 5
 
 
-def available(cfg="gx3"):
-    return os.path.exists(os.path.join(REFDIR, f"libcice_ref_{cfg}.so"))
+def available(cfg="gx3", kind="ref"):
+    return os.path.exists(os.path.join(REFDIR, f"libcice_{kind}_{cfg}.so"))
 
 
 def _p(a):
@@ -45,17 +45,27 @@ def i4(a):
 class Ref:
     """One loaded reference library (one compile-time grid configuration)."""
 
-    def __init__(self, cfg="gx3"):
-        path = os.path.join(REFDIR, f"libcice_ref_{cfg}.so")
+    def __init__(self, cfg="gx3", kind="ref"):
+        """kind 'ref': the pure reference.  kind 'dropin': the same reference closure and the
+        same wrapper, but with cice4_amd/fortran/ice_dyn_evp.F90 (GPU path through the
+        ISO_C_BINDING shim) in place of the reference's ice_dyn_evp.F90."""
+        path = os.path.join(REFDIR, f"libcice_{kind}_{cfg}.so")
+        self.kind = kind
         # the reference's binary grid/kmt files are big-endian (bld/Macros.*: -convert
         # big_endian); flang applies -fconvert only from a Fortran main program, so
         # set the runtime's FORT_CONVERT switch and run its start-up hook (which a
         # Fortran main would have run) so that it reads the environment.
-        os.environ.setdefault("FORT_CONVERT", "BIG_ENDIAN")
+        had = os.environ.get("FORT_CONVERT")
+        os.environ["FORT_CONVERT"] = "BIG_ENDIAN"
         self.lib = C.CDLL(path, mode=os.RTLD_LOCAL | os.RTLD_NOW)
         self.cfg = cfg
         environ = C.POINTER(C.c_char_p).in_dll(C.CDLL(None), "environ")
         self.lib._FortranAProgramStart(C.c_int(0), None, environ, None)
+        # the runtime has read it; do not leak it to child processes (native-endian Fortran tools)
+        if had is None:
+            del os.environ["FORT_CONVERT"]
+        else:
+            os.environ["FORT_CONVERT"] = had
         self.lib.ref_boot()
         d = np.zeros(10, np.int32)
         self.lib.ref_dims(_p(d))
@@ -219,6 +229,9 @@ class Ref:
 
     def evp(self, dt):
         self.lib.ref_evp(C.c_double(dt))
+
+    def evp_gpu_setup(self):
+        self.lib.ref_evp_gpu_setup()
 
     def halo_r8(self, a, loc=1, kind=1):
         self.lib.ref_halo_r8(_p(a), C.c_int(loc), C.c_int(kind))

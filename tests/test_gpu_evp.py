@@ -222,3 +222,80 @@ def test_errors_are_reported_not_fatal(ctx):
         c2.evp_step(DT)          # no domain / init
     with pytest.raises(lib.CiceError):
         c2.domain_create(10, 10, 20, 20, ew=7)
+
+
+def test_fortran_dropin_module_inside_reference_callers(orc):
+    """The drop-in proof: the reference's own compiled modules (ice_state, ice_flux, ice_grid,
+    ice_domain, ... and the capture wrapper that calls `evp(dt)`) linked with OUR
+    cice4_amd/fortran/ice_dyn_evp.F90 instead of the reference's.  `call evp(dt)` then goes
+    Fortran -> ISO_C_BINDING shim -> libcice4_amd.so -> GPU, on the reference's own module
+    arrays and 2x2 block layout, and must reproduce the checker (pinned to the pure reference
+    bit for bit by tests/test_oracle_vs_ref.py)."""
+    import tempfile
+    from oracle import refapi
+    if not refapi.available("gx3b4", "dropin"):
+        pytest.skip("oracle/_ref/libcice_dropin_gx3b4.so not built")
+    ref = refapi.Ref("gx3b4", kind="dropin")
+    nb = ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
+    dom = lib.Context().domain_create(100, 116, 50, 58, ew=1, ns=0)
+    assert nb == 4 == dom["nblocks"]
+    grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.15, land_frac=0.05), dom)
+    s = synth.evp_state(grid, dom, cover="patchy")
+    for k in ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
+              "uarear", "tinyarea", "fcor"):
+        ref.set(k, grid[k])
+    ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
+    ref.set_strength_parameters(1, 0, 0, 4.0)      # exp-free strength: bit-for-bit comparison
+    ref.evp_gpu_setup()
+    for k in ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty",
+              "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx",
+              "strinty") + synth.SIG_NAMES:
+        ref.set(k, s[k])
+    ref.set("iceumask", s["iceumask"].astype(float))
+    ny, nx = dom["ny"], dom["nx"]
+    ref.set("aicen", s["aicen"].reshape(-1, ny, nx)); ref.set("vicen", s["vicen"].reshape(-1, ny, nx))
+    ref.evp(DT)
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    so = {k: v.copy() for k, v in s.items()}
+    orc.evp(orc.make_domain(dom, grid), so)
+    orc.set_strength_parameters()
+    for k in EVP_OUT_FIELDS:
+        assert np.array_equal(ref.get(k), so[k]), k
+    assert np.array_equal(ref.get("iceumask"), so["iceumask"])
+
+
+def test_standalone_fortran_driver(ctx, tmp_path):
+    """Host code in Fortran: cice4_amd/fortran/evp_driver (amdflang) calls the C-ABI through the
+    ISO_C_BINDING shim; its evp(dt) result must equal the ctypes-driven one bit for bit."""
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(lib.HERE), "cice4_amd", "fortran", "evp_driver")
+    if not os.path.exists(exe):
+        pytest.skip("cice4_amd/fortran/evp_driver not built")
+    dom, grid, s = _setup(ctx, 96, 70, 48, 35, cover="patchy", seed=12)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        np.array([96, 70, 48, 35, 1, 0, NDTE], np.int32).tofile(f)
+        np.array([DT]).tofile(f)
+        for k in lib.EVP_GRID[:14]:
+            grid[k].tofile(f)
+        grid["tmask"].astype(np.int32).tofile(f); grid["umask"].astype(np.int32).tofile(f)
+        for k in ("aice", "vice", "vsno", "aice0", "aicen", "vicen", "strairxT", "strairyT", "uocn", "vocn",
+                  "ss_tltx", "ss_tlty", "uvel", "vvel") + synth.SIG_NAMES:
+            s[k].tofile(f)
+        s["iceumask"].astype(np.int32).tofile(f)
+        for k in ("fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty"):
+            s[k].tofile(f)
+    r = subprocess.run([exe, fin, fout, "2"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    sg = {k: v.copy() for k, v in s.items()}
+    ctx.evp_init(grid, ndte=NDTE)
+    ctx.evp(DT, sg); ctx.evp(DT, sg)
+    n = sg["uvel"].size
+    with open(fout, "rb") as f:
+        for k in ("uvel", "vvel") + synth.SIG_NAMES:
+            assert np.array_equal(np.fromfile(f, np.float64, n).reshape(sg[k].shape), sg[k]), k
+        assert np.array_equal(np.fromfile(f, np.int32, n).reshape(sg["iceumask"].shape), sg["iceumask"])
+        for k in ("fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty", "strairx", "strairy",
+                  "strength", "divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strocnxT", "strocnyT"):
+            assert np.array_equal(np.fromfile(f, np.float64, n).reshape(sg[k].shape), sg[k]), k
