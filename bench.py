@@ -46,6 +46,7 @@ def parse():
     p.add_argument("--waves", type=int, default=0, help="wavefronts per EVP workgroup (4/8/16); 0 = auto")
     p.add_argument("--rows", type=int, default=0, help="T-rows per wavefront (1/2/4/8); 0 = auto")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
     p.add_argument("--no-thermo", action="store_true")
@@ -252,6 +253,8 @@ def main():
     ctx.evp_set_option("rows_per_wave", rows)
     tile = f"64x{waves * rows} T-cells ({waves} wavefronts x {rows} rows)"
     ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
+    ctx.evp_set_option("derive_metrics", 0 if args.no_derive else 1)
+    derive = bool(ctx.evp_get_info("derive_metrics"))
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
     nt, nu = ctx.evp_active_cells()
@@ -343,6 +346,7 @@ def main():
             "config": {"workload": WORKLOADS[args.workload][3], "nx_global": dom["nxg"],
                        "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
                        "decomposition": f"1x{world} j-slabs, one block per GPU", "tile": tile,
+                       "metrics_recomputed_from_HTN_HTE": derive,
                        "active_T_cells": nt_all, "active_U_cells": nu_all,
                        "cell_subcycles_per_s": value * nt_all},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

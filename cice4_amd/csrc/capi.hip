@@ -273,6 +273,14 @@ int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) NEED_EVP; c_->evp->finish(); 
 int cice_evp_set_option(cice_ctx* ctx, const char* key, int value) {
   CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(key, "NULL key"); c_->evp->set_option(key, value); CICE_CATCH
 }
+int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(key && value, "NULL argument");
+  if (!std::strcmp(key, "derive_metrics")) *value = c_->evp->derives_metrics() ? 1 : 0;
+  else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
+  CICE_CATCH
+}
 int cice_evp_active_cells(cice_ctx* ctx, long long* nt, long long* nu) {
   CICE_TRY(ctx) NEED_EVP; c_->evp->active_cells(nt, nu); CICE_CATCH
 }

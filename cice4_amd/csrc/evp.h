@@ -31,6 +31,7 @@ class Evp {
   }
   void set_option(const char* key, int value);
   void active_cells(long long* nt, long long* nu);
+  bool derives_metrics() const;
 
   // one-block, host-pointer entries with the reference argument lists
   static void stress_host(hipStream_t s, double dt, int ndte, int damping, int nx, int ny, int ksub,
@@ -51,12 +52,13 @@ class Evp {
   bool ready = false, prepared = false;
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
+  bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)
   size_t n = 0;  // nblocks*ny*nx
   int cur = 0;   // which ping-pong copy of u, v, sigma holds the current values
 
   // grid
   DevBuf<double> dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarea, uarea, tarear, uarear, tinyarea,
-      fcor;
+      fcor, HTN, HTE;
   DevBuf<int32_t> tmask, umask, blk;  // blk: ilo,ihi,jlo,jhi per block
   // in
   DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,

@@ -194,6 +194,7 @@ struct SubArgs {
   const double *__restrict__ dxt, *__restrict__ dyt, *__restrict__ dxhy, *__restrict__ dyhx,
       *__restrict__ cxp, *__restrict__ cyp, *__restrict__ cxm, *__restrict__ cym,
       *__restrict__ tarear, *__restrict__ tinyarea, *__restrict__ strength;
+  const double *__restrict__ HTN, *__restrict__ HTE;  // DERIVE: the 9 T-cell metrics recomputed from these
   const double *__restrict__ aiu, *__restrict__ uocn, *__restrict__ vocn, *__restrict__ waterx,
       *__restrict__ watery, *__restrict__ forcex, *__restrict__ forcey, *__restrict__ umassdtei,
       *__restrict__ fm, *__restrict__ uarear;
@@ -211,9 +212,17 @@ struct UIn {  // the ten read-only U-cell fields of stepu (ice_dyn_evp.F90:1339-
   double aiu, uocn, vocn, waterx, watery, forcex, forcey, umassdtei, fm, uarear;
 };
 
+template <bool DERIVE>
 __device__ __forceinline__ void load_uin(const SubArgs& a, size_t q, UIn& x) {
-  x.aiu = a.aiu[q]; x.uocn = a.uocn[q]; x.vocn = a.vocn[q]; x.waterx = a.waterx[q];
-  x.watery = a.watery[q]; x.forcex = a.forcex[q]; x.forcey = a.forcey[q];
+  x.aiu = a.aiu[q]; x.uocn = a.uocn[q]; x.vocn = a.vocn[q];
+  if (DERIVE) {  // evp_prep2's own expressions (ice_dyn_evp.F90:915-916) instead of two loads
+    x.waterx = x.uocn * cosw - x.vocn * sinw;
+    x.watery = x.vocn * cosw + x.uocn * sinw;
+  } else {
+    x.waterx = a.waterx[q];
+    x.watery = a.watery[q];
+  }
+  x.forcex = a.forcex[q]; x.forcey = a.forcey[q];
   x.umassdtei = a.umassdtei[q]; x.fm = a.fm[q]; x.uarear = a.uarear[q];
 }
 
@@ -265,7 +274,13 @@ __device__ __forceinline__ void stepu_store(const SubArgs& a, const UIn& x, size
 // Consecutive blockIdx values are dealt round-robin to the 8 XCDs, so blockIdx is remapped
 // to give every XCD one contiguous run of tiles: the re-read overlap rows then hit that
 // XCD's own L2.  (Pure performance: any placement gives the same results.)
-template <int W, int R, bool LAST, bool DAMP>
+//
+// DERIVE: dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym and tinyarea are exact functions of the two
+// primary lengths HTN, HTE (ice_grid.F90:335-361, primary_grid_lengths_* :1139-1289); when the
+// host has verified that bit for bit for this grid (Evp::init), the kernel recomputes them with
+// the same expressions from HTN(i,j), HTN(i,j-1) (carried), HTE(i,j), HTE(i-1,j) (shuffle):
+// 2 loads per T-cell instead of 9, results unchanged.
+template <int W, int R, bool LAST, bool DAMP, bool DERIVE>
 __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
   constexpr int TROWS = W * R;
   __shared__ double s_edge[W][4][TX];
@@ -291,7 +306,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
   const int jfirst = j0 + w * R;
 
   // carried row below the first T-row of this wavefront
-  double us = c0, vs = c0, usw = c0, vsw = c0;
+  double us = c0, vs = c0, usw = c0, vsw = c0, hn_s = c0;
   {
     const int j = jfirst - 1;
     const bool ok = in_i && j <= jhi + 1;
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
       usw = a.u_in[q - 1];
       vsw = a.v_in[q - 1];
     }
+    if (DERIVE && ok) hn_s = a.HTN[q];
   }
   double p0 = c0, pe1 = c0, p4 = c0, pe6 = c0;  // str of the row below: (i,j,1) (i+1,j,2) (i,j,5) (i+1,j,7)
   // The wavefront's last U-row is finished after the barrier; fetch its read-only inputs now so
@@ -317,7 +333,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
   // the multi-row shapes are bandwidth-bound and need the registers for occupancy)
   constexpr bool PREFETCH = (R == 1);
   UIn xl{};
-  if (PREFETCH && do_last) load_uin(a, qu_last, xl);
+  if (PREFETCH && do_last) load_uin<DERIVE>(a, qu_last, xl);
 
 #pragma unroll
   for (int r = 0; r < R; ++r) {
@@ -334,6 +350,15 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
       uw = a.u_in[q - 1];
       vw = a.v_in[q - 1];
     }
+    double hn = c0, he = c0, hew = c0;
+    if (DERIVE) {
+      if (ok) {
+        hn = a.HTN[q];
+        he = a.HTE[q];
+      }
+      hew = __shfl_up(he, 1);
+      if (lx == 0 && ok) hew = a.HTE[q - 1];
+    }
     StressOut o;
 #pragma unroll
     for (int c = 0; c < 8; ++c) o.str[c] = c0;
@@ -341,9 +366,23 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
       double s[12];
 #pragma unroll
       for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
-      stress_cell<LAST, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, a.dxt[q], a.dyt[q], a.dxhy[q],
-                              a.dyhx[q], a.cxp[q], a.cyp[q], a.cxm[q], a.cym[q],
-                              LAST ? a.tarear[q] : 0.0, a.tinyarea[q], a.strength[q], s, o);
+      double Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm, Cym, Tiny;
+      if (DERIVE) {
+        Dxt = p5 * (hn + hn_s);                 // ice_grid.F90:1184 (dxt)
+        Dyt = p5 * (he + hew);                  // :1271 (dyt)
+        Dxhy = p5 * (he - hew);                 // :347
+        Dyhx = p5 * (hn - hn_s);                // :348
+        Cyp = 1.5 * he - p5 * hew;              // :354
+        Cxp = 1.5 * hn - p5 * hn_s;             // :355
+        Cym = -(1.5 * hew - p5 * he);           // :357
+        Cxm = -(1.5 * hn_s - p5 * hn);          // :358
+        Tiny = puny * (Dxt * Dyt);              // :334, :346
+      } else {
+        Dxt = a.dxt[q]; Dyt = a.dyt[q]; Dxhy = a.dxhy[q]; Dyhx = a.dyhx[q]; Cxp = a.cxp[q];
+        Cyp = a.cyp[q]; Cxm = a.cxm[q]; Cym = a.cym[q]; Tiny = a.tinyarea[q];
+      }
+      stress_cell<LAST, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp,
+                              Cxm, Cym, LAST ? a.tarear[q] : 0.0, Tiny, a.strength[q], s, o);
       if (own_i && (min(j, jhi) - j0) < (TROWS - 1)) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
@@ -370,7 +409,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
       const size_t qu = q - nx;
       if (u_lane && ju <= jhi && a.iceumask[qu]) {
         UIn x;
-        load_uin(a, qu, x);
+        load_uin<DERIVE>(a, qu, x);
         const double sx = p0 + pe1 + o.str[2] + e3;      // :1415-1416 order
         const double sy = p4 + o.str[5] + pe6 + e7;      // :1417-1418 order
         stepu_store<LAST>(a, x, qu, i, ju, ilo, ihi, jlo, jhi, us, vs, sx, sy);
@@ -378,10 +417,11 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
     }
     p0 = o.str[0]; pe1 = e1; p4 = o.str[4]; pe6 = e6;
     us = un; vs = vn; usw = uw; vsw = vw;
+    hn_s = hn;
   }
   __syncthreads();
   if (do_last) {
-    if (!PREFETCH) load_uin(a, qu_last, xl);
+    if (!PREFETCH) load_uin<DERIVE>(a, qu_last, xl);
     const double sx = p0 + pe1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];
     const double sy = p4 + s_edge[w + 1][2][lx] + pe6 + s_edge[w + 1][3][lx];
     stepu_store<LAST>(a, xl, qu_last, i, ju_last, ilo, ihi, jlo, jhi, us, vs, sx, sy);
@@ -730,6 +770,8 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "rows_per_wave")) {
     CICE_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8, "rows_per_wave must be 1, 2, 4 or 8");
     rows_per_wave = value;
+  } else if (!std::strcmp(key, "derive_metrics")) {
+    derive_on = value != 0;
   } else if (!std::strcmp(key, "use_graph")) {
     use_graph = value != 0;
   } else {
@@ -762,6 +804,34 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   CICE_REQUIRE(g.tmask && g.umask, "cice_evp_init: NULL mask");
   tmask.alloc(n); tmask.upload(g.tmask, stream);
   umask.alloc(n); umask.upload(g.umask, stream);
+  // Optional primary lengths: enable metric derivation only if it reproduces the nine metric
+  // arrays BIT FOR BIT on every ocean T-cell the stress kernel can touch (ilo..ihi+1, jlo..jhi+1).
+  derive_ok = false;
+  if (g.HTN && g.HTE) {
+    bool same = true;
+    const int nx = dom.nx_block, ny = dom.ny_block;
+    for (int lb = 0; lb < dom.nblocks() && same; ++lb) {
+      const Block& b = dom.all[dom.local[lb]];
+      const size_t base = (size_t)lb * nx * ny;
+      for (int j = b.jlo; j <= b.jhi + 1 && same; ++j)
+        for (int i = b.ilo; i <= b.ihi + 1; ++i) {
+          const size_t q = base + (size_t)(j - 1) * nx + (i - 1);
+          if (!g.tmask[q]) continue;
+          const double hn = g.HTN[q], hs = g.HTN[q - nx], he = g.HTE[q], hw = g.HTE[q - 1];
+          const double Dxt = p5 * (hn + hs), Dyt = p5 * (he + hw);
+          same = Dxt == g.dxt[q] && Dyt == g.dyt[q] && p5 * (he - hw) == g.dxhy[q] &&
+                 p5 * (hn - hs) == g.dyhx[q] && (1.5 * he - p5 * hw) == g.cyp[q] &&
+                 (1.5 * hn - p5 * hs) == g.cxp[q] && -(1.5 * hw - p5 * he) == g.cym[q] &&
+                 -(1.5 * hs - p5 * hn) == g.cxm[q] && puny * (Dxt * Dyt) == g.tinyarea[q];
+          if (!same) break;
+        }
+    }
+    if (same) {
+      HTN.alloc(n); HTN.upload(g.HTN, stream);
+      HTE.alloc(n); HTE.upload(g.HTE, stream);
+      derive_ok = true;
+    }
+  }
   for (DevBuf<double>* d : {&aice, &vice, &vsno, &aice0, &strairxT, &strairyT, &uocn, &vocn, &ss_tltx,
                             &ss_tlty, &fm, &strtltx, &strtlty, &strocnx, &strocny, &strintx, &strinty,
                             &strairx, &strairy, &strength, &divu, &shear, &rdg_conv, &rdg_shear,
@@ -881,6 +951,8 @@ void Evp::prepare(double dt) {
   prepared = true;
 }
 
+bool Evp::derives_metrics() const { return derive_ok && derive_on; }
+
 void Evp::active_cells(long long* nt, long long* nu) {
   CICE_REQUIRE(prepared, "cice_evp_active_cells before cice_evp_prepare");
   unsigned long long h[2];
@@ -890,16 +962,22 @@ void Evp::active_cells(long long* nt, long long* nu) {
   if (nu) *nu = (long long)h[1];
 }
 
-template <int W, int R>
-static void launch_wr(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+template <int W, int R, bool DERIVE>
+static void launch_wrd(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
   const dim3 blk(64 * W);
   if (last) {
-    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, true, true>), g, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_subcycle<W, R, true, false>), g, blk, 0, s, a);
+    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, true, true, DERIVE>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<W, R, true, false, DERIVE>), g, blk, 0, s, a);
   } else {
-    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, false, true>), g, blk, 0, s, a);
-    else hipLaunchKernelGGL((k_subcycle<W, R, false, false>), g, blk, 0, s, a);
+    if (damp) hipLaunchKernelGGL((k_subcycle<W, R, false, true, DERIVE>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle<W, R, false, false, DERIVE>), g, blk, 0, s, a);
   }
+}
+
+template <int W, int R>
+static void launch_wr(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+  if (a.HTN) launch_wrd<W, R, true>(a, last, damp, g, s);
+  else launch_wrd<W, R, false>(a, last, damp, g, s);
 }
 
 void Evp::launch_subcycle(int ksub) {
@@ -915,6 +993,8 @@ void Evp::launch_subcycle(int ksub) {
   a.sig_in = sig[cur].p; a.sig_out = sig[1 - cur].p;
   a.dxt = dxt.p; a.dyt = dyt.p; a.dxhy = dxhy.p; a.dyhx = dyhx.p; a.cxp = cxp.p; a.cyp = cyp.p;
   a.cxm = cxm.p; a.cym = cym.p; a.tarear = tarear.p; a.tinyarea = tinyarea.p; a.strength = strength.p;
+  const bool dv = derive_ok && derive_on;
+  a.HTN = dv ? HTN.p : nullptr; a.HTE = dv ? HTE.p : nullptr;
   a.aiu = aiu.p; a.uocn = uocn.p; a.vocn = vocn.p; a.waterx = waterx.p; a.watery = watery.p;
   a.forcex = forcex.p; a.forcey = forcey.p; a.umassdtei = umassdtei.p; a.fm = fm.p; a.uarear = uarear.p;
   a.divu = divu.p; a.rdg_conv = rdg_conv.p; a.rdg_shear = rdg_shear.p; a.shear = shear.p;
@@ -953,7 +1033,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   // RCCL calls are not captured: graphs only on a single rank
   const bool graph_ok = use_graph && !halo.multi_rank() && nsub > 1;
   if (graph_ok) {
-    const int key[4] = {cur, ksub0, nsub, waves * 100 + rows_per_wave};
+    const int key[4] = {cur, ksub0, nsub, (waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)};
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();
       hipGraph_t gph = nullptr;

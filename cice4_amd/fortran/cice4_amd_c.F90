@@ -14,6 +14,7 @@ module cice4_amd_c
    type, bind(C) :: cice_evp_grid      ! source/ice_grid.F90:58-133 arrays
       type(c_ptr) :: dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarea, uarea, tarear, &
                      uarear, tinyarea, fcor, tmask, umask
+      type(c_ptr) :: HTN = c_null_ptr, HTE = c_null_ptr   ! optional
    end type
 
    type, bind(C) :: cice_evp_config    ! ice_dyn_evp.F90:64-74, ice_mechred.F90:64-79

@@ -63,6 +63,7 @@ program evp_driver
    grid%tarea = c_loc(g(1,9)); grid%uarea = c_loc(g(1,10)); grid%tarear = c_loc(g(1,11))
    grid%uarear = c_loc(g(1,12)); grid%tinyarea = c_loc(g(1,13)); grid%fcor = c_loc(g(1,14))
    grid%tmask = c_loc(tmask); grid%umask = c_loc(umask)
+   grid%HTN = c_null_ptr; grid%HTE = c_null_ptr
    cfg%ndte = ndte; cfg%evp_damping = 0
    cfg%kstrength = 1; cfg%krdg_partic = 1; cfg%krdg_redist = 1; cfg%mu_rdg = 4.0d0
    call cice_gpu_check(cice_evp_init(cice_gpu_ctx, cfg, grid), 'cice_evp_init')

@@ -145,6 +145,7 @@
       g%tarear = addr_r8(tarear); g%uarear = addr_r8(uarear); g%tinyarea = addr_r8(tinyarea)
       g%fcor = addr_r8(fcor_blk)
       g%tmask = addr_l4(tmask); g%umask = addr_l4(umask)
+      g%HTN = addr_r8(HTN); g%HTE = addr_r8(HTE)
       cfg%ndte = ndte
       cfg%evp_damping = merge(1, 0, evp_damping)
       cfg%kstrength = kstrength; cfg%krdg_partic = krdg_partic; cfg%krdg_redist = krdg_redist

@@ -18,6 +18,7 @@ SIG_NAMES = ("stressp_1", "stressp_2", "stressp_3", "stressp_4", "stressm_1", "s
              "stressm_3", "stressm_4", "stress12_1", "stress12_2", "stress12_3", "stress12_4")
 EVP_GRID = ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
             "uarear", "tinyarea", "fcor", "tmask", "umask")
+EVP_GRID_OPT = ("HTN", "HTE")
 EVP_IN = ("aice", "vice", "vsno", "aice0", "aicen", "vicen", "strairxT", "strairyT", "uocn", "vocn",
           "ss_tltx", "ss_tlty")
 EVP_IO = ("uvel", "vvel") + SIG_NAMES + ("iceumask", "fm", "strtltx", "strtlty", "strocnx", "strocny",
@@ -40,7 +41,7 @@ class CiceError(RuntimeError):
 
 
 class EvpGrid(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in EVP_GRID]
+    _fields_ = [(n, C.c_void_p) for n in EVP_GRID + EVP_GRID_OPT]
 
 
 class EvpConfig(C.Structure):
@@ -189,6 +190,8 @@ class Context:
         for n in EVP_GRID:
             a = grid[n]
             setattr(g, n, (_i4(a) if n in ("tmask", "umask") else _f8(a)))
+        for n in EVP_GRID_OPT:
+            setattr(g, n, _f8(grid[n]) if n in grid else None)
         cfg = EvpConfig(ndte, int(evp_damping), kstrength, krdg_partic, krdg_redist, mu_rdg)
         self._ck(self.lib.cice_evp_init(self.h, C.byref(cfg), C.byref(g)))
 
@@ -230,6 +233,11 @@ class Context:
 
     def evp_set_option(self, key, value):
         self._ck(self.lib.cice_evp_set_option(self.h, key.encode(), int(value)))
+
+    def evp_get_info(self, key):
+        v = C.c_int(0)
+        self._ck(self.lib.cice_evp_get_info(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def evp_active_cells(self):
         nt = C.c_longlong(); nu = C.c_longlong()

@@ -84,6 +84,10 @@ typedef struct { /* source/ice_grid.F90:58-133; each (nx_block,ny_block,nblocks)
       *uarear, *tinyarea;
   const double *fcor;           /* fcor_blk, ice_dyn_evp.F90:105,503 */
   const int32_t *tmask, *umask; /* logical */
+  /* Optional (may be NULL): the primary cell lengths HTN, HTE (ice_grid.F90:60-61).  When given and
+   * the nine T-cell metrics above are bit-for-bit the functions of HTN/HTE that init_grid2 computes
+   * (checked on the host at init), the subcycle kernel recomputes them instead of loading them. */
+  const double *HTN, *HTE;
 } cice_evp_grid;
 
 typedef struct { /* namelist + ridging switches read by evp (ice_dyn_evp.F90:64-74; ice_mechred.F90:64-79) */
@@ -130,9 +134,11 @@ int cice_evp_download(cice_ctx *ctx, cice_evp_fields *f);       /* io + out fiel
 int cice_evp_prepare(cice_ctx *ctx, double dt);
 int cice_evp_subcycles(cice_ctx *ctx, int ksub0, int nsub, float *elapsed_ms);
 int cice_evp_finish(cice_ctx *ctx);
-/* tuning / A-B switches: key "tile_rows" (rows of T-cells per workgroup tile: 8,16,32),
- * "use_graph" (0/1).  Results never depend on them. */
+/* tuning / A-B switches: "waves" (wavefronts per workgroup: 4, 8, 16), "rows_per_wave" (T-rows
+ * per wavefront: 1, 2, 4, 8), "use_graph" (0/1), "derive_metrics" (0/1, see cice_evp_grid).
+ * Results never depend on them.  cice_evp_get_info: key "derive_metrics" -> 1 if active. */
 int cice_evp_set_option(cice_ctx *ctx, const char *key, int value);
+int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
  * (= sum of icellt / icellu, ice_dyn_evp.F90:160-162) */
 int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucells);

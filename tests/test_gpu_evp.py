@@ -242,7 +242,7 @@ def test_fortran_dropin_module_inside_reference_callers(orc):
     grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.15, land_frac=0.05), dom)
     s = synth.evp_state(grid, dom, cover="patchy")
     for k in ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
-              "uarear", "tinyarea", "fcor"):
+              "uarear", "tinyarea", "fcor", "HTN", "HTE"):
         ref.set(k, grid[k])
     ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
     ref.set_strength_parameters(1, 0, 0, 4.0)      # exp-free strength: bit-for-bit comparison
@@ -299,3 +299,31 @@ def test_standalone_fortran_driver(ctx, tmp_path):
         for k in ("fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty", "strairx", "strairy",
                   "strength", "divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strocnxT", "strocnyT"):
             assert np.array_equal(np.fromfile(f, np.float64, n).reshape(sg[k].shape), sg[k]), k
+
+
+def test_metric_derivation_is_verified_and_exact(ctx, orc):
+    """The kernel may recompute the nine T-cell metrics from HTN/HTE only after the host has
+    verified the identity bit for bit; with it on or off, and on a grid where the identity does
+    NOT hold (so that it must switch itself off), results equal the checker bit for bit."""
+    dom, grid, s = _setup(ctx, 96, 70, 48, 35, cover="patchy", seed=21)
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    outs = []
+    for variant in ("derive", "off", "inconsistent"):
+        g = dict(grid)
+        if variant == "inconsistent":
+            g["dxt"] = grid["dxt"] * (1.0 + 1e-9)      # metrics no longer functions of HTN/HTE
+            g["tarear"] = grid["tarear"].copy()
+        so = {k: v.copy() for k, v in s.items()}
+        orc.evp(orc.make_domain(dom, g), so)
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp_init(g, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+        if variant == "off":
+            ctx.evp_set_option("derive_metrics", 0)
+        assert ctx.evp_get_info("derive_metrics") == (1 if variant == "derive" else 0)
+        ctx.evp(DT, sg)
+        for k in EVP_OUT_FIELDS:
+            assert np.array_equal(sg[k], so[k]), (variant, k)
+        outs.append(sg)
+    orc.set_strength_parameters()
+    for k in EVP_OUT_FIELDS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
