@@ -568,6 +568,44 @@ int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
   CICE_CATCH
 }
 
+int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
+  CICE_TRY(ctx)
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0 && f, "cice_thermo_batch_alloc has not been called");
+  hipStream_t s = c_->stream;
+  const size_t n2 = (size_t)t.nx * t.ny * t.nb, nc = n2 * NCAT;
+  DevBuf<double> up, acc;
+  up.alloc(5 * nc);
+  acc.alloc(20 * n2);
+  const double* hin[5] = {f->aicen_init, f->strairxn, f->strairyn, f->Trefn, f->Qrefn};
+  for (int k = 0; k < 5; ++k) {
+    CICE_REQUIRE(hin[k] != nullptr, "cice_thermo_batch_merge: NULL input");
+    CICE_HIP(hipMemcpyAsync(up.p + (size_t)k * nc, hin[k], nc * 8, hipMemcpyHostToDevice, s));
+  }
+  for (int k = 0; k < 20; ++k) {
+    CICE_REQUIRE(f->acc[k] != nullptr, "cice_thermo_batch_merge: NULL accumulator");
+    CICE_HIP(hipMemcpyAsync(acc.p + (size_t)k * n2, f->acc[k], n2 * 8, hipMemcpyHostToDevice, s));
+  }
+  MergeArgs a{};
+  a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.blk = t.blk.p;
+  a.aicen_init = up.p; a.flw = t.flw.p;
+  auto out = [&](int k) { return (const double*)(t.out15.p + (size_t)k * nc); };
+  // out15 order: fsurfn fcondtopn fsensn flatn fswabsn flwoutn evapn freshn fsaltn fhocnn meltt melts
+  //              meltb congel snoice
+  const double* src[20] = {up.p + nc, up.p + 2 * nc, out(0), out(1), out(2), out(3), out(4), out(5),
+                           out(6), up.p + 3 * nc, up.p + 4 * nc, out(7), out(8), out(9), t.fswthrun.p,
+                           out(10), out(12), out(11), out(13), out(14)};
+  for (int k = 0; k < 20; ++k) {
+    a.src[k] = src[k];
+    a.acc[k] = acc.p + (size_t)k * n2;
+  }
+  merge_launch(a, s);
+  for (int k = 0; k < 20; ++k)
+    CICE_HIP(hipMemcpyAsync(f->acc[k], acc.p + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  CICE_CATCH
+}
+
 int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, int jlo, int jhi,
                                double dt, const double* aice, const double* frzmlt,
                                const double* eicen, const double* esnon, const double* sst,

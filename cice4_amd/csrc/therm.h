@@ -39,6 +39,15 @@ struct ThermoArgs {
 void thermo_launch_list(const ThermoArgs& a, hipStream_t s);
 void thermo_launch_dense(const ThermoArgs& a, hipStream_t s);
 
+struct MergeArgs {  // merge_fluxes, ice_flux.F90:613-762
+  int nx, ny, ncat, nblocks;
+  const int32_t* blk;
+  const double *aicen_init, *flw;
+  const double* src[20];  // per-category sources, (nx,ny,ncat,nb)
+  double* acc[20];        // cumulative, (nx,ny,nb)
+};
+void merge_launch(const MergeArgs& a, hipStream_t s);
+
 struct FrzmltArgs {
   int nx, ny, ilo, ihi, jlo, jhi;
   double dt, ustar_min;

@@ -721,6 +721,41 @@ __global__ __launch_bounds__(256) void k_thermo_dense(const ThermoArgs a) {
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
 }
 
+// merge_fluxes (ice_flux.F90:730-760): one lane per cell accumulates the categories in order
+__global__ __launch_bounds__(256) void k_merge(const MergeArgs a) {
+  const size_t np = (size_t)a.nx * a.ny;
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (q >= np) return;
+  const int j = (int)(q / a.nx) + 1, i = (int)(q - (size_t)(j - 1) * a.nx) + 1;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  if (i < ilo || i > ihi || j < jlo || j > jhi) return;
+  const size_t f2d = (size_t)b * np + q;
+  double acc[20];
+  bool any = false;
+  for (int n = 0; n < a.ncat; ++n) {
+    const size_t c2d = ((size_t)b * a.ncat + n) * np + q;
+    const double ai = a.aicen_init[c2d];
+    if (!(ai > puny)) continue;
+    if (!any) {
+#pragma unroll
+      for (int k = 0; k < 20; ++k) acc[k] = a.acc[k][f2d];
+      any = true;
+    }
+#pragma unroll
+    for (int k = 0; k < 20; ++k) {
+      if (k == 7)
+        acc[k] = acc[k] + (a.src[k][c2d] - (c1 - emissivity) * a.flw[f2d]) * ai;
+      else
+        acc[k] = acc[k] + a.src[k][c2d] * ai;
+    }
+  }
+  if (any) {
+#pragma unroll
+    for (int k = 0; k < 20; ++k) a.acc[k][f2d] = acc[k];
+  }
+}
+
 // frzmlt_bottom_lateral :605-824 (cpchr compile-time constant of the non-AusCOM build)
 __global__ __launch_bounds__(256) void k_frzmlt(const FrzmltArgs a) {
   const size_t np = (size_t)a.nx * a.ny;
@@ -770,6 +805,12 @@ void thermo_launch_dense(const ThermoArgs& a, hipStream_t s) {
   const size_t np = (size_t)a.nx * a.ny;
   const dim3 g((unsigned)((np + 255) / 256), a.ncat, a.nblocks);
   hipLaunchKernelGGL(k_thermo_dense, g, dim3(256), 0, s, a);
+  CICE_HIP(hipGetLastError());
+}
+
+void merge_launch(const MergeArgs& a, hipStream_t s) {
+  const size_t np = (size_t)a.nx * a.ny;
+  hipLaunchKernelGGL(k_merge, dim3((unsigned)((np + 255) / 256), a.nblocks), dim3(256), 0, s, a);
   CICE_HIP(hipGetLastError());
 }
 

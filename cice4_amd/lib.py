@@ -59,6 +59,15 @@ class ThermoConfig(C.Structure):
                 ("nt_iage", C.c_int)]
 
 
+MERGE_ORDER = ("strairxT", "strairyT", "fsurf", "fcondtop", "fsens", "flat", "fswabs", "flwout", "evap", "Tref",
+               "Qref", "fresh", "fsalt", "fhocn", "fswthru", "meltt", "meltb", "melts", "congel", "snoice")
+
+
+class MergeFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("aicen_init", "strairxn", "strairyn", "Trefn", "Qrefn")] + \
+               [("acc", C.c_void_p * 20)]
+
+
 class ThermoFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in THERMO_STATE + THERMO_FORCING + THERMO_CAT_IN + THERMO_SW
                 + THERMO_OUT + THERMO_ONSET]
@@ -316,6 +325,17 @@ class Context:
     def thermo_batch_download(self, a):
         f = self._thermo_fields(a)
         self._ck(self.lib.cice_thermo_batch_download(self.h, C.byref(f)))
+
+    def thermo_batch_merge(self, percat, acc):
+        """percat: aicen_init, strairxn, strairyn, Trefn, Qrefn ((nb,ncat,ny,nx)); acc: dict keyed by
+        MERGE_ORDER ((nb,ny,nx)), updated in place (merge_fluxes for every category)."""
+        f = MergeFields()
+        for n in ("aicen_init", "strairxn", "strairyn", "Trefn", "Qrefn"):
+            setattr(f, n, _f8(percat[n]))
+        for k, n in enumerate(MERGE_ORDER):
+            f.acc[k] = acc[n].ctypes.data
+            assert acc[n].dtype == np.float64 and acc[n].flags["C_CONTIGUOUS"]
+        self._ck(self.lib.cice_thermo_batch_merge(self.h, C.byref(f)))
 
     def frzmlt_bottom_lateral(self, ilo, ihi, jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf,
                               strocnxT, strocnyT):

@@ -223,6 +223,20 @@ int cice_thermo_batch_step(cice_ctx *ctx, double dt, double yday, long long *n_u
                            int32_t *bstop, float *elapsed_ms);
 int cice_thermo_batch_download(cice_ctx *ctx, cice_thermo_fields *host);
 
+/* merge_fluxes (source/ice_flux.F90:613-762) for all categories of all blocks after a batched
+ * step: acc[k] += catn[k] * aicen_init over n = 1..ncat in category order, on the cells of each
+ * category's list (aicen_init(i,j,n) > puny on the physical domain), flwout with its
+ * -(1-emissivity)*flw term.  The 15 thermo outputs and fswthrun come from the device-resident
+ * batch; strairxn, strairyn, Trefn, Qrefn (atmo_boundary_layer outputs, (nx,ny,ncat,nb)) and
+ * aicen_init are given here.  acc[20]: host (nx,ny,nb) cumulative fields in the order
+ * strairxT, strairyT, fsurf, fcondtop, fsens, flat, fswabs, flwout, evap, Tref, Qref, fresh, fsalt,
+ * fhocn, fswthru, meltt, meltb, melts, congel, snoice; updated in place. */
+typedef struct {
+  const double *aicen_init, *strairxn, *strairyn, *Trefn, *Qrefn;
+  double *acc[20];
+} cice_merge_fields;
+int cice_thermo_batch_merge(cice_ctx *ctx, const cice_merge_fields *f);
+
 /* frzmlt_bottom_lateral (:605-824), one block, host pointers;
  * eicen (nx,ny,ntilyr), esnon (nx,ny,ntslyr). */
 int cice_frzmlt_bottom_lateral(cice_ctx *ctx, int nx_block, int ny_block, int ilo, int ihi,

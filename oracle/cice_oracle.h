@@ -150,4 +150,11 @@ void orc_frzmlt_bottom_lateral(const orc_thermo_cfg *c, int nx, int ny, int ilo,
                                const double *Tf, const double *strocnxT, const double *strocnyT,
                                double *Tbot, double *fbot, double *rside);
 
+/* merge_fluxes, ice_flux.F90:613-762; catn/acc order: strairx, strairy, fsurf, fcondtop, fsens,
+ * flat, fswabs, flwout, evap, Tref, Qref, fresh, fsalt, fhocn, fswthru, meltt, meltb, melts,
+ * congel, snoice */
+void orc_merge_fluxes(int nx, int ny, int icells, const int32_t *indxi, const int32_t *indxj,
+                      const double *aicen, const double *flw, const double *const catn[20],
+                      double *const acc[20]);
+
 #endif

@@ -228,3 +228,15 @@ class Oracle:
                                            _p(Tf), _p(strocnxT), _p(strocnyT), _p(Tbot), _p(fbot),
                                            _p(rside))
         return Tbot, fbot, rside
+
+    MERGE_ORDER = ("strairx", "strairy", "fsurf", "fcondtop", "fsens", "flat", "fswabs", "flwout", "evap",
+                   "Tref", "Qref", "fresh", "fsalt", "fhocn", "fswthru", "meltt", "meltb", "melts", "congel",
+                   "snoice")
+
+    def merge_fluxes(self, icells, indxi, indxj, aicen, flw, catn, acc):
+        """catn / acc: dicts keyed by MERGE_ORDER ((ny,nx) arrays); acc modified in place."""
+        ny, nx = aicen.shape
+        cp = (C.c_void_p * 20)(*[catn[k].ctypes.data for k in self.MERGE_ORDER])
+        ap = (C.c_void_p * 20)(*[acc[k].ctypes.data for k in self.MERGE_ORDER])
+        self.lib.orc_merge_fluxes(C.c_int(nx), C.c_int(ny), C.c_int(icells), _p(indxi), _p(indxj), _p(aicen),
+                                  _p(flw), cp, ap)

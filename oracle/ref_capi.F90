@@ -256,6 +256,25 @@ contains
       if (ls) l_stop = 1
    end subroutine ref_thermo_vertical
 
+   subroutine ref_merge_fluxes(nx, ny, icells, indxi, indxj, aicen, flw, c, a) bind(C, name='ref_merge_fluxes')
+      ! c(:,:,k), a(:,:,k): the 20 per-category / cumulative fields in the order strairx, strairy,
+      ! fsurf, fcondtop, fsens, flat, fswabs, flwout, evap, Tref, Qref, fresh, fsalt, fhocn, fswthru,
+      ! meltt, meltb, melts, congel, snoice
+      use ice_flux, only: merge_fluxes
+      integer(c_int), value :: nx, ny, icells
+      integer(c_int), intent(in) :: indxi(nx*ny), indxj(nx*ny)
+      real(c_double), intent(in) :: aicen(nx,ny), flw(nx,ny), c(nx,ny,20)
+      real(c_double), intent(inout) :: a(nx,ny,20)
+      real(c_double) :: coszn(nx,ny)
+      coszn = 0.0d0
+      call merge_fluxes(nx, ny, icells, indxi, indxj, aicen, flw, coszn, c(:,:,1), c(:,:,2), c(:,:,3), &
+         c(:,:,4), c(:,:,5), c(:,:,6), c(:,:,7), c(:,:,8), c(:,:,9), c(:,:,10), c(:,:,11), c(:,:,12), &
+         c(:,:,13), c(:,:,14), c(:,:,15), a(:,:,1), a(:,:,2), a(:,:,3), a(:,:,4), a(:,:,5), a(:,:,6), &
+         a(:,:,7), a(:,:,8), a(:,:,9), a(:,:,10), a(:,:,11), a(:,:,12), a(:,:,13), a(:,:,14), a(:,:,15), &
+         c(:,:,16), c(:,:,18), c(:,:,17), c(:,:,19), c(:,:,20), a(:,:,16), a(:,:,18), a(:,:,17), &
+         a(:,:,19), a(:,:,20))
+   end subroutine ref_merge_fluxes
+
    subroutine ref_frzmlt_bottom_lateral(nx, ny, ilo, ihi, jlo, jhi, dt, aice, frzmlt, &
          eicen, esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside) &
          bind(C, name='ref_frzmlt_bottom_lateral')

@@ -183,6 +183,19 @@ class Ref:
                                            _p(strocnxT), _p(strocnyT), _p(Tbot), _p(fbot), _p(rside))
         return Tbot, fbot, rside
 
+    MERGE_ORDER = ("strairx", "strairy", "fsurf", "fcondtop", "fsens", "flat", "fswabs", "flwout", "evap",
+                   "Tref", "Qref", "fresh", "fsalt", "fhocn", "fswthru", "meltt", "meltb", "melts", "congel",
+                   "snoice")
+
+    def merge_fluxes(self, icells, indxi, indxj, aicen, flw, catn, acc):
+        ny, nx = aicen.shape
+        c = np.ascontiguousarray(np.stack([catn[k] for k in self.MERGE_ORDER]))
+        a = np.ascontiguousarray(np.stack([acc[k] for k in self.MERGE_ORDER]))
+        self.lib.ref_merge_fluxes(C.c_int(nx), C.c_int(ny), C.c_int(icells), _p(indxi), _p(indxj), _p(aicen),
+                                  _p(flw), _p(c), _p(a))
+        for i, k in enumerate(self.MERGE_ORDER):
+            acc[k][...] = a[i]
+
     # ---- whole-domain path --------------------------------------------
     def init_domain(self, workdir, dt=3600.0, ndte=120, damping=False, grid="rectangular",
                     grid_file="", kmt_file="", ew="cyclic", ns="open", nprocs=1):

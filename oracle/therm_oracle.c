@@ -758,3 +758,22 @@ void orc_frzmlt_bottom_lateral(const orc_thermo_cfg *c, int nx, int ny, int ilo,
       rside[q] = rside[q] * xtmp;
     }
 }
+
+/* merge_fluxes, source/ice_flux.F90:613-762: area-weighted accumulation of one category's
+ * fluxes into the cell aggregates, over the compressed list of the category. */
+void orc_merge_fluxes(int nx, int ny, int icells, const int32_t *indxi, const int32_t *indxj,
+                      const double *aicen, const double *flw, const double *const catn[20],
+                      double *const acc[20]) {
+  /* order of catn / acc: strairx, strairy, fsurf, fcondtop, fsens, flat, fswabs, flwout, evap,
+   * Tref, Qref, fresh, fsalt, fhocn, fswthru, meltt, meltb, melts, congel, snoice */
+  (void)ny;
+  for (int ij = 0; ij < icells; ij++) {
+    const size_t q = (size_t)(indxj[ij] - 1) * nx + (indxi[ij] - 1);
+    for (int k = 0; k < 20; k++) {
+      if (k == 7)
+        acc[k][q] = acc[k][q] + (catn[k][q] - (c1 - emissivity) * flw[q]) * aicen[q];
+      else
+        acc[k][q] = acc[k][q] + catn[k][q] * aicen[q];
+    }
+  }
+}

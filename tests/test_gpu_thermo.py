@@ -160,6 +160,40 @@ def test_batched_step_equals_per_category_calls(ctx, orc):
     assert st["n_updates"] == nupd
 
 
+def test_batch_merge_equals_merge_fluxes(ctx, orc):
+    """cice_thermo_batch_merge = merge_fluxes (ice_flux.F90:613) called once per category with
+    that category's list and aicen_init, on the batch's own per-category outputs: bit for bit."""
+    ctx.thermo_init(); orc.init_thermo()
+    ny, nx, nb = 22, 34, 2
+    batch, percat = _batch_inputs(ny, nx, nb, seed=33)
+    aicen_init = batch["aicen"].copy()
+    ctx.thermo_batch_alloc(nx, ny, nb)
+    ctx.thermo_batch_upload(batch)
+    assert ctx.thermo_batch_step(DT, yday=150.0)["l_stop"] == 0
+    ctx.thermo_batch_download(batch)
+    rng = np.random.default_rng(4)
+    pc = dict(aicen_init=aicen_init)
+    for k in ("strairxn", "strairyn", "Trefn", "Qrefn"):
+        pc[k] = np.ascontiguousarray(rng.uniform(-1, 1, aicen_init.shape))
+    acc0 = {k: np.ascontiguousarray(rng.uniform(-1, 1, (nb, ny, nx))) for k in lib.MERGE_ORDER}
+    got = {k: v.copy() for k, v in acc0.items()}
+    ctx.thermo_batch_merge(pc, got)
+    src = dict(strairx="strairxn", strairy="strairyn", Tref="Trefn", Qref="Qrefn", fsurf="fsurfn",
+               fcondtop="fcondtopn", fsens="fsensn", flat="flatn", fswabs="fswabsn", flwout="flwoutn",
+               evap="evapn", fresh="freshn", fsalt="fsaltn", fhocn="fhocnn", fswthru="fswthrun",
+               meltt="meltt", meltb="meltb", melts="melts", congel="congel", snoice="snoice")
+    okeys = orc.MERGE_ORDER
+    for b in range(nb):
+        want = {ok: acc0[lk][b].copy() for ok, lk in zip(okeys, lib.MERGE_ORDER)}
+        for n in range(5):
+            a, icells, ii, jj = percat[(b, n)]
+            catn = {ok: np.ascontiguousarray((pc if src[ok] in pc else batch)[src[ok]][b, n]) for ok in okeys}
+            orc.merge_fluxes(icells, ii, jj, np.ascontiguousarray(aicen_init[b, n]),
+                             np.ascontiguousarray(batch["flw"][b]), catn, want)
+        for ok, lk in zip(okeys, lib.MERGE_ORDER):
+            assert np.array_equal(got[lk][b], want[ok]), (b, lk)
+
+
 def test_frzmlt_bottom_lateral(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
     ny, nx = 30, 44
@@ -173,3 +207,36 @@ def test_frzmlt_bottom_lateral(ctx, orc):
     c = orc.frzmlt_bottom_lateral(2, nx - 1, 2, ny - 1, DT, aice, frzmlt, eicen, esnon, sst, Tf, sx, sy)
     for a, b, nm in zip(g, c, ("Tbot", "fbot", "rside")):
         assert relerr(a, b) <= TOL, nm
+
+
+def test_fortran_dropin_thermo_module(orc):
+    """The reference's callers + wrapper linked with OUR cice4_amd/fortran/ice_therm_vertical.F90:
+    `call thermo_vertical(...)` / `call frzmlt_bottom_lateral(...)` go Fortran -> ISO_C_BINDING
+    shim -> GPU and must reproduce the checker; init_thermo_vertical hands back the salinity
+    profile."""
+    from oracle import refapi
+    if not refapi.available("gx3b4", "dropin"):
+        pytest.skip("oracle/_ref/libcice_dropin_gx3b4.so not built")
+    ref = refapi.Ref("gx3b4", kind="dropin")
+    sr, tr = ref.init_thermo(); so, to = orc.init_thermo()
+    assert relerr(sr, so) < 1e-15 and relerr(tr, to) < 1e-15
+    for n in (0, 2, 4):
+        a, icells, ii, jj = synth.thermo_columns(30, 44, n, regime="mixed", seed=77)
+        ag = {k: v.copy() for k, v in a.items()}; ac = {k: v.copy() for k, v in a.items()}
+        assert ref.thermo_vertical(DT, icells, ii, jj, ag, yday=100.0) == \
+            orc.thermo_vertical(DT, icells, ii, jj, ac, yday=100.0) == (0, 0, 0)
+        _cmp(ag, ac, ("dropin", n))
+    # error path through the Fortran logical
+    a, icells, ii, jj = synth.thermo_columns(20, 30, 2, regime="winter", seed=5)
+    a["eicen"][1][jj[7] - 1, ii[7] - 1] *= 40.0
+    ag = {k: v.copy() for k, v in a.items()}; ac = {k: v.copy() for k, v in a.items()}
+    lg = ref.thermo_vertical(DT, icells, ii, jj, ag); lc = orc.thermo_vertical(DT, icells, ii, jj, ac)
+    assert lc[0] == 1 and lg == lc
+    ny, nx = 30, 44
+    rng = np.random.default_rng(8)
+    aice = np.where(rng.uniform(0, 1, (ny, nx)) < 0.8, rng.uniform(0.01, 1, (ny, nx)), 0.0)
+    args = (2, nx - 1, 2, ny - 1, DT, aice, rng.uniform(-60, 20, (ny, nx)), -rng.uniform(1e6, 3e8, (20, ny, nx)),
+            -rng.uniform(0, 5e7, (5, ny, nx)), np.full((ny, nx), -1.8) + rng.uniform(0, 1.5, (ny, nx)),
+            np.full((ny, nx), -1.8), rng.uniform(-0.2, 0.2, (ny, nx)), rng.uniform(-0.2, 0.2, (ny, nx)))
+    for x, y, nm in zip(ref.frzmlt_bottom_lateral(*args), orc.frzmlt_bottom_lateral(*args), ("Tbot", "fbot", "rside")):
+        assert relerr(x, y) <= TOL, nm

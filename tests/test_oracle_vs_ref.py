@@ -186,3 +186,17 @@ def test_frzmlt_bottom_lateral(ref_gx3, orc):
             np.full((ny, nx), -1.8), rng.uniform(-0.2, 0.2, (ny, nx)), rng.uniform(-0.2, 0.2, (ny, nx)))
     for x, y in zip(ref_gx3.frzmlt_bottom_lateral(*args), orc.frzmlt_bottom_lateral(*args)):
         assert np.array_equal(x, y)
+
+
+def test_merge_fluxes(ref_gx3, orc):
+    rng = np.random.default_rng(0); ny, nx = 20, 30
+    U = lambda: np.ascontiguousarray(rng.uniform(-1, 1, (ny, nx)))
+    aicen = np.ascontiguousarray(rng.uniform(0, 1, (ny, nx))); flw = np.ascontiguousarray(rng.uniform(200, 300, (ny, nx)))
+    catn = {k: U() for k in orc.MERGE_ORDER}; acc0 = {k: U() for k in orc.MERGE_ORDER}
+    jj, ii = np.nonzero(rng.uniform(0, 1, (ny, nx)) < 0.7); n = len(ii)
+    li = np.zeros(nx * ny, np.int32); lj = np.zeros(nx * ny, np.int32); li[:n] = ii + 1; lj[:n] = jj + 1
+    a1 = {k: v.copy() for k, v in acc0.items()}; a2 = {k: v.copy() for k, v in acc0.items()}
+    ref_gx3.merge_fluxes(n, li, lj, aicen, flw, catn, a1); orc.merge_fluxes(n, li, lj, aicen, flw, catn, a2)
+    for k in a1:
+        assert np.array_equal(a1[k], a2[k]), k
+    assert any((a1[k] != acc0[k]).any() for k in a1)
