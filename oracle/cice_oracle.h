@@ -102,6 +102,11 @@ typedef struct {
   const int32_t *tmask, *umask;
   int kstrength, krdg_partic, krdg_redist;
   double mu_rdg;
+  /* sensitivity probe (tests only): move every computed strength value by one ulp, up or down
+   * in a fixed pseudo-random pattern, before the subcycling -- the size of the libm (exp)
+   * difference between any two hosts -- so that a test can measure how much the reference's own
+   * result moves under it. 0 = off. */
+  int perturb_strength_ulp;
 } orc_domain;
 
 typedef struct {

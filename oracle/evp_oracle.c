@@ -529,6 +529,10 @@ static void evp_prepare(const orc_domain *d, const orc_evp_params *p, orc_evp_st
                      s->aice + o, s->vice + o, s->aice0 + o, s->aicen + (size_t)b * ORC_NCAT * np,
                      s->vicen + (size_t)b * ORC_NCAT * np, s->strength + o);
   }
+  if (d->perturb_strength_ulp)
+    for (size_t q = 0; q < n; q++)
+      if (s->strength[q] != 0.0)
+        s->strength[q] = nextafter(s->strength[q], ((q * 2654435761u) >> 7) & 1 ? INFINITY : -INFINITY);
   halo8(d, s->strength); /* :336-344 */
   halo8(d, s->uvel);
   halo8(d, s->vvel);

@@ -46,7 +46,8 @@ class Domain(C.Structure):
                 ("nfill", C.c_int), ("hfill", C.c_void_p)] + \
                [(n, C.c_void_p) for n in _DOM_PTRS] + \
                [("tmask", C.c_void_p), ("umask", C.c_void_p), ("kstrength", C.c_int),
-                ("krdg_partic", C.c_int), ("krdg_redist", C.c_int), ("mu_rdg", C.c_double)]
+                ("krdg_partic", C.c_int), ("krdg_redist", C.c_int), ("mu_rdg", C.c_double),
+                ("perturb_strength_ulp", C.c_int)]
 
 
 _ST_IN = ("aice", "vice", "vsno", "aice0", "aicen", "vicen", "strairxT", "strairyT", "uocn", "vocn",
@@ -154,7 +155,7 @@ class Oracle:
         return strength
 
     # ---- whole evp ------------------------------------------------------
-    def make_domain(self, dom, grid):
+    def make_domain(self, dom, grid, perturb_strength_ulp=0):
         """dom: dict(nx, ny, nblocks, ilo.., hsrc, hdst[, hfill]); grid: dict of (nb,ny,nx)."""
         d = Domain()
         d.nx, d.ny, d.nblocks = dom["nx"], dom["ny"], dom["nblocks"]
@@ -174,6 +175,7 @@ class Oracle:
             a = np.ascontiguousarray(grid[n], np.int32); keep.append(a)
             setattr(d, n, a.ctypes.data)
         d.kstrength, d.krdg_partic, d.krdg_redist, d.mu_rdg = self.strength_params
+        d.perturb_strength_ulp = perturb_strength_ulp
         d._keep = keep
         return d
 

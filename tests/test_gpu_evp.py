@@ -327,3 +327,32 @@ def test_metric_derivation_is_verified_and_exact(ctx, orc):
     orc.set_strength_parameters()
     for k in EVP_OUT_FIELDS:
         assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("case", ["no_ice", "one_cell", "all_land", "ndte1"])
+def test_degenerate_inputs(ctx, orc, case):
+    """Edge cases: no ice anywhere (empty lists), a single ice cell, an all-land grid, ndte = 1."""
+    dom, grid, s = _setup(ctx, 40, 30, 20, 15, cover="patchy", seed=6)
+    ndte = 1 if case == "ndte1" else 6
+    if case in ("no_ice", "one_cell"):
+        for k in ("aice", "vice", "vsno", "aicen", "vicen", "strairxT", "strairyT"):
+            s[k][...] = 0.0
+        s["aice0"][...] = 1.0
+        s["iceumask"][...] = 0; s["uvel"][...] = 0.0; s["vvel"][...] = 0.0
+        if case == "one_cell":
+            s["aicen"][1, 2, 7, 9] = 0.8; s["vicen"][1, 2, 7, 9] = 1.5
+            s["aice"][1, 7, 9] = 0.8; s["vice"][1, 7, 9] = 1.5; s["aice0"][1, 7, 9] = 0.2
+            s["strairxT"][1, 7, 9] = 0.1
+    if case == "all_land":
+        grid = dict(grid); grid["tmask"] = np.zeros_like(grid["tmask"]); grid["umask"] = np.zeros_like(grid["umask"])
+    orc.set_evp_parameters(DT, ndte, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    so = {k: v.copy() for k, v in s.items()}
+    orc.evp(orc.make_domain(dom, grid), so)
+    sg = {k: v.copy() for k, v in s.items()}
+    ctx.evp_init(grid, ndte=ndte, krdg_partic=0, krdg_redist=0)
+    ctx.evp(DT, sg)
+    orc.set_strength_parameters()
+    for k in EVP_OUT_FIELDS + ("iceumask",):
+        assert np.array_equal(sg[k], so[k]), (case, k)
+    if case in ("no_ice", "all_land"):
+        assert ctx.evp_active_cells() == (0, 0)
