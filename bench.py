@@ -188,6 +188,23 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     return out
 
 
+def pmc_traffic(workload, waves, rows, derive):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic_final.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
+    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and re-verified on the
+    k_diag_copy8 calibration stream).  None if no pass exists for this kernel variant."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.csv")
+    want = f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>"
+    try:
+        for row in csv.DictReader(open(path)):
+            if row["workload"] == workload and want in row["kernel"]:
+                return float(row["total_MB_per_launch"]) * 1e6, os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    return None, None
+
+
 def cpu_baseline_worker(args):
     """Child process: no GPU is touched.  Rebuilds the same synthetic case on the host, times
     the checker, writes JSON to the given file.  Keeps the Fortran runtime's stdout away from
@@ -245,12 +262,11 @@ def main():
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
     ctx.evp_init(grid, ndte=ndte)
-    nyl = dom["ny"] - 2
-    small = dom["nxg"] * nyl <= 400 * 400     # too few cells to fill 1024 SIMDs: one row per wavefront
-    waves = args.waves or (8 if small else 4)
-    rows = args.rows or (1 if small else 4)
-    ctx.evp_set_option("waves", waves)
-    ctx.evp_set_option("rows_per_wave", rows)
+    if args.waves:
+        ctx.evp_set_option("waves", args.waves)
+    if args.rows:
+        ctx.evp_set_option("rows_per_wave", args.rows)
+    waves, rows = ctx.evp_get_info("waves"), ctx.evp_get_info("rows_per_wave")   # library's own choice by grid size
     tile = f"64x{waves * rows} T-cells ({waves} wavefronts x {rows} rows)"
     ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
     ctx.evp_set_option("derive_metrics", 0 if args.no_derive else 1)
@@ -338,6 +354,7 @@ def main():
         us_per_launch = dev_ms * 1e3 / nsub_total
         bytes_per_launch = EVP_BYTES_PER_CELL * (nt_all / world)
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+        traffic, traffic_src = (pmc_traffic(args.workload, waves, rows, derive) if world == 1 else (None, None))
         out = {
             "metric": "EVP subcycles/sec", "value": value, "unit": "subcycles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_evp / args.steps,
@@ -350,7 +367,8 @@ def main():
                        "active_T_cells": nt_all, "active_U_cells": nu_all,
                        "cell_subcycles_per_s": value * nt_all},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch,
                          "kernel": "k_subcycle (fused stress + stepu + on-rank halo)",
                          "us_per_launch": us_per_launch, "bytes_per_unit": EVP_BYTES_PER_CELL,
                          "units_per_launch": nt_all / world},

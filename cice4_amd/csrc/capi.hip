@@ -278,6 +278,8 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   NEED_EVP;
   CICE_REQUIRE(key && value, "NULL argument");
   if (!std::strcmp(key, "derive_metrics")) *value = c_->evp->derives_metrics() ? 1 : 0;
+  else if (!std::strcmp(key, "waves")) *value = c_->evp->tile_waves();
+  else if (!std::strcmp(key, "rows_per_wave")) *value = c_->evp->tile_rows();
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
   CICE_CATCH
 }

@@ -32,6 +32,8 @@ class Evp {
   void set_option(const char* key, int value);
   void active_cells(long long* nt, long long* nu);
   bool derives_metrics() const;
+  int tile_waves() const { return waves; }
+  int tile_rows() const { return rows_per_wave; }
 
   // one-block, host-pointer entries with the reference argument lists
   static void stress_host(hipStream_t s, double dt, int ndte, int damping, int nx, int ny, int ksub,

@@ -850,6 +850,14 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   iceumask.alloc(n); iceumask.zero(stream);
   icetmask.alloc(n); icetmask.zero(stream);
   counters.alloc(2);
+  // Tile shape by problem size (measured): small grids cannot fill the 1,024 SIMDs
+  // and are latency-bound -> many small workgroups, one row per wavefront; large grids are
+  // bandwidth-bound -> two rows per wavefront (fewer redundant overlap rows, same occupancy).
+  {
+    const long long cells = (long long)dom.nblocks() * dom.bsx * dom.bsy;
+    waves = 4;
+    rows_per_wave = cells <= 400LL * 400LL ? 1 : 2;
+  }
   cur = 0;
   CICE_HIP(hipStreamSynchronize(stream));
   ready = true;

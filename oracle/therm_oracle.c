@@ -37,6 +37,9 @@ static const double ferrmax = 1.0e-3;
 static inline double dmin(double a, double b) { return a < b ? a : b; }
 static inline double dmax(double a, double b) { return a > b ? a : b; }
 
+/* diagnostics for tests/bench: histogram of temperature-solver iterations per column */
+long orc_iter_hist[101];
+
 /* ice_therm_vertical.F90:533-584 */
 void orc_init_thermo(int heat_capacity, int calc_Tsfc, int conduct, double ustar_min,
                      orc_thermo_cfg *c) {
@@ -228,7 +231,9 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
   }
   f->fswabsn = f->fswsfc + f->fswint + f->fswthrun; /* :1605 */
 
+  int niter_done = 0;
   for (int niter = 1; niter <= nitermax && !converged; niter++) {
+    niter_done = niter;
     double etai[NI], sbdiag[NMAT], diag[NMAT], spdiag[NMAT], rhs[NMAT], Tmat[NMAT];
     double dfsurf_dT, avg_Tsi = c0, enew = c0, Tsf_start, dTsf, avg_Tsf;
     double dTmat[NI], dqmat[NI];
@@ -400,6 +405,7 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
         }
     }
   }
+  orc_iter_hist[niter_done]++;
   /* :2136-2145 */
   f->flwoutn = f->flwoutn + dTsf_prev * dflwout_dT;
   f->fsensn = f->fsensn + dTsf_prev * dfsens_dT;
