@@ -68,9 +68,14 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
         if (ig < 0 || jg < 0) continue;  // beyond an open/closed edge: never written
         const Block& s = all[(jg / bsy) * nbx + (ig / bsx)];
         int is = s.ilo + (ig - s.i0), js = s.jlo + (jg - s.j0);
-        if (d.owner == rank && s.owner == rank) {
+        if (d.owner == rank && s.owner == rank && !(self_comm && s.gid != d.gid)) {
           hsrc.push_back(addr(s, is, js));
           hdst.push_back(addr(d, i, j));
+        } else if (d.owner == rank && s.owner == rank) {  // self_comm: both ends are this rank
+          HaloMsg& mr = rmap[rank]; mr.peer = rank;
+          mr.addr.push_back(addr(d, i, j));
+          HaloMsg& ms = smap[rank]; ms.peer = rank;
+          ms.addr.push_back(addr(s, is, js));
         } else if (d.owner == rank) {
           HaloMsg& m = rmap[s.owner]; m.peer = s.owner;
           m.addr.push_back(addr(d, i, j));

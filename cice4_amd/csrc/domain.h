@@ -32,6 +32,9 @@ struct Domain {
   int nx_block = 0, ny_block = 0;
   int nbx = 0, nby = 0, npx = 1, npy = 1, rank = 0, nranks = 1;
   int ew = BND_CYCLIC, ns = BND_OPEN;
+  // Test aid: route copies between DIFFERENT blocks of this rank through the message path
+  // (send to / receive from the own rank), so that pack / RCCL / unpack run on a single GPU.
+  bool self_comm = false;
   std::vector<Block> all;
   std::vector<int> local;            // gids of this rank's blocks, ascending
   std::vector<int32_t> hsrc, hdst;   // on-rank ghost copies: a[hdst[n]] = a[hsrc[n]]

@@ -15,6 +15,7 @@
 #include "evp.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace cice {
@@ -1038,27 +1039,46 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     CICE_HIP(hipEventCreate(&e1));
     CICE_HIP(hipEventRecord(e0, stream));
   }
-  // RCCL calls are not captured: graphs only on a single rank
-  const bool graph_ok = use_graph && !halo.multi_rank() && nsub > 1;
+  // The whole loop -- kernels, pack/unpack and the RCCL point-to-point calls of a multi-rank
+  // domain -- is captured once and replayed (RCCL send/recv capture verified on this ROCm by
+  // scripts/rccl_graph_probe.cpp).  CICE4_AMD_NO_COMM_GRAPH=1 keeps multi-rank loops eager.
+  static const bool no_comm_graph = std::getenv("CICE4_AMD_NO_COMM_GRAPH") != nullptr;
+  const bool graph_ok = use_graph && nsub > 1 && !(halo.multi_rank() && no_comm_graph);
+  bool replayed = false;
   if (graph_ok) {
     const int key[4] = {cur, ksub0, nsub, (waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)};
+    const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();
       hipGraph_t gph = nullptr;
-      const int cur0 = cur;
-      CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-      for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
-      CICE_HIP(hipStreamEndCapture(stream, &gph));
-      CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
-      CICE_HIP(hipGraphDestroy(gph));
-      std::memcpy(graph_key, key, sizeof(key));
+      bool capturing = false;
+      try {
+        CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        capturing = true;
+        for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+        capturing = false;
+        CICE_HIP(hipStreamEndCapture(stream, &gph));
+        CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
+        CICE_HIP(hipGraphDestroy(gph));
+        std::memcpy(graph_key, key, sizeof(key));
+      } catch (const Error&) {
+        // capture not possible here: close it, forget graphs for this context, run eagerly
+        if (capturing) (void)hipStreamEndCapture(stream, &gph);
+        if (gph) (void)hipGraphDestroy(gph);
+        (void)hipGetLastError();
+        drop_graph();
+        use_graph = false;
+      }
       cur = cur0;
     }
-    CICE_HIP(hipGraphLaunch(graph_exec, stream));
-    if (nsub & 1) cur = 1 - cur;
-  } else {
-    for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+    if (graph_exec) {
+      CICE_HIP(hipGraphLaunch(graph_exec, stream));
+      if (nsub & 1) cur = 1 - cur;
+      replayed = true;
+    }
   }
+  if (!replayed)
+    for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
   CICE_HIP(hipGetLastError());
   if (elapsed_ms) {
     CICE_HIP(hipEventRecord(e1, stream));

@@ -19,7 +19,7 @@ class Halo {
   ~Halo();
   void init(const Domain& d, hipStream_t s);
   void comm_init(const char uid[128], int rank, int nranks);
-  bool multi_rank() const { return nranks_ > 1; }
+  bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
   // nfields fields of element type T, field k starting at base + k*stride (elements)
   // local = false: only the off-rank part (the caller has written the on-rank ghosts itself)
   void update_r8(double* base, int nfields, size_t stride, bool local = true);
@@ -39,7 +39,7 @@ class Halo {
   void update(T* base, int nfields, size_t stride, bool local);
   hipStream_t stream_ = nullptr;
   int ncopy_ = 0, rank_ = 0, nranks_ = 1;
-  bool fwd_ok_ = true;
+  bool fwd_ok_ = true, remote_ = false;
   DevBuf<int32_t> src_, dst_, send_addr_, recv_addr_, ring_slot_, fwd_;
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;

@@ -118,6 +118,7 @@ void Halo::init(const Domain& d, hipStream_t s) {
   };
   int ts = flatten(d.send, send_peer_, send_off_, send_cnt_, send_addr_, nsend_);
   int tr = flatten(d.recv, recv_peer_, recv_off_, recv_cnt_, recv_addr_, nrecv_);
+  remote_ = nsend_ > 0 || nrecv_ > 0;
   sendbuf_.alloc((size_t)ts * MAXF);
   recvbuf_.alloc((size_t)tr * MAXF);
   CICE_HIP(hipStreamSynchronize(s));
@@ -142,7 +143,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool local) {
   CICE_REQUIRE(nfields >= 1 && nfields <= MAXF, "halo: too many fields in one update");
   const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
   const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
-  if (nranks_ > 1) {
+  if (remote_) {
     CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
     T* sb = reinterpret_cast<T*>(sendbuf_.p);
     T* rb = reinterpret_cast<T*>(recvbuf_.p);
@@ -166,7 +167,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool local) {
     hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, src_.p, dst_.p, ncopy_);
   }
-  if (nranks_ > 1 && total_r) {
+  if (remote_ && total_r) {
     const int* meta = reinterpret_cast<const int*>(recv_addr_.p + total_r);
     hipLaunchKernelGGL(k_unpack<T>, dim3((total_r + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, recv_addr_.p, total_r, reinterpret_cast<const T*>(recvbuf_.p), meta,

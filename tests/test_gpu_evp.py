@@ -356,3 +356,36 @@ def test_degenerate_inputs(ctx, orc, case):
         assert np.array_equal(sg[k], so[k]), (case, k)
     if case in ("no_ice", "all_land"):
         assert ctx.evp_active_cells() == (0, 0)
+
+
+def test_message_path_on_one_gpu(orc, monkeypatch):
+    """pack -> RCCL send/recv -> unpack (the off-rank halo path) exercised on a single GPU: with
+    CICE4_AMD_SELF_COMM the copies between different blocks of the rank are routed through
+    messages to the own rank (1-rank RCCL communicator).  Whole evp(dt) on 6 blocks, eager and
+    hipGraph-captured (RCCL calls inside the graph), must equal the checker bit for bit."""
+    monkeypatch.setenv("CICE4_AMD_SELF_COMM", "1")
+    c = lib.Context()
+    c.sync()
+    dom = c.domain_create(96, 70, 32, 35, ew=1, ns=0)
+    assert dom["nsend"] == 1 and dom["nsend_elems"] == dom["nrecv_elems"] > 0
+    c.comm_init(c.comm_unique_id(), 0, 1)
+    # the checker needs the plain on-rank list of the same decomposition
+    monkeypatch.delenv("CICE4_AMD_SELF_COMM")
+    dom_plain = lib.Context().domain_create(96, 70, 32, 35, ew=1, ns=0)
+    grid = synth.block_fields(synth.global_grid(96, 70, perturb=0.15, land_frac=0.05, seed=1), dom_plain)
+    s = synth.evp_state(grid, dom_plain, seed=1, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    so = {k: v.copy() for k, v in s.items()}
+    orc.evp(orc.make_domain(dom_plain, grid), so)
+    orc.set_strength_parameters()
+    for graph in (0, 1):
+        sg = {k: v.copy() for k, v in s.items()}
+        c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+        c.evp_set_option("use_graph", graph)
+        c.evp(DT, sg)
+        for k in EVP_OUT_FIELDS + ("iceumask",):
+            assert np.array_equal(sg[k], so[k]), (graph, k)
+    a = np.random.default_rng(0).uniform(0, 1, (2, dom["nblocks"], dom["ny"], dom["nx"]))
+    want = a.copy().reshape(2, -1); want[:, dom_plain["hdst"]] = want[:, dom_plain["hsrc"]]
+    c.halo_update(a)
+    assert np.array_equal(a.reshape(2, -1), want)
