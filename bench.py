@@ -46,6 +46,9 @@ def parse():
     p.add_argument("--waves", type=int, default=0, help="wavefronts per EVP workgroup (4/8/16); 0 = auto")
     p.add_argument("--rows", type=int, default=0, help="T-rows per wavefront (1/2/4/8); 0 = auto")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--overlap", type=int, default=-1,
+                   help="N > 1: overlap rows of the wide-halo slabs = subcycles between ghost exchanges "
+                        "(-1 = auto: 8, or a quarter of a rank's rows if that is smaller; 0 = exchange every subcycle)")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -75,11 +78,20 @@ def init_dist(n_gpus):
     return rank, world, local, dist
 
 
-def build_case(ctx, wl, rank, world):
+def build_case(ctx, wl, rank, world, overlap=-1):
     nxg, nyg, ndte, _ = WORKLOADS[wl]
     if nyg % world:
         raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
-    dom = ctx.domain_create(nxg, nyg, nxg, nyg // world, ew=1, ns=0, rank=rank, npx=1, npy=world)
+    if world == 1:
+        dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+        dom["overlap"] = 0
+    else:
+        rows = nyg // world
+        if overlap < 0:
+            overlap = min(8, max(1, rows // 4))
+        # j-slabs, one per GPU, each extended by `overlap` rows that are recomputed and refreshed
+        # only every `overlap` subcycles
+        dom = ctx.domain_create_slabs(nxg, nyg, world, ew=1, ns=0, rank=rank, nranks=world, overlap=overlap)
     gg = synth.global_grid(nxg, nyg)          # uniform 30 km rectangular grid (ice_grid.F90:976)
     grid = synth.block_fields(gg, dom)
     state = synth.evp_state(grid, dom, cover="full")
@@ -256,7 +268,7 @@ def main():
         ms = ctx.diag_stream_copy(nd)
         calib = {"kernel": "k_diag_copy8", "bytes_read": nd * 8, "bytes_written": nd * 8, "ms": ms,
                  "GBps": 2 * nd * 8 / (ms * 1e-3) / 1e9}
-    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world)
+    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world, args.overlap)
     if world > 1:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -362,7 +374,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": WORKLOADS[args.workload][3], "nx_global": dom["nxg"],
                        "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
-                       "decomposition": f"1x{world} j-slabs, one block per GPU", "tile": tile,
+                       "decomposition": f"1x{world} j-slabs, one block per GPU" + (
+                           f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
+                           f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
+                       "tile": tile,
                        "metrics_recomputed_from_HTN_HTE": derive,
                        "active_T_cells": nt_all, "active_U_cells": nu_all,
                        "cell_subcycles_per_s": value * nt_all},

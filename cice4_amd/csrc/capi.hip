@@ -183,6 +183,30 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   CICE_CATCH
 }
 
+int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int ew, int ns, int rank,
+                             int nranks, int overlap) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 2, "boundary type must be 0 (open), 1 (cyclic) or 2 (closed)");
+  c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;
+  const char* msg = c_->dom.create_slabs(nxg, nyg, nblocks_y, ew, ns, rank, nranks, overlap);
+  if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_slabs: ") + msg};
+  c_->have_domain = true;
+  c_->evp.reset();
+  c_->halo.reset();
+  CICE_CATCH
+}
+
+int cice_domain_halo_refresh(const cice_ctx* ctx, int* n, int32_t* src, int32_t* dst) {
+  if (!ctx || !ctx->have_domain || !n) return CICE_EINVAL;
+  const Domain& d = ctx->dom;
+  *n = (int)d.rsrc.size();
+  if (src && dst && !d.rsrc.empty()) {
+    std::memcpy(src, d.rsrc.data(), d.rsrc.size() * 4);
+    std::memcpy(dst, d.rdst.data(), d.rdst.size() * 4);
+  }
+  return CICE_OK;
+}
+
 int cice_domain_info(const cice_ctx* ctx, int info[9]) {
   if (!ctx || !info || !ctx->have_domain) return CICE_EINVAL;
   const Domain& d = ctx->dom;
@@ -195,10 +219,10 @@ int cice_domain_info(const cice_ctx* ctx, int info[9]) {
   return CICE_OK;
 }
 
-int cice_domain_block(const cice_ctx* ctx, int lb, int info[8]) {
+int cice_domain_block(const cice_ctx* ctx, int lb, int info[10]) {
   if (!ctx || !info || !ctx->have_domain || lb < 0 || lb >= ctx->dom.nblocks()) return CICE_EINVAL;
   const Block& b = ctx->dom.all[ctx->dom.local[lb]];
-  const int v[8] = {b.ilo, b.ihi, b.jlo, b.jhi, b.i0, b.j0, b.gid, b.owner};
+  const int v[10] = {b.ilo, b.ihi, b.jlo, b.jhi, b.i0, b.j0, b.gid, b.owner, b.own_jlo, b.own_jhi};
   std::memcpy(info, v, sizeof(v));
   return CICE_OK;
 }
@@ -462,7 +486,7 @@ int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
   if (c_->have_domain && c_->dom.nblocks() == nb && c_->dom.nx_block == nx && c_->dom.ny_block == ny) {
     for (int gid : c_->dom.local) {
       const Block& b = c_->dom.all[gid];
-      hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi});
+      hb.insert(hb.end(), {b.ilo, b.ihi, b.own_jlo, b.own_jhi});  // owned rows only
     }
   } else {
     for (int b = 0; b < nb; ++b) hb.insert(hb.end(), {2, nx - 1, 2, ny - 1});

@@ -30,6 +30,7 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
   if (rank < 0 || rank >= nranks) return "rank out of range";
   if (npx > nbx || npy > nby) return "more ranks than blocks along an axis";
   all.clear(); local.clear(); hsrc.clear(); hdst.clear(); send.clear(); recv.clear();
+  rsrc.clear(); rdst.clear(); overlap = 0;
 
   std::vector<int> nlocal(nranks, 0);
   for (int jb = 0; jb < nby; ++jb)
@@ -44,6 +45,7 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
       int px = (int)((long long)ib * npx / nbx), py = (int)((long long)jb * npy / nby);
       b.owner = py * npx + px;
       b.local_id = nlocal[b.owner]++;
+      b.own_jlo = b.jlo; b.own_jhi = b.jhi;
       all.push_back(b);
     }
   for (const Block& b : all)
@@ -85,6 +87,79 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
         }
       }
   }
+  for (auto& kv : smap) send.push_back(std::move(kv.second));
+  for (auto& kv : rmap) recv.push_back(std::move(kv.second));
+  return "";
+}
+
+const char* Domain::create_slabs(int nx_global, int ny_global, int nblocks_y, int ew_bnd, int ns_bnd,
+                                 int rank_, int nranks_, int overlap_rows) {
+  if (nx_global < 1 || ny_global < 1) return "domain size < 1";
+  if (nblocks_y < 1 || nranks_ < 1 || nblocks_y % nranks_) return "nblocks_y must be a positive multiple of nranks";
+  if (ny_global % nblocks_y) return "ny_global must be divisible by nblocks_y";
+  if (rank_ < 0 || rank_ >= nranks_) return "rank out of range";
+  if (overlap_rows < 0) return "overlap < 0";
+  if (ns_bnd == BND_CYCLIC) return "cyclic north-south boundary is not supported with slabs";
+  nxg = nx_global; nyg = ny_global; bsx = nxg; bsy = nyg / nblocks_y;
+  if (overlap_rows > bsy) return "overlap larger than a slab";
+  overlap = overlap_rows;
+  nx_block = bsx + 2; ny_block = bsy + 2 * overlap + 2;
+  nbx = 1; nby = nblocks_y; npx = 1; npy = nranks_; nranks = nranks_; rank = rank_;
+  ew = ew_bnd; ns = ns_bnd;
+  all.clear(); local.clear(); hsrc.clear(); hdst.clear(); send.clear(); recv.clear();
+  rsrc.clear(); rdst.clear();
+  const int per_rank = nby / nranks;
+  std::vector<int> e0(nby);
+  for (int jb = 0; jb < nby; ++jb) {
+    Block b;
+    b.gid = jb; b.ib = 0; b.jb = jb;
+    const int o0 = jb * bsy, o1 = o0 + bsy - 1;
+    e0[jb] = std::max(0, o0 - overlap);
+    const int e1 = std::min(nyg - 1, o1 + overlap);
+    b.i0 = 0; b.j0 = e0[jb];
+    b.ilo = 2; b.ihi = 1 + bsx; b.jlo = 2; b.jhi = 1 + (e1 - e0[jb] + 1);
+    b.own_jlo = b.jlo + (o0 - e0[jb]); b.own_jhi = b.jlo + (o1 - e0[jb]);
+    b.owner = jb / per_rank; b.local_id = jb % per_rank;
+    all.push_back(b);
+    if (b.owner == rank) local.push_back(b.gid);
+  }
+  const long long np = (long long)nx_block * ny_block;
+  if (np * (long long)local.size() > 0x7fffffffLL) return "local array too large for int32 addressing";
+  auto addr = [&](const Block& b, int i, int j) {
+    return (int32_t)((long long)b.local_id * np + (long long)(j - 1) * nx_block + (i - 1));
+  };
+  // E-W wrap of every physical row (every subcycle; folded into the producing kernel)
+  if (ew == BND_CYCLIC)
+    for (int gid : local) {
+      const Block& b = all[gid];
+      for (int j = b.jlo; j <= b.jhi; ++j) {
+        hsrc.push_back(addr(b, b.ihi, j)); hdst.push_back(addr(b, b.ilo - 1, j));
+        hsrc.push_back(addr(b, b.ilo, j)); hdst.push_back(addr(b, b.ihi + 1, j));
+      }
+    }
+  // refresh: every row outside the owned range (overlap rows and the two ghost rows), whole
+  // rows including the E/W ghost columns, from the block that owns that global row
+  std::map<int, HaloMsg> smap, rmap;
+  for (const Block& d : all)
+    for (int j = d.jlo - 1; j <= d.jhi + 1; ++j) {
+      if (j >= d.own_jlo && j <= d.own_jhi) continue;
+      const int jg = d.j0 + (j - d.jlo);
+      if (jg < 0 || jg >= nyg) continue;  // beyond the open/closed edge: never written
+      const Block& s = all[jg / bsy];
+      const int js = s.jlo + (jg - s.j0);
+      for (int i = 1; i <= nx_block; ++i) {
+        if (d.owner == rank && s.owner == rank && !self_comm) {
+          rsrc.push_back(addr(s, i, js)); rdst.push_back(addr(d, i, j));
+        } else if (d.owner == rank && s.owner == rank) {
+          HaloMsg& mr = rmap[rank]; mr.peer = rank; mr.addr.push_back(addr(d, i, j));
+          HaloMsg& ms = smap[rank]; ms.peer = rank; ms.addr.push_back(addr(s, i, js));
+        } else if (d.owner == rank) {
+          HaloMsg& m = rmap[s.owner]; m.peer = s.owner; m.addr.push_back(addr(d, i, j));
+        } else if (s.owner == rank) {
+          HaloMsg& m = smap[d.owner]; m.peer = d.owner; m.addr.push_back(addr(s, i, js));
+        }
+      }
+    }
   for (auto& kv : smap) send.push_back(std::move(kv.second));
   for (auto& kv : rmap) recv.push_back(std::move(kv.second));
   return "";

@@ -20,6 +20,7 @@ struct Block {
   int i0, j0;              // 0-based global index of local cell (ilo), (jlo)
   int owner;               // rank
   int local_id;            // position among the owner's blocks
+  int own_jlo, own_jhi;    // rows this block owns (== jlo..jhi unless the domain has overlap rows)
 };
 
 struct HaloMsg {
@@ -39,11 +40,22 @@ struct Domain {
   std::vector<int> local;            // gids of this rank's blocks, ascending
   std::vector<int32_t> hsrc, hdst;   // on-rank ghost copies: a[hdst[n]] = a[hsrc[n]]
   std::vector<HaloMsg> send, recv;   // per peer, ascending peer; element order agrees on both ends
+  // Wide-halo ("overlap") mode, create_slabs(): every block is a j-slab extended by `overlap`
+  // rows into its neighbours; the extension rows are recomputed redundantly and refreshed from
+  // their owner only every `overlap` subcycles.  Then hsrc/hdst hold only the E-W wrap (needed
+  // every subcycle), rsrc/rdst the on-rank part of the refresh, send/recv its off-rank part.
+  int overlap = 0;
+  std::vector<int32_t> rsrc, rdst;
 
   int nblocks() const { return (int)local.size(); }
   // Returns empty string on success, else an error message.
   const char* create(int nx_global, int ny_global, int block_size_x, int block_size_y, int ew_bnd,
                      int ns_bnd, int rank_, int npx_, int npy_);
+  // nblocks_y j-slabs of full width dealt to nranks ranks (contiguous runs), each extended by
+  // overlap_rows rows on both sides (clipped at the domain edge).  overlap_rows = 0 gives the
+  // same blocks as create(nx, ny, nx, ny/nblocks_y, ...).
+  const char* create_slabs(int nx_global, int ny_global, int nblocks_y, int ew_bnd, int ns_bnd,
+                           int rank_, int nranks_, int overlap_rows);
 };
 
 }  // namespace cice

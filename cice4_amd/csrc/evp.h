@@ -66,8 +66,9 @@ class Evp {
   DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,
       ss_tlty;
   // io (u, v, sigma double-buffered)
-  DevBuf<double> uv[2];    // [2*n]: u then v
-  DevBuf<double> sig[2];   // [12*n]
+  DevBuf<double> st[2];                  // [14*n]: u, v, 12 stresses
+  struct View { double* p = nullptr; };
+  View uv[2], sig[2];                    // views into st[k]: u at 0, v at n, stresses at 2n
   DevBuf<int32_t> iceumask;
   DevBuf<double> fm, strtltx, strtlty, strocnx, strocny, strintx, strinty;
   // out

@@ -293,8 +293,8 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
   const int b = tile_lin / per_blk;
   const int rem = tile_lin - b * per_blk;
   const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
-  const int ilo = a.blk[4 * b + 0], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2],
-            jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b + 0], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2],
+            jhi = a.blk[6 * b + 3];
   const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (TROWS - 1);  // 1-based
   const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nx = a.nx;
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void k_prep1(const PrepArgs a) {
   a.tmass[t] = a.tmask[t] ? (rhoi * a.vice[t] + rhos * a.vsno[t]) : c0;
   a.strairx[t] = a.strairxT[t];
   a.strairy[t] = a.strairyT[t];
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   int m = 0;
   if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.tmask[t]) {
     bool any = false;
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(256) void k_to_ugrid2(const PrepArgs a, const doubl
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
   if (!cell_of(a, t, b, i, j)) return;
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   double r1 = c0, r2 = c0;
   if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) {
     const size_t e = t + 1, n = t + a.nx, ne = t + a.nx + 1;
@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void k_to_tgrid2(const PrepArgs a, const doubl
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
   if (!cell_of(a, t, b, i, j)) return;
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   if (i >= ilo && i <= ihi && j >= jlo && j <= jhi) {
     const size_t w = t - 1, s = t - a.nx, sw = t - a.nx - 1;
     const double ua = a.uarea[t], ub = a.uarea[w], uc = a.uarea[s], ud = a.uarea[sw], ta = a.tarea[t];
@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void k_prep2(const PrepArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
   if (!cell_of(a, t, b, i, j)) return;
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   double wx = c0, wy = c0, fx = c0, fy = c0, umd = c0;
   if (a.icetmask[t] == 0) {
 #pragma unroll
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(256) void k_strength(const PrepArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
   if (!cell_of(a, t, b, i, j)) return;
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   double st = c0;
   const bool phys = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
   if (a.kstrength != 1) {
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_finish(const PrepArgs a) {
   int b, i, j;
   if (!cell_of(a, t, b, i, j)) return;
   double xT = c0, yT = c0;
-  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.iceumask[t]) {  // the indxu list
     const double du = a.uocn[t] - a.u[t], dv = a.vocn[t] - a.v[t];
     const double vrel = dragw * sqrt(du * du + dv * dv);
@@ -737,9 +737,12 @@ __global__ __launch_bounds__(256) void k_count_active(const PrepArgs a) {
   int b, i, j;
   unsigned long long nt = 0, nu = 0;
   if (cell_of(a, t, b, i, j)) {
-    const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
-    if (i >= ilo && i <= ihi + 1 && j >= jlo && j <= jhi + 1 && a.icetmask[t] == 1) nt = 1;
-    if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.iceumask[t]) nu = 1;
+    const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
+    // rows this block owns (a wide-halo domain recomputes its overlap rows; they are not counted)
+    const int ojlo = a.blk[6 * b + 4], ojhi = a.blk[6 * b + 5];
+    const int tjhi = ojhi + (ojhi == jhi ? 1 : 0);
+    if (i >= ilo && i <= ihi + 1 && j >= ojlo && j <= tjhi && a.icetmask[t] == 1) nt = 1;
+    if (i >= ilo && i <= ihi && j >= ojlo && j <= ojhi && a.iceumask[t]) nu = 1;
   }
   for (int off = 32; off > 0; off >>= 1) {
     nt += __shfl_down(nt, off);
@@ -789,7 +792,7 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   std::vector<int32_t> hb;
   for (int gid : dom.local) {
     const Block& b = dom.all[gid];
-    hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi});
+    hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi, b.own_jlo, b.own_jhi});
   }
   blk.alloc(hb.size());
   blk.upload(hb.data(), stream);
@@ -845,8 +848,9 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   aicen.alloc(NCAT * n); aicen.zero(stream);
   vicen.alloc(NCAT * n); vicen.zero(stream);
   for (int k = 0; k < 2; ++k) {  // init_evp :487-520: velocities, stresses = 0, iceumask = F
-    uv[k].alloc(2 * n); uv[k].zero(stream);
-    sig[k].alloc(12 * n); sig[k].zero(stream);
+    st[k].alloc(14 * n); st[k].zero(stream);   // u, v, 12 stresses contiguous: one halo message
+    uv[k].p = st[k].p;
+    sig[k].p = st[k].p + 2 * n;
   }
   iceumask.alloc(n); iceumask.zero(stream);
   icetmask.alloc(n); icetmask.zero(stream);
@@ -855,7 +859,7 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   // and are latency-bound -> many small workgroups, one row per wavefront; large grids are
   // bandwidth-bound -> two rows per wavefront (fewer redundant overlap rows, same occupancy).
   {
-    const long long cells = (long long)dom.nblocks() * dom.bsx * dom.bsy;
+    const long long cells = (long long)dom.nblocks() * (dom.nx_block - 2) * (dom.ny_block - 2);
     waves = 4;
     rows_per_wave = cells <= 400LL * 400LL ? 1 : 2;
   }
@@ -949,11 +953,11 @@ void Evp::prepare(double dt) {
   hipLaunchKernelGGL(k_prep2, g, blk256, 0, stream, a);                       // :280-316
   hipLaunchKernelGGL(k_strength, g, blk256, 0, stream, a);                    // :322-332
   halo.update_r8(strength.p, 1, n);                                           // :337
-  halo.update_r8(uv[cur].p, 2, n);                                            // :340-343
+  if (dom.overlap > 0) halo.update_r8(st[cur].p, 14, n);   // overlap rows of u, v AND sigma from their owners
+  else halo.update_r8(uv[cur].p, 2, n);                                       // :340-343
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
-  CICE_HIP(hipMemcpyAsync(uv[1 - cur].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
-  CICE_HIP(hipMemcpyAsync(sig[1 - cur].p, sig[cur].p, 12 * n * 8, hipMemcpyDeviceToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
   counters.zero(stream);
   hipLaunchKernelGGL(k_count_active, g, blk256, 0, stream, a);
   CICE_HIP(hipGetLastError());
@@ -993,8 +997,9 @@ void Evp::launch_subcycle(int ksub) {
   SubArgs a{};
   a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.n = n; a.nblocks = dom.nblocks();
   const int trows = waves * rows_per_wave;
-  a.tiles_x = (dom.bsx + (TX - 1) - 1) / (TX - 1);
-  a.tiles_y = (dom.bsy + (trows - 1) - 1) / (trows - 1);
+  // physical extent of a block (a wide-halo slab is bsy + 2*overlap rows tall)
+  a.tiles_x = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+  a.tiles_y = ((dom.ny_block - 2) + (trows - 1) - 1) / (trows - 1);
   const bool fwd = halo.fwd_ok();
   a.ring_slot = fwd ? halo.d_ring_slot() : nullptr; a.fwd = halo.d_fwd();
   a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
@@ -1026,8 +1031,16 @@ void Evp::launch_subcycle(int ksub) {
     default: throw Error{CICE_EINVAL, "unsupported (waves, rows_per_wave) combination"};
   }
   cur = 1 - cur;
-  // on-rank ghost cells were written by the kernel itself; other ranks' rows travel by RCCL
-  if (halo.multi_rank() || !fwd) halo.update_r8(uv[cur].p, 2, n, /*local=*/!fwd);  // :397-402
+  // On-rank ghost cells were written by the kernel itself.  Rows owned by other blocks/ranks:
+  // classic domain -> every subcycle (:397-402); wide-halo domain -> u, v and sigma every
+  // `overlap` subcycles and after the last one (the overlap rows are recomputed in between and
+  // lose one valid row per side per subcycle).
+  if (dom.overlap > 0) {
+    if (ksub % dom.overlap == 0 || ksub == sc.ndte) halo.update_r8(st[cur].p, 14, n, /*wrap=*/!fwd);
+    else if (!fwd) halo.update_r8(uv[cur].p, 2, n, true);
+  } else if (halo.has_refresh() || !fwd) {
+    halo.update_r8(uv[cur].p, 2, n, /*wrap=*/!fwd);
+  }
 }
 
 void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {

@@ -20,9 +20,12 @@ class Halo {
   void init(const Domain& d, hipStream_t s);
   void comm_init(const char uid[128], int rank, int nranks);
   bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
-  // nfields fields of element type T, field k starting at base + k*stride (elements)
-  // local = false: only the off-rank part (the caller has written the on-rank ghosts itself)
-  void update_r8(double* base, int nfields, size_t stride, bool local = true);
+  bool has_refresh() const { return remote_ || nrefresh_ > 0; }
+  // nfields fields of element type T, field k starting at base + k*stride (elements).
+  // Always performs the refresh part (on-rank block-to-block rows of a wide-halo domain and all
+  // off-rank messages); wrap = false skips the every-subcycle on-rank list (hsrc/hdst) because
+  // the caller -- the subcycle kernel -- has written those ghosts itself.
+  void update_r8(double* base, int nfields, size_t stride, bool wrap = true);
   void update_i4(int32_t* base, int nfields, size_t stride);
   // Device pointers to the on-rank copy list, for kernels that fold it in.
   const int32_t* d_src() const { return src_.p; }
@@ -36,16 +39,16 @@ class Halo {
 
  private:
   template <class T>
-  void update(T* base, int nfields, size_t stride, bool local);
+  void update(T* base, int nfields, size_t stride, bool wrap);
   hipStream_t stream_ = nullptr;
-  int ncopy_ = 0, rank_ = 0, nranks_ = 1;
+  int ncopy_ = 0, nrefresh_ = 0, rank_ = 0, nranks_ = 1;
   bool fwd_ok_ = true, remote_ = false;
-  DevBuf<int32_t> src_, dst_, send_addr_, recv_addr_, ring_slot_, fwd_;
+  DevBuf<int32_t> src_, dst_, rsrc_, rdst_, send_addr_, recv_addr_, ring_slot_, fwd_;
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;
   DevBuf<double> sendbuf_, recvbuf_;  // sized for MAXF fields of 8-byte elements
   ncclComm* comm_ = nullptr;
-  static constexpr int MAXF = 4;
+  static constexpr int MAXF = 14;  // u, v and the 12 stresses in one message
 };
 
 }  // namespace cice

@@ -71,6 +71,13 @@ void Halo::init(const Domain& d, hipStream_t s) {
     src_.upload(d.hsrc.data(), s);
     dst_.upload(d.hdst.data(), s);
   }
+  nrefresh_ = (int)d.rsrc.size();
+  rsrc_.alloc(nrefresh_);
+  rdst_.alloc(nrefresh_);
+  if (nrefresh_) {
+    rsrc_.upload(d.rsrc.data(), s);
+    rdst_.upload(d.rdst.data(), s);
+  }
   {  // forwarding form: source cell -> the (at most 3: edge, edge, corner) ghosts mirroring it
     const size_t n = (size_t)d.nblocks() * d.nx_block * d.ny_block;
     std::vector<int32_t> slot(n, -1), fwd;
@@ -139,10 +146,17 @@ void Halo::comm_init(const char uid[128], int rank, int nranks) {
 }
 
 template <class T>
-void Halo::update(T* base, int nfields, size_t stride, bool local) {
+void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
   CICE_REQUIRE(nfields >= 1 && nfields <= MAXF, "halo: too many fields in one update");
   const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
   const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
+  // The wrap list goes first: a wide-halo refresh copies whole rows INCLUDING their E/W ghost
+  // columns, so the owner's ghost columns must be current before they are packed or copied.
+  if (ncopy_ && wrap) {
+    int t = ncopy_ * nfields;
+    hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
+                       stride, src_.p, dst_.p, ncopy_);
+  }
   if (remote_) {
     CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
     T* sb = reinterpret_cast<T*>(sendbuf_.p);
@@ -162,10 +176,10 @@ void Halo::update(T* base, int nfields, size_t stride, bool local) {
                          send_peer_[m], (ncclComm_t)comm_, stream_));
     CICE_NCCL(ncclGroupEnd());
   }
-  if (ncopy_ && local) {
-    int t = ncopy_ * nfields;
+  if (nrefresh_) {  // sources are owned rows, destinations overlap/ghost rows: disjoint from the wrap list's sources
+    int t = nrefresh_ * nfields;
     hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
-                       stride, src_.p, dst_.p, ncopy_);
+                       stride, rsrc_.p, rdst_.p, nrefresh_);
   }
   if (remote_ && total_r) {
     const int* meta = reinterpret_cast<const int*>(recv_addr_.p + total_r);
@@ -176,7 +190,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool local) {
   CICE_HIP(hipGetLastError());
 }
 
-void Halo::update_r8(double* base, int nfields, size_t stride, bool local) { update<double>(base, nfields, stride, local); }
+void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap) { update<double>(base, nfields, stride, wrap); }
 void Halo::update_i4(int32_t* base, int nfields, size_t stride) { update<int32_t>(base, nfields, stride, true); }
 
 }  // namespace cice

@@ -154,12 +154,23 @@ class Context:
                           nxg=nxg, nyg=nyg)
         return self.domain()
 
+    def domain_create_slabs(self, nxg, nyg, nblocks_y, ew=1, ns=0, rank=0, nranks=1, overlap=0):
+        """j-slabs of full width, optionally extended by `overlap` rows (wide halo)."""
+        self._ck(self.lib.cice_domain_create_slabs(self.h, nxg, nyg, nblocks_y, ew, ns, rank, nranks, overlap))
+        info = (C.c_int * 9)()
+        self._ck(self.lib.cice_domain_info(self.h, info))
+        self.nx, self.ny, self.nblocks = info[0], info[1], info[2]
+        self.dinfo = dict(nx=info[0], ny=info[1], nblocks=info[2], nblocks_tot=info[3], ncopy=info[4],
+                          nsend=info[5], nrecv=info[6], nsend_elems=info[7], nrecv_elems=info[8],
+                          nxg=nxg, nyg=nyg, overlap=overlap)
+        return self.domain()
+
     def domain(self):
         """dict describing the local blocks + on-rank halo list (host logic, no GPU needed)."""
         d = dict(self.dinfo)
-        cols = {k: [] for k in ("ilo", "ihi", "jlo", "jhi", "i0", "j0", "gid", "owner")}
+        cols = {k: [] for k in ("ilo", "ihi", "jlo", "jhi", "i0", "j0", "gid", "owner", "own_jlo", "own_jhi")}
         for b in range(self.nblocks):
-            info = (C.c_int * 8)()
+            info = (C.c_int * 10)()
             self._ck(self.lib.cice_domain_block(self.h, b, info))
             for k, v in zip(cols, info):
                 cols[k].append(v)
@@ -168,6 +179,12 @@ class Context:
         if d["ncopy"]:
             self._ck(self.lib.cice_domain_halo_local(self.h, _i4(src), _i4(dst)))
         d["hsrc"], d["hdst"] = src, dst
+        nr = C.c_int(0)
+        self._ck(self.lib.cice_domain_halo_refresh(self.h, C.byref(nr), None, None))
+        rs = np.zeros(nr.value, np.int32); rd = np.zeros(nr.value, np.int32)
+        if nr.value:
+            self._ck(self.lib.cice_domain_halo_refresh(self.h, C.byref(nr), _i4(rs), _i4(rd)))
+        d["rsrc"], d["rdst"] = rs, rd
         return d
 
     def halo_msgs(self, direction):

@@ -59,12 +59,24 @@ int cice_diag_stream_copy(cice_ctx *ctx, long long n_doubles, float *elapsed_ms)
 int cice_domain_create(cice_ctx *ctx, int nx_global, int ny_global, int block_size_x,
                        int block_size_y, int ew_boundary, int ns_boundary, int rank, int npx,
                        int npy);
+/* Wide-halo variant for j-slab decompositions (strong scaling over GPUs): nblocks_y slabs of
+ * full width dealt to nranks ranks in contiguous runs; every slab is extended by `overlap`
+ * rows into its neighbours.  The overlap rows are recomputed redundantly by the subcycle kernel
+ * and refreshed from their owner (u, v and the 12 stresses in ONE message per neighbour) only
+ * every `overlap` subcycles instead of after every subcycle: results on the owned rows are
+ * bit-identical, the number of exchanges drops by that factor.  Host arrays then describe the
+ * EXTENDED blocks (cice_domain_block gives the owned rows).  overlap = 0: plain slabs. */
+int cice_domain_create_slabs(cice_ctx *ctx, int nx_global, int ny_global, int nblocks_y,
+                             int ew_boundary, int ns_boundary, int rank, int nranks, int overlap);
 /* info: nx_block, ny_block, nblocks(local), nblocks_tot, n_local_copies, n_send_msgs,
  *       n_recv_msgs, n_send_elems, n_recv_elems */
 int cice_domain_info(const cice_ctx *ctx, int info[9]);
 /* info: ilo, ihi, jlo, jhi (1-based, = type block, source/ice_blocks.F90:32-45),
- *       i0, j0 (0-based global index of cell ilo/jlo), global block id, owner rank */
-int cice_domain_block(const cice_ctx *ctx, int local_block, int info[8]);
+ *       i0, j0 (0-based global index of cell ilo/jlo), global block id, owner rank,
+ *       own_jlo, own_jhi (rows owned by the block; = jlo, jhi without overlap) */
+int cice_domain_block(const cice_ctx *ctx, int local_block, int info[10]);
+/* on-rank part of the wide-halo refresh (empty without overlap): n pairs */
+int cice_domain_halo_refresh(const cice_ctx *ctx, int *n, int32_t *src, int32_t *dst);
 /* on-rank halo copy list (0-based linear addresses into the (nx_block,ny_block,nblocks)
  * array): a[dst[n]] = a[src[n]]; = srcLocalAddr/dstLocalAddr of serial/ice_boundary.F90:49-62 */
 int cice_domain_halo_local(const cice_ctx *ctx, int32_t *src, int32_t *dst);

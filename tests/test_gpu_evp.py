@@ -389,3 +389,51 @@ def test_message_path_on_one_gpu(orc, monkeypatch):
     want = a.copy().reshape(2, -1); want[:, dom_plain["hdst"]] = want[:, dom_plain["hsrc"]]
     c.halo_update(a)
     assert np.array_equal(a.reshape(2, -1), want)
+
+
+def _owned(dom, f):
+    """global physical field from the OWNED rows of (possibly overlapping) slab blocks"""
+    g = np.zeros((dom["nyg"], dom["nxg"]))
+    for b in range(dom["nblocks"]):
+        r0 = dom["j0"][b] + (dom["own_jlo"][b] - dom["jlo"][b])
+        nr = dom["own_jhi"][b] - dom["own_jlo"][b] + 1
+        g[r0:r0 + nr, :] = f[b, dom["own_jlo"][b] - 1:dom["own_jhi"][b], dom["ilo"][b] - 1:dom["ihi"][b]]
+    return g
+
+
+@pytest.mark.parametrize("overlap,selfcomm", [(0, False), (1, False), (4, False), (7, False), (4, True), (7, True)])
+def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm):
+    """Wide-halo j-slabs: the overlap rows are recomputed and refreshed (u, v, 12 sigma in one
+    message) only every `overlap` subcycles.  Owned rows must equal the single-domain checker run
+    bit for bit; with CICE4_AMD_SELF_COMM the refresh goes through pack/RCCL/unpack."""
+    nxg, nyg, nb = 96, 72, 4
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    if selfcomm:
+        monkeypatch.setenv("CICE4_AMD_SELF_COMM", "1")
+    c = lib.Context(); c.sync()
+    dom = c.domain_create_slabs(nxg, nyg, nb, ew=1, ns=0, overlap=overlap)
+    if selfcomm:
+        assert dom["nsend"] == 1
+        c.comm_init(c.comm_unique_id(), 0, 1)
+    grid = synth.block_fields(gg, dom)
+    s = synth.evp_state(grid, dom, seed=31, cover="patchy")
+    c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    c.evp(DT, s)
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
+        assert np.array_equal(_owned(dom, s[k]), _owned(one, s1[k])), (overlap, selfcomm, k)
+    nt, nu = c.evp_active_cells()
+    c1.evp_init(grid1, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    s1b = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    c1.evp_upload(s1b); c1.evp_prepare(DT)
+    nt1, nu1 = c1.evp_active_cells()
+    assert nu == nu1                                # overlap rows are not counted twice
+    assert nt1 <= nt <= nt1 + nb * (nxg + 2)        # T lists: each block also lists its N/E ghost ring
