@@ -49,6 +49,9 @@ def parse():
     p.add_argument("--overlap", type=int, default=-1,
                    help="N > 1: overlap rows of the wide-halo slabs = subcycles between ghost exchanges "
                         "(-1 = auto: 8, or a quarter of a rank's rows if that is smaller; 0 = exchange every subcycle)")
+    p.add_argument("--slabs", type=int, default=0,
+                   help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
+                        "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -78,17 +81,34 @@ def init_dist(n_gpus):
     return rank, world, local, dist
 
 
-def build_case(ctx, wl, rank, world, overlap=-1):
+def auto_overlap(nxg, rows):
+    """Rows of overlap = subcycles between ghost exchanges.  Redundant work grows like
+    2H/rows x t_kernel, exchange cost falls like t_comm/H (t_comm ~ 12 us measured through
+    pack + RCCL p2p + unpack); small slabs are latency-bound, so extra rows cost them nothing."""
+    t_kernel = nxg * rows * 62e-6            # us, from 537 us per 8.63 M cells
+    if nxg * rows <= 200 * 200:
+        return max(1, min(12, rows // 4))
+    return max(1, min(rows // 4, int(round((12.0 * rows / (2.0 * t_kernel)) ** 0.5))))
+
+
+def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
     nxg, nyg, ndte, _ = WORKLOADS[wl]
     if nyg % world:
         raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
-    if world == 1:
+    if world == 1 and slabs > 1:
+        rows = nyg // slabs
+        if overlap < 0:
+            overlap = auto_overlap(nxg, rows)
+        dom = ctx.domain_create_slabs(nxg, nyg, slabs, ew=1, ns=0, rank=0, nranks=1, overlap=overlap)
+        if dom["nsend"]:
+            ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    elif world == 1:
         dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
         dom["overlap"] = 0
     else:
         rows = nyg // world
         if overlap < 0:
-            overlap = min(8, max(1, rows // 4))
+            overlap = auto_overlap(nxg, rows)
         # j-slabs, one per GPU, each extended by `overlap` rows that are recomputed and refreshed
         # only every `overlap` subcycles (DESIGN.md section 7)
         dom = ctx.domain_create_slabs(nxg, nyg, world, ew=1, ns=0, rank=rank, nranks=world, overlap=overlap)
@@ -268,7 +288,7 @@ def main():
         ms = ctx.diag_stream_copy(nd)
         calib = {"kernel": "k_diag_copy8", "bytes_read": nd * 8, "bytes_written": nd * 8, "ms": ms,
                  "GBps": 2 * nd * 8 / (ms * 1e-3) / 1e9}
-    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world, args.overlap)
+    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world, args.overlap, args.slabs)
     if world > 1:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
