@@ -66,6 +66,24 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          integer(c_int), intent(out) :: info(9)
       end function
+      integer(c_int) function cice_domain_block(ctx, local_block, info) bind(C, name='cice_domain_block')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: local_block
+         integer(c_int), intent(out) :: info(10)
+      end function
+      integer(c_int) function cice_halo_update_r8(ctx, field, nlev) bind(C, name='cice_halo_update_r8')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double) :: field(*)
+         integer(c_int), value :: nlev
+      end function
+      integer(c_int) function cice_halo_update_i4(ctx, field, nlev) bind(C, name='cice_halo_update_i4')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int) :: field(*)
+         integer(c_int), value :: nlev
+      end function
       integer(c_int) function cice_comm_unique_id(uid) bind(C, name='cice_comm_unique_id')
          import
          character(kind=c_char), intent(out) :: uid(128)

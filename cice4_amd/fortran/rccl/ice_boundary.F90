@@ -1,0 +1,395 @@
+!=======================================================================
+! Drop-in replacement for the reference's boundary module (same module name and public
+! entities as serial/ice_boundary.F90 and mpi/ice_boundary.F90: type ice_halo,
+! ice_HaloCreate, the generic ice_HaloUpdate for 2-d/3-d/4-d R8/R4/I4 fields and
+! ice_HaloExtrapolate), selected at link time like the reference's serial/ and mpi/
+! variants.  Ghost cells are filled on the MI355X through libcice4_amd.so: on-rank copies
+! by the halo kernel, off-rank rows by grouped RCCL send/recv over xGMI
+! (include/cice4_amd.h: cice_domain_create, cice_halo_update_r8/i4).
+!
+! Scope: ghost width 1, cyclic / open / closed edges, cartesian block distribution without
+! land-block elimination (SURVEY.md section 8f).  Tripole grids stop with a message.
+! Ghost cells beyond an open or closed edge are left untouched, which is what the reference
+! does for them (mpi/ice_boundary.F90: messages to a non-existent neighbour are never
+! created), so the fillValue / fieldLoc / fieldKind arguments have no effect here.
+!
+! This generic entry point moves the host field to the device and back on every call: it
+! is the functional drop-in for the model's set-up and state updates (ice_grid.F90,
+! ice_state.F90:bound_state).  The dynamics do NOT come through here -- the EVP module
+! keeps its fields on the device and updates their ghost cells inside its kernels.
+!=======================================================================
+module ice_boundary
+
+   use iso_c_binding
+   use ice_kinds_mod
+   use ice_communicate, only: my_task
+   use ice_fileunits, only: nu_diag
+   use ice_domain_size, only: nx_global, ny_global, block_size_x, block_size_y
+   use ice_blocks, only: nx_block, ny_block, nghost, nblocks_x, nblocks_y, block, get_block
+   use ice_distribution, only: distrb, ice_distributionGet, ice_distributionGetBlockLoc, &
+                               ice_distributionGetBlockID
+   use ice_exit, only: abort_ice
+   use cice4_amd_c
+
+   implicit none
+   private
+   save
+
+   type, public :: ice_halo
+      integer (int_kind) :: communicator   ! kept for source compatibility (unused)
+      integer (int_kind) :: numBlocks      ! local blocks the device domain was built for
+      integer (int_kind) :: ewBnd, nsBnd   ! 0 open, 1 cyclic, 2 closed
+   end type
+
+   public :: ice_HaloCreate, ice_HaloUpdate, ice_HaloExtrapolate
+
+   interface ice_HaloUpdate
+      module procedure ice_HaloUpdate2DR8, ice_HaloUpdate2DR4, ice_HaloUpdate2DI4, &
+                       ice_HaloUpdate3DR8, ice_HaloUpdate3DR4, ice_HaloUpdate3DI4, &
+                       ice_HaloUpdate4DR8, ice_HaloUpdate4DR4, ice_HaloUpdate4DI4
+   end interface
+
+   interface ice_HaloExtrapolate
+      module procedure ice_HaloExtrapolate2DR8
+   end interface
+
+contains
+
+!=======================================================================
+! Builds the device-side block topology and halo lists for the distribution `dist`
+! and checks that the device's block->task map is the host's.
+   function ice_HaloCreate(dist, nsBoundaryType, ewBoundaryType, nxGlobal) result(halo)
+      type (distrb), intent(in) :: dist
+      character (*), intent(in) :: nsBoundaryType, ewBoundaryType
+      integer (int_kind), intent(in) :: nxGlobal
+      type (ice_halo) :: halo
+
+      integer (int_kind) :: nprocs, numBlocks, npx, npy, ib, proc, lid, last, n, gid
+      integer (c_int) :: info(9), binfo(10)
+
+      if (nghost /= 1) call abort_ice('ice_HaloCreate: the GPU path needs nghost = 1')
+      if (nxGlobal /= nx_global) call abort_ice('ice_HaloCreate: nxGlobal /= nx_global')
+      halo%ewBnd = boundary_code(ewBoundaryType)
+      halo%nsBnd = boundary_code(nsBoundaryType)
+
+      call ice_distributionGet(dist, nprocs=nprocs, communicator=halo%communicator, &
+                               numLocalBlocks=numBlocks)
+      ! process grid of the cartesian distribution: distinct owners along the first block row
+      npx = 0; last = -1
+      do ib = 1, nblocks_x
+         call ice_distributionGetBlockLoc(dist, ib, proc, lid)
+         if (proc == 0) call abort_ice('ice_HaloCreate: land-block elimination is not supported')
+         if (proc /= last) npx = npx + 1
+         last = proc
+      enddo
+      if (mod(nprocs, npx) /= 0) call abort_ice('ice_HaloCreate: distribution is not cartesian')
+      npy = nprocs/npx
+
+      call cice_gpu_ensure()
+      call cice_gpu_check(cice_domain_create(cice_gpu_ctx, nx_global, ny_global, block_size_x, &
+           block_size_y, halo%ewBnd, halo%nsBnd, my_task, npx, npy), 'cice_domain_create')
+      call cice_gpu_check(cice_domain_info(cice_gpu_ctx, info), 'cice_domain_info')
+      if (info(1) /= nx_block .or. info(2) /= ny_block .or. info(3) /= numBlocks) then
+         write(nu_diag,*) 'ice_HaloCreate: device layout', info(1:3), ' host layout', &
+                          nx_block, ny_block, numBlocks
+         call abort_ice('ice_HaloCreate: device block layout differs from the host layout')
+      endif
+      do n = 1, numBlocks
+         call ice_distributionGetBlockID(dist, n, gid)
+         call cice_gpu_check(cice_domain_block(cice_gpu_ctx, n-1, binfo), 'cice_domain_block')
+         if (binfo(7) + 1 /= gid) then
+            write(nu_diag,*) 'ice_HaloCreate: local block', n, ' is global block', gid, &
+                             ' on the host but', binfo(7) + 1, ' on the device'
+            call abort_ice('ice_HaloCreate: block distribution is not the cartesian one')
+         endif
+      enddo
+      halo%numBlocks = numBlocks
+   end function ice_HaloCreate
+
+   integer (int_kind) function boundary_code(name)
+      character (*), intent(in) :: name
+      boundary_code = -1
+      select case (trim(name))
+      case ('open');   boundary_code = 0
+      case ('cyclic'); boundary_code = 1
+      case ('closed'); boundary_code = 2
+      case default
+         call abort_ice('ice_HaloCreate: boundary type not supported on the GPU path: '//trim(name))
+      end select
+   end function boundary_code
+
+!=======================================================================
+! Workers: nlev horizontal slabs in the device layout (nx_block,ny_block,nblocks,nlev).
+   subroutine update_levels_r8(buf, nblk, nlev, halo, who)
+      integer (int_kind), intent(in) :: nblk, nlev
+      real (dbl_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+      type (ice_halo), intent(in) :: halo
+      character (*), intent(in) :: who
+      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
+      if (nlev < 1) return
+      call cice_gpu_check(cice_halo_update_r8(cice_gpu_ctx, buf, nlev), who)
+   end subroutine update_levels_r8
+
+   subroutine update_levels_i4(buf, nblk, nlev, halo, who)
+      integer (int_kind), intent(in) :: nblk, nlev
+      integer (int_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+      type (ice_halo), intent(in) :: halo
+      character (*), intent(in) :: who
+      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
+      if (nlev < 1) return
+      call cice_gpu_check(cice_halo_update_i4(cice_gpu_ctx, buf, nlev), who)
+   end subroutine update_levels_i4
+
+   subroutine check_shape(n1, n2, who)
+      integer (int_kind), intent(in) :: n1, n2
+      character (*), intent(in) :: who
+      if (n1 /= nx_block .or. n2 /= ny_block) &
+         call abort_ice(who//': horizontal extent is not (nx_block,ny_block)')
+   end subroutine check_shape
+
+!=======================================================================
+! 2-d fields: (nx_block,ny_block,nblocks)
+   subroutine ice_HaloUpdate2DR8(array, halo, fieldLoc, fieldKind, fillValue)
+      real (dbl_kind), dimension(:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (dbl_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR8')
+      allocate(buf(nx_block,ny_block,size(array,3),1))
+      buf(:,:,:,1) = array
+      call update_levels_r8(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DR8')
+      array = buf(:,:,:,1)
+   end subroutine ice_HaloUpdate2DR8
+
+   subroutine ice_HaloUpdate2DR4(array, halo, fieldLoc, fieldKind, fillValue)
+      real (real_kind), dimension(:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (real_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR4')
+      allocate(buf(nx_block,ny_block,size(array,3),1))
+      buf(:,:,:,1) = real(array, dbl_kind)          ! exact; the update only copies
+      call update_levels_r8(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DR4')
+      array = real(buf(:,:,:,1), real_kind)
+   end subroutine ice_HaloUpdate2DR4
+
+   subroutine ice_HaloUpdate2DI4(array, halo, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), dimension(:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      integer (int_kind), intent(in), optional :: fillValue
+      integer (int_kind), allocatable :: buf(:,:,:,:)
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DI4')
+      allocate(buf(nx_block,ny_block,size(array,3),1))
+      buf(:,:,:,1) = array
+      call update_levels_i4(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DI4')
+      array = buf(:,:,:,1)
+   end subroutine ice_HaloUpdate2DI4
+
+!=======================================================================
+! 3-d fields: (nx_block,ny_block,nz,nblocks) -- all levels in ONE device update
+   subroutine ice_HaloUpdate3DR8(array, halo, fieldLoc, fieldKind, fillValue)
+      real (dbl_kind), dimension(:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (dbl_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, n, nz, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR8')
+      nz = size(array,3); nb = size(array,4)
+      allocate(buf(nx_block,ny_block,nb,nz))
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,k) = array(:,:,k,n)
+      enddo
+      enddo
+      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR8')
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,n) = buf(:,:,n,k)
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate3DR8
+
+   subroutine ice_HaloUpdate3DR4(array, halo, fieldLoc, fieldKind, fillValue)
+      real (real_kind), dimension(:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (real_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, n, nz, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR4')
+      nz = size(array,3); nb = size(array,4)
+      allocate(buf(nx_block,ny_block,nb,nz))
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,k) = real(array(:,:,k,n), dbl_kind)
+      enddo
+      enddo
+      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR4')
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,n) = real(buf(:,:,n,k), real_kind)
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate3DR4
+
+   subroutine ice_HaloUpdate3DI4(array, halo, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), dimension(:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      integer (int_kind), intent(in), optional :: fillValue
+      integer (int_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, n, nz, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DI4')
+      nz = size(array,3); nb = size(array,4)
+      allocate(buf(nx_block,ny_block,nb,nz))
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,k) = array(:,:,k,n)
+      enddo
+      enddo
+      call update_levels_i4(buf, nb, nz, halo, 'ice_HaloUpdate3DI4')
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,n) = buf(:,:,n,k)
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate3DI4
+
+!=======================================================================
+! 4-d fields: (nx_block,ny_block,nz,nt,nblocks) -- nz*nt levels in ONE device update
+   subroutine ice_HaloUpdate4DR8(array, halo, fieldLoc, fieldKind, fillValue)
+      real (dbl_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (dbl_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, l, n, nz, nt, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR8')
+      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      allocate(buf(nx_block,ny_block,nb,nz*nt))
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
+      enddo
+      enddo
+      enddo
+      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR8')
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
+      enddo
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate4DR8
+
+   subroutine ice_HaloUpdate4DR4(array, halo, fieldLoc, fieldKind, fillValue)
+      real (real_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      real (real_kind), intent(in), optional :: fillValue
+      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, l, n, nz, nt, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR4')
+      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      allocate(buf(nx_block,ny_block,nb,nz*nt))
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,(l-1)*nz+k) = real(array(:,:,k,l,n), dbl_kind)
+      enddo
+      enddo
+      enddo
+      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR4')
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,l,n) = real(buf(:,:,n,(l-1)*nz+k), real_kind)
+      enddo
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate4DR4
+
+   subroutine ice_HaloUpdate4DI4(array, halo, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: fieldKind, fieldLoc
+      integer (int_kind), intent(in), optional :: fillValue
+      integer (int_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: k, l, n, nz, nt, nb
+      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DI4')
+      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      allocate(buf(nx_block,ny_block,nb,nz*nt))
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
+      enddo
+      enddo
+      enddo
+      call update_levels_i4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DI4')
+      do l = 1, nt
+      do k = 1, nz
+      do n = 1, nb
+         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
+      enddo
+      enddo
+      enddo
+   end subroutine ice_HaloUpdate4DI4
+
+!=======================================================================
+! Ghost cells on non-cyclic domain edges by linear extrapolation from the two cells inside
+! (used by ice_grid.F90 for HTN/HTE/dxhy/dyhx).  Host arithmetic: it runs a few times at
+! set-up on grid arrays that live on the host.  West/east columns first, then south/north
+! rows over the full width, so corner ghosts extrapolate the extrapolated columns.  The
+! east/north target is the last column/row whose global index is non-zero, counted as the
+! reference counts it (serial/ice_boundary.F90:4283-4310): padding has index 0 and so has the
+! ghost line of a 'closed' edge, for which the target therefore is the last physical line.
+   subroutine ice_HaloExtrapolate2DR8(ARRAY, dist, ew_bndy_type, ns_bndy_type)
+      real (dbl_kind), dimension(:,:,:), intent(inout) :: ARRAY
+      type (distrb), intent(in) :: dist
+      character (char_len) :: ew_bndy_type, ns_bndy_type
+
+      integer (int_kind) :: i, j, n, numBlocks, gid, ig, jg
+      logical (log_kind) :: ew_edge, ns_edge
+      type (block) :: blk
+      real (dbl_kind), parameter :: two = 2.0_dbl_kind
+
+      ew_edge = trim(ew_bndy_type) /= 'cyclic'
+      ns_edge = trim(ns_bndy_type) /= 'cyclic'
+      call ice_distributionGet(dist, numLocalBlocks=numBlocks)
+      do n = 1, numBlocks
+         call ice_distributionGetBlockID(dist, n, gid)
+         blk = get_block(gid, gid)
+         if (ew_edge .and. blk%iblock == 1) then
+            do j = 1, ny_block
+               ARRAY(1,j,n) = two*ARRAY(2,j,n) - ARRAY(3,j,n)
+            enddo
+         endif
+         if (ew_edge .and. blk%iblock == nblocks_x) then
+            ig = nx_block - count(blk%i_glob(nghost+1:nx_block) == 0)
+            do j = 1, ny_block
+               ARRAY(ig,j,n) = two*ARRAY(ig-1,j,n) - ARRAY(ig-2,j,n)
+            enddo
+         endif
+         if (ns_edge .and. blk%jblock == 1) then
+            do i = 1, nx_block
+               ARRAY(i,1,n) = two*ARRAY(i,2,n) - ARRAY(i,3,n)
+            enddo
+         endif
+         if (ns_edge .and. blk%jblock == nblocks_y .and. &
+             trim(ns_bndy_type) /= 'tripole' .and. trim(ns_bndy_type) /= 'tripoleT') then
+            jg = ny_block - count(blk%j_glob(nghost+1:ny_block) == 0)
+            do i = 1, nx_block
+               ARRAY(i,jg,n) = two*ARRAY(i,jg-1,n) - ARRAY(i,jg-2,n)
+            enddo
+         endif
+      enddo
+   end subroutine ice_HaloExtrapolate2DR8
+
+end module ice_boundary

@@ -41,15 +41,18 @@ SRCS="source/ice_kinds_mod.F90 serial/ice_communicate.F90 source/ice_domain_size
  serial/ice_timers.F90 source/ice_grid.F90 source/ice_itd.F90 source/ice_mechred.F90
  source/ice_dyn_evp.F90 source/ice_calendar.F90 source/ice_atmo.F90 source/ice_ocean.F90
  source/ice_restart.F90 source/ice_age.F90 source/ice_therm_vertical.F90"
-# DROPIN=1: the same closure, but with OUR drop-in modules (cice4_amd/fortran/ice_dyn_evp.F90 and
-# ice_therm_vertical.F90, which forward evp(dt) / thermo_vertical(...) to the GPU library through the
-# ISO_C_BINDING shim) in place of the reference's files of the same name -> libcice_dropin_<cfg>.so.  Every caller of evp in the
-# closure and the capture wrapper are the reference's / the same: this is the drop-in test.
+# DROPIN=1: the same closure, but with OUR drop-in modules (cice4_amd/fortran/rccl/ice_boundary.F90,
+# ice_dyn_evp.F90 and ice_therm_vertical.F90, which forward ice_HaloUpdate / evp(dt) /
+# thermo_vertical(...) to the GPU library through the ISO_C_BINDING shim) in place of the reference's
+# files of the same name -> libcice_dropin_<cfg>.so.  Every caller in the closure (ice_domain,
+# ice_grid, ice_state, ...) and the capture wrapper are the reference's / the same: this is the
+# drop-in test.
 DROPIN=${DROPIN:-0}
 KIND=ref
 if [ "$DROPIN" = "1" ]; then
   KIND=dropin
   OBJ=$OUT/obj_${CFG}_dropin
+  rm -rf "$OBJ"            # our modules change: never reuse dependents' objects / .mod files
   mkdir -p "$OBJ"
   FFLAGS="${FFLAGS//obj_$CFG/obj_${CFG}_dropin}"
 fi
@@ -57,9 +60,12 @@ OBJS=""
 for s in $SRCS; do
   src="$REF/$s"
   o=$OBJ/$(basename "${s%.F90}").o
-  if [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_dyn_evp.F90" ]; then
+  if [ "$DROPIN" = "1" ] && [ "$s" = "serial/ice_boundary.F90" ]; then
     $FC $FFLAGS -c "$HERE/../cice4_amd/fortran/cice4_amd_c.F90" -o "$OBJ/cice4_amd_c.o"
     OBJS="$OBJS $OBJ/cice4_amd_c.o"
+    src="$HERE/../cice4_amd/fortran/rccl/ice_boundary.F90"
+    $FC $FFLAGS -c "$src" -o "$o"
+  elif [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_dyn_evp.F90" ]; then
     src="$HERE/../cice4_amd/fortran/ice_dyn_evp.F90"
     $FC $FFLAGS -c "$src" -o "$o"
   elif [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_therm_vertical.F90" ]; then

@@ -382,6 +382,66 @@ contains
       call ice_HaloUpdate(a, halo_info, loc, kind)
    end subroutine ref_halo_i4
 
+   ! generic n-d update: typ 0 = R8, 1 = R4, 2 = I4; nz = nt = 0 -> (nx,ny,nblk);
+   ! nt = 0 -> (nx,ny,nz,nblk); else (nx,ny,nz,nt,nblk)
+   subroutine ref_halo_nd(buf, typ, nz, nt, loc, kind) bind(C, name='ref_halo_nd')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_boundary
+      use ice_domain, only: halo_info
+      type(c_ptr), value :: buf
+      integer(c_int), value :: typ, nz, nt, loc, kind
+      real(c_double), pointer :: d2(:,:,:), d3(:,:,:,:), d4(:,:,:,:,:)
+      real(c_float), pointer :: f2(:,:,:), f3(:,:,:,:), f4(:,:,:,:,:)
+      integer(c_int), pointer :: i2(:,:,:), i3(:,:,:,:), i4(:,:,:,:,:)
+      if (nz == 0) then
+         select case (typ)
+         case (0); call c_f_pointer(buf, d2, [nx_block,ny_block,max_blocks])
+                   call ice_HaloUpdate(d2, halo_info, loc, kind)
+         case (1); call c_f_pointer(buf, f2, [nx_block,ny_block,max_blocks])
+                   call ice_HaloUpdate(f2, halo_info, loc, kind)
+         case (2); call c_f_pointer(buf, i2, [nx_block,ny_block,max_blocks])
+                   call ice_HaloUpdate(i2, halo_info, loc, kind)
+         end select
+      else if (nt == 0) then
+         select case (typ)
+         case (0); call c_f_pointer(buf, d3, [nx_block,ny_block,nz,max_blocks])
+                   call ice_HaloUpdate(d3, halo_info, loc, kind)
+         case (1); call c_f_pointer(buf, f3, [nx_block,ny_block,nz,max_blocks])
+                   call ice_HaloUpdate(f3, halo_info, loc, kind)
+         case (2); call c_f_pointer(buf, i3, [nx_block,ny_block,nz,max_blocks])
+                   call ice_HaloUpdate(i3, halo_info, loc, kind)
+         end select
+      else
+         select case (typ)
+         case (0); call c_f_pointer(buf, d4, [nx_block,ny_block,nz,nt,max_blocks])
+                   call ice_HaloUpdate(d4, halo_info, loc, kind)
+         case (1); call c_f_pointer(buf, f4, [nx_block,ny_block,nz,nt,max_blocks])
+                   call ice_HaloUpdate(f4, halo_info, loc, kind)
+         case (2); call c_f_pointer(buf, i4, [nx_block,ny_block,nz,nt,max_blocks])
+                   call ice_HaloUpdate(i4, halo_info, loc, kind)
+         end select
+      endif
+   end subroutine ref_halo_nd
+
+   subroutine ref_halo_extrapolate(a) bind(C, name='ref_halo_extrapolate')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_boundary
+      use ice_domain, only: distrb_info, ew_boundary_type, ns_boundary_type
+      real(c_double), intent(inout) :: a(nx_block,ny_block,max_blocks)
+      call ice_HaloExtrapolate(a, distrb_info, ew_boundary_type, ns_boundary_type)
+   end subroutine ref_halo_extrapolate
+
+   ! the state-variable ghost update of ice_state.F90:bound_state on caller-supplied arrays
+   subroutine ref_bound_state(aicen, trcrn, vicen, vsnon, eicen, esnon) bind(C, name='ref_bound_state')
+      use ice_blocks, only: nx_block, ny_block
+      use ice_state, only: bound_state
+      real(c_double), intent(inout) :: aicen(nx_block,ny_block,ncat,max_blocks), &
+         trcrn(nx_block,ny_block,max_ntrcr,ncat,max_blocks), vicen(nx_block,ny_block,ncat,max_blocks), &
+         vsnon(nx_block,ny_block,ncat,max_blocks), eicen(nx_block,ny_block,ntilyr,max_blocks), &
+         esnon(nx_block,ny_block,ntslyr,max_blocks)
+      call bound_state(aicen, trcrn, vicen, vsnon, eicen, esnon)
+   end subroutine ref_bound_state
+
    subroutine ref_to_ugrid(w1, w2) bind(C, name='ref_to_ugrid')
       use ice_blocks, only: nx_block, ny_block
       use ice_grid, only: to_ugrid

@@ -251,3 +251,21 @@ class Ref:
 
     def halo_i4(self, a, loc=1, kind=1):
         self.lib.ref_halo_i4(_p(a), C.c_int(loc), C.c_int(kind))
+
+    def halo_nd(self, a, loc=1, kind=1):
+        """Generic ice_HaloUpdate on a C-ordered array (nblk[,nt][,nz],ny,nx) of float64,
+        float32 or int32 -- the 2-d/3-d/4-d x R8/R4/I4 specifics."""
+        typ = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2}[a.dtype]
+        assert a.shape[0] == self.max_blocks and a.shape[-2:] == (self.ny_block, self.nx_block)
+        nz = a.shape[-3] if a.ndim >= 4 else 0
+        nt = a.shape[-4] if a.ndim == 5 else 0
+        self.lib.ref_halo_nd(_p(a), C.c_int(typ), C.c_int(nz), C.c_int(nt), C.c_int(loc),
+                             C.c_int(kind))
+
+    def halo_extrapolate(self, a):
+        self.lib.ref_halo_extrapolate(_p(a))
+
+    def bound_state(self, aicen, trcrn, vicen, vsnon, eicen, esnon):
+        """ice_state.F90:bound_state; arrays C-ordered (nblk,ncat,ny,nx), trcrn
+        (nblk,ncat,max_ntrcr,ny,nx), eicen (nblk,ncat*nilyr,ny,nx), esnon (nblk,ncat*nslyr,ny,nx)."""
+        self.lib.ref_bound_state(_p(aicen), _p(trcrn), _p(vicen), _p(vsnon), _p(eicen), _p(esnon))
