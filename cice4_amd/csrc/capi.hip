@@ -361,8 +361,8 @@ int cice_thermo_init(cice_ctx* ctx, const cice_thermo_config* cfg, double* salin
   CICE_REQUIRE(cfg, "NULL argument");
   CICE_REQUIRE(cfg->conduct == 0 || cfg->conduct == 1, "conduct must be 0 (MU71) or 1 (bubbly)");
   CICE_REQUIRE(cfg->nt_Tsfc >= 1 && cfg->nt_Tsfc <= NTRCR, "nt_Tsfc out of range");
-  if (!cfg->heat_capacity || !cfg->calc_Tsfc)
-    throw Error{CICE_EUNSUPPORTED, "only heat_capacity = T, calc_Tsfc = T is implemented on the device"};
+  if (!cfg->heat_capacity)
+    throw Error{CICE_EUNSUPPORTED, "zero-layer thermodynamics (heat_capacity = F) is not implemented on the device"};
   c_->tp.init(*cfg);
   c_->have_thermo = true;
   if (salin) std::memcpy(salin, c_->tp.salin, sizeof(c_->tp.salin));
@@ -434,6 +434,9 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
   up(A_FSWSFC, fswsfc); up(A_FSWINT, fswint); up(A_FSWTHRU, fswthrun);
   up(A_SSW, Sswabs, NSLYR); up(A_ISW, Iswabs, NILYR);
   up(A_MLT, mlt_onset); up(A_FRZ, frz_onset);
+  if (!c_->tp.calc_Tsfc) {  // intent(in) then (ice_therm_vertical.F90:213-217): planes 0, 1, 3 of the outputs
+    up(A_OUT + 0, fsurfn); up(A_OUT + 1, fcondtopn); up(A_OUT + 3, flatn);
+  }
   if (icells) {
     CICE_HIP(hipMemcpyAsync(li.p, indxi, (size_t)icells * 4, hipMemcpyHostToDevice, s));
     CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, s));
@@ -521,6 +524,15 @@ int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
   for (U& x : us) {
     CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
     x.d->upload(x.h, c_->stream);
+  }
+  if (c_->have_thermo && !c_->tp.calc_Tsfc) {  // surface fluxes are inputs (ice_therm_vertical.F90:213-217)
+    const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
+    const double* in3[3] = {h->fsurfn, h->fcondtopn, h->flatn};
+    const int plane[3] = {0, 1, 3};
+    for (int k = 0; k < 3; ++k) {
+      CICE_REQUIRE(in3[k] != nullptr, "cice_thermo_batch_upload: calc_Tsfc = F needs fsurfn, fcondtopn, flatn");
+      CICE_HIP(hipMemcpyAsync(t.out15.p + (size_t)plane[k] * nc, in3[k], nc * 8, hipMemcpyHostToDevice, c_->stream));
+    }
   }
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH

@@ -6,7 +6,7 @@
 // iteration loop.  Fields are read and written in the reference's own layout, so lanes of a
 // wavefront touch 64 consecutive i of one (j, level) row.
 //
-// Configuration covered: heat_capacity = T, calc_Tsfc = T (input_templates/gx3/ice_in and
+// Configuration covered: heat_capacity = T, calc_Tsfc = T or F (input_templates/gx3/ice_in and
 // the COSIMA configurations); conduct = 'MU71' or 'bubbly'.
 #include "therm.h"
 
@@ -131,12 +131,16 @@ __device__ __forceinline__ unsigned init_profile(const ThermoParams& P, double a
 }
 
 // temperature_changes :1288-2148 (+ conductivity :2169, surface_fluxes :2314,
-// get_matrix_elements_calc_Tsfc :2447, tridiag_solver :3069)
+// get_matrix_elements_calc_Tsfc :2447 or, CALC = false (calc_Tsfc = F: fsurfn, fcondtopn, flatn
+// are the caller's, Tsf is not solved for), get_matrix_elements_know_Tsfc :2777;
+// tridiag_solver :3069)
+template <bool CALC>
 __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, double dt, Col& c, Flx& f) {
   constexpr int nitermax = 100;
   constexpr double Tsf_errmax = 5.0e-4;
   const double hilyr = c.hilyr, hslyr = c.hslyr;
   bool converged = false, l_snow = false, l_cold = true;
+  double dTi1_prev = c0;
   double dTsf_prev = c0, dfsens_dT = c0, dflat_dT = c0, dflwout_dT = c0;
   double Tin_init[NI], Tin_start[NI], Tsn_init[NS], Tsn_start[NS], etas[NS], kh[NMAT];
   const double dt_rhoi_hlyr = dt / (rhoi * hilyr);
@@ -209,7 +213,7 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
 #pragma unroll 1
   for (int niter = 1; niter <= nitermax && !converged; ++niter) {
     double etai[NI], sb[NMAT], dg[NMAT], sp[NMAT], rh[NMAT], Tm[NMAT];
-    double dfsurf_dT, avg_Tsi = c0, enew = c0, Tsf_start, dTsf, avg_Tsf;
+    double dfsurf_dT = c0, avg_Tsi = c0, enew = c0, Tsf_start = c0, dTsf = c0, avg_Tsf = c0;
     double dqmat[NI];
     bool reduce_kh[NI];
     converged = true;
@@ -218,7 +222,7 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
       const double ci = P.l_brine ? cp_ice - Lfresh * P.Tmlt[k] / (c.Tin[k] * Tin_init[k]) : cp_ice;
       etai[k] = dt_rhoi_hlyr / ci;
     }
-    {  // surface_fluxes :2389-2421
+    if (CALC) {  // surface_fluxes :2389-2421
       const double TsfK = c.Tsf + Tffresh;
       const double tmpvar = c1 / TsfK;
       const double qsat = qqqice * exp(-TTTice * tmpvar);
@@ -235,18 +239,25 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
       dflat_dT = -f.lhcoef * dQsfcdT;
       f.fsurfn = f.fswsfc + flwdabs + f.flwoutn + f.fsensn + f.flatn;
       dfsurf_dT = dflwout_dT + dfsens_dT + dflat_dT;
+      // :1719-1738
+      f.fcondtopn = l_snow ? kh[0] * (c.Tsf - c.Tsn[0]) : kh[NS] * (c.Tsf - c.Tin[0]);
+      if (f.fsurfn < f.fcondtopn) c.Tsf = fmin(c.Tsf, -puny);
+      Tsf_start = c.Tsf;
+      l_cold = (c.Tsf <= -puny);
     }
-    // :1719-1738
-    f.fcondtopn = l_snow ? kh[0] * (c.Tsf - c.Tsn[0]) : kh[NS] * (c.Tsf - c.Tin[0]);
-    if (f.fsurfn < f.fcondtopn) c.Tsf = fmin(c.Tsf, -puny);
-    Tsf_start = c.Tsf;
-    l_cold = (c.Tsf <= -puny);
-    // get_matrix_elements_calc_Tsfc :2540-2751 (0-based rows)
+    // get_matrix_elements_calc_Tsfc :2540-2751 / _know_Tsfc :2871-3048 (0-based rows)
 #pragma unroll
     for (int k = 0; k <= NS; ++k) {
       sb[k] = c0; dg[k] = c1; sp[k] = c0; rh[k] = c0;
     }
-    if (l_cold) {
+    if (!CALC) {
+      if (l_snow) {  // :2892-2902
+        sb[1] = c0;
+        sp[1] = -etas[0] * kh[1];
+        dg[1] = c1 + etas[0] * kh[1];
+        rh[1] = Tsn_init[0] + etas[0] * f.Sswabs[0] + etas[0] * f.fcondtopn;
+      }
+    } else if (l_cold) {
       if (l_snow) {
         sb[0] = c0; dg[0] = dfsurf_dT - kh[0]; sp[0] = kh[0]; rh[0] = dfsurf_dT * c.Tsf - f.fsurfn;
       } else {
@@ -254,7 +265,7 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
         rh[NS] = dfsurf_dT * c.Tsf - f.fsurfn;
       }
     }
-    if (l_snow) {
+    if (CALC && l_snow) {
       if (l_cold) {
         sb[1] = -etas[0] * kh[0];
         sp[1] = -etas[0] * kh[1];
@@ -277,7 +288,12 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
       }
     {  // top ice layer
       constexpr int k = NS, kr = NS + 1;
-      if (l_snow || l_cold) {
+      if (!CALC && !l_snow) {  // :2956-2962
+        sb[kr] = c0;
+        sp[kr] = -etai[0] * kh[k + 1];
+        dg[kr] = c1 + etai[0] * kh[k + 1];
+        rh[kr] = Tin_init[0] + etai[0] * f.Iswabs[0] + etai[0] * f.fcondtopn;
+      } else if (!CALC || l_snow || l_cold) {
         sb[kr] = -etai[0] * kh[k];
         sp[kr] = -etai[0] * kh[k + 1];
         dg[kr] = c1 + etai[0] * (kh[k] + kh[k + 1]);
@@ -316,28 +332,28 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
 #pragma unroll
       for (int k = NMAT - 2; k >= 0; --k) Tm[k] = Tm[k] - wg[k + 1] * Tm[k + 1];
     }
-    // :1824-1884
-    if (l_cold)
-      c.Tsf = l_snow ? Tm[0] : Tm[NS];
-    else
-      c.Tsf = c0;
-    dTsf = c.Tsf - Tsf_start;
-    avg_Tsf = c0;
-    if (c.Tsf > puny) {
-      c.Tsf = c0;
-      dTsf = -Tsf_start;
-      if (P.l_brine) avg_Tsi = c1;
-      converged = false;
-    } else if (niter > 1 && Tsf_start <= -puny && fabs(dTsf) > puny && fabs(dTsf_prev) > puny &&
-               -dTsf / (dTsf_prev + puny * puny) > p5) {
-      if (P.l_brine) {
-        avg_Tsf = c1;
-        avg_Tsi = c1;
+    if (CALC) {  // :1824-1884
+      if (l_cold)
+        c.Tsf = l_snow ? Tm[0] : Tm[NS];
+      else
+        c.Tsf = c0;
+      dTsf = c.Tsf - Tsf_start;
+      if (c.Tsf > puny) {
+        c.Tsf = c0;
+        dTsf = -Tsf_start;
+        if (P.l_brine) avg_Tsi = c1;
+        converged = false;
+      } else if (niter > 1 && Tsf_start <= -puny && fabs(dTsf) > puny && fabs(dTsf_prev) > puny &&
+                 -dTsf / (dTsf_prev + puny * puny) > p5) {
+        if (P.l_brine) {
+          avg_Tsf = c1;
+          avg_Tsi = c1;
+        }
+        dTsf = p5 * dTsf;
+        converged = false;
       }
-      dTsf = p5 * dTsf;
-      converged = false;
+      c.Tsf = c.Tsf + avg_Tsf * p5 * (Tsf_start - c.Tsf);
     }
-    c.Tsf = c.Tsf + avg_Tsf * p5 * (Tsf_start - c.Tsf);
 #pragma unroll
     for (int k = 0; k < NS; ++k) {  // :1890-1924
       c.Tsn[k] = l_snow ? Tm[k + 1] : c0;
@@ -358,6 +374,16 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
         c.Tin[k] = P.Tmlt[k];
         reduce_kh[k] = true;
       }
+      if (!CALC && k == 0) {  // condition 2b :1961-1975
+        double dTi1 = c.Tin[k] - Tin_start[k];
+        if (niter > 1 && fabs(dTi1) > puny && fabs(dTi1_prev) > puny &&
+            -dTi1 / (dTi1_prev + puny * puny) > p5) {
+          if (P.l_brine) avg_Tsi = c1;
+          dTi1 = p5 * dTi1;
+          converged = false;
+        }
+        dTi1_prev = dTi1;
+      }
       c.Tin[k] = c.Tin[k] + avg_Tsi * p5 * (Tin_start[k] - c.Tin[k]);
       if (P.l_brine)
         c.qin[k] = -rhoi * (cp_ice * (P.Tmlt[k] - c.Tin[k]) + Lfresh * (c1 - P.Tmlt[k] / c.Tin[k]) -
@@ -367,12 +393,13 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
       enew = enew + hilyr * (c.qin[k] - dqmat[k]);
       Tin_start[k] = c.Tin[k];
     }
-    // :2017-2038
-    if (fabs(dTsf) > Tsf_errmax) converged = false;
-    f.fsurfn = f.fsurfn + dTsf * dfsurf_dT;
-    f.fcondtopn = l_snow ? kh[0] * (c.Tsf - c.Tsn[0]) : kh[NS] * (c.Tsf - c.Tin[0]);
-    if (c.Tsf > -puny && f.fsurfn < f.fcondtopn) converged = false;
-    dTsf_prev = dTsf;
+    if (CALC) {  // :2017-2038
+      if (fabs(dTsf) > Tsf_errmax) converged = false;
+      f.fsurfn = f.fsurfn + dTsf * dfsurf_dT;
+      f.fcondtopn = l_snow ? kh[0] * (c.Tsf - c.Tsn[0]) : kh[NS] * (c.Tsf - c.Tin[0]);
+      if (c.Tsf > -puny && f.fsurfn < f.fcondtopn) converged = false;
+      dTsf_prev = dTsf;
+    }
     // :2053-2073
     c.fcondbot = kh[NS + NI] * (c.Tin[NI - 1] - f.Tbot);
     const double ferr = fabs((enew - c.einit) / dt - (f.fcondtopn - c.fcondbot + f.fswint));
@@ -387,10 +414,11 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
         }
     }
   }
-  // :2136-2145
-  f.flwoutn = f.flwoutn + dTsf_prev * dflwout_dT;
-  f.fsensn = f.fsensn + dTsf_prev * dfsens_dT;
-  f.flatn = f.flatn + dTsf_prev * dflat_dT;
+  if (CALC) {  // :2136-2145
+    f.flwoutn = f.flwoutn + dTsf_prev * dflwout_dT;
+    f.fsensn = f.fsensn + dTsf_prev * dfsens_dT;
+    f.flatn = f.flatn + dTsf_prev * dflat_dT;
+  }
   return converged;
 }
 
@@ -593,6 +621,7 @@ __device__ __forceinline__ void thickness_changes(const ThermoParams& P, double 
 // One column of thermo_vertical :108-515.  q: cell offset inside the (nx,ny) plane;
 // n, b: category and block (0-based); order: rank of this column in the reference's
 // failure-reporting order.
+template <bool CALC>
 __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int b,
                                        unsigned long long order) {
   const ThermoParams& P = a.p;
@@ -629,7 +658,10 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
 #pragma unroll
   for (int k = 0; k < NI; ++k) f.Iswabs[k] = a.Iswabs[iq + (size_t)k * np];
   f.fsurfn = f.fcondtopn = f.fsensn = f.flatn = f.fswabsn = f.flwoutn = c0;
-  const bool conv = temperature_changes(P, a.dt, c, f);
+  if (!CALC) {  // intent(in) when calc_Tsfc = F (:213-217)
+    f.fsurfn = a.fsurfn[c2d]; f.fcondtopn = a.fcondtopn[c2d]; f.flatn = a.flatn[c2d];
+  }
+  const bool conv = temperature_changes<CALC>(P, a.dt, c, f);
   a.fswsfc[c2d] = f.fswsfc; a.fswint[c2d] = f.fswint;
 #pragma unroll
   for (int k = 0; k < NS; ++k) a.Sswabs[ssq + (size_t)k * np] = f.Sswabs[k];
@@ -684,39 +716,51 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   }
 }
 
+template <bool CALC>
 __device__ __forceinline__ void zero_outputs(const ThermoArgs& a, size_t c2d) {  // :299-329
   a.fsensn[c2d] = c0; a.fswabsn[c2d] = c0; a.flwoutn[c2d] = c0; a.evapn[c2d] = c0;
   a.freshn[c2d] = c0; a.fsaltn[c2d] = c0; a.fhocnn[c2d] = c0;
   a.meltt[c2d] = c0; a.meltb[c2d] = c0; a.melts[c2d] = c0; a.congel[c2d] = c0; a.snoice[c2d] = c0;
-  a.flatn[c2d] = c0; a.fsurfn[c2d] = c0; a.fcondtopn[c2d] = c0;
+  if (CALC) {  // :321-329; inputs otherwise
+    a.flatn[c2d] = c0; a.fsurfn[c2d] = c0; a.fcondtopn[c2d] = c0;
+  }
 }
 
 // reference-signature form: one lane per entry of the compressed cell list
+template <bool CALC>
 __global__ __launch_bounds__(256) void k_thermo_list(const ThermoArgs a) {
   const int ij = blockIdx.x * blockDim.x + threadIdx.x;
   if (ij >= a.icells) return;
   const size_t q = (size_t)(a.indxj[ij] - 1) * a.nx + (a.indxi[ij] - 1);
-  column(a, q, 0, 0, (unsigned long long)ij);
+  column<CALC>(a, q, 0, 0, (unsigned long long)ij);
 }
 
+template <bool CALC>
 __global__ __launch_bounds__(256) void k_thermo_zero(const ThermoArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < (size_t)a.nx * a.ny) zero_outputs(a, t);
+  if (t < (size_t)a.nx * a.ny) zero_outputs<CALC>(a, t);
 }
 
 // batched form: grid (cell blocks, ncat, nblocks); the aicen > puny test on the physical
 // domain replaces the host-side list compaction of step_therm1 (CICE_RunMod.F90:380-389)
-__global__ __launch_bounds__(256) void k_thermo_dense(const ThermoArgs a) {
+// Occupancy: the column state needs ~260 VGPRs unconstrained = ONE wavefront per SIMD; capping at
+// 256 (two workgroups of 256 per CU) costs a 20-byte spill and gives two wavefronts per SIMD, which
+// hides the latency of the dependent fp64 division chains: +40 % measured (profiles/).
+#ifndef CICE_THERMO_MIN_BLOCKS
+#define CICE_THERMO_MIN_BLOCKS 2
+#endif
+template <bool CALC>
+__global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_dense(const ThermoArgs a) {
   const size_t np = (size_t)a.nx * a.ny;
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int n = blockIdx.y, b = blockIdx.z;
   if (q >= np) return;
   const size_t c2d = ((size_t)b * a.ncat + n) * np + q;
-  zero_outputs(a, c2d);
+  zero_outputs<CALC>(a, c2d);
   const int j = (int)(q / a.nx) + 1, i = (int)(q - (size_t)(j - 1) * a.nx) + 1;
   const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
   const bool active = i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.aicen[c2d] > puny;
-  if (active) column(a, q, n, b, (unsigned long long)q);
+  if (active) column<CALC>(a, q, n, b, (unsigned long long)q);
   unsigned long long cnt = __popcll(__ballot(active));
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
 }
@@ -795,16 +839,24 @@ __global__ __launch_bounds__(256) void k_frzmlt(const FrzmltArgs a) {
 
 void thermo_launch_list(const ThermoArgs& a, hipStream_t s) {
   const size_t np = (size_t)a.nx * a.ny;
-  hipLaunchKernelGGL(k_thermo_zero, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, s, a);
-  if (a.icells > 0)
-    hipLaunchKernelGGL(k_thermo_list, dim3((a.icells + 255) / 256), dim3(256), 0, s, a);
+  const dim3 gz((unsigned)((np + 255) / 256)), gl((unsigned)((a.icells + 255) / 256));
+  if (a.p.calc_Tsfc) {
+    hipLaunchKernelGGL(k_thermo_zero<true>, gz, dim3(256), 0, s, a);
+    if (a.icells > 0) hipLaunchKernelGGL(k_thermo_list<true>, gl, dim3(256), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_thermo_zero<false>, gz, dim3(256), 0, s, a);
+    if (a.icells > 0) hipLaunchKernelGGL(k_thermo_list<false>, gl, dim3(256), 0, s, a);
+  }
   CICE_HIP(hipGetLastError());
 }
 
 void thermo_launch_dense(const ThermoArgs& a, hipStream_t s) {
   const size_t np = (size_t)a.nx * a.ny;
   const dim3 g((unsigned)((np + 255) / 256), a.ncat, a.nblocks);
-  hipLaunchKernelGGL(k_thermo_dense, g, dim3(256), 0, s, a);
+  if (a.p.calc_Tsfc)
+    hipLaunchKernelGGL(k_thermo_dense<true>, g, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(k_thermo_dense<false>, g, dim3(256), 0, s, a);
   CICE_HIP(hipGetLastError());
 }
 

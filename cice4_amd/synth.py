@@ -321,3 +321,24 @@ def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac
     indxi[:icells] = ii + 2
     indxj[:icells] = jj + 2
     return a, icells, indxi, indxj
+
+
+def known_tsfc_inputs(a, solved, seed=20261003, perturb=0.3):
+    """Inputs for thermo_vertical with calc_Tsfc = F (surface fluxes handed over by a coupler,
+    ice_therm_vertical.F90:213-217).  `a` = the columns, `solved` = the same columns after a
+    calc_Tsfc = T call: its fsurfn, fcondtopn, flatn and surface temperature become the inputs.
+    Where the solved surface is colder than -1 C, fsurfn and fcondtopn are scaled together by up to
+    +-perturb (their difference keeps its sign, so no surface energy is lost) and flatn separately;
+    melting surfaces and snow layers thinner than 2 cm keep the solved fluxes (an inconsistent
+    flux drives such a layer to 0 C, where the energy cannot be conserved and the reference stops)."""
+    b = {k: v.copy() for k, v in a.items()}
+    rng = np.random.default_rng(seed)
+    shape = solved["fsurfn"].shape
+    hs = np.where(a["aicen"] > 0.0, a["vsnon"] / np.where(a["aicen"] > 0.0, a["aicen"], 1.0), 0.0)
+    cold = (solved["trcrn"][0] < -1.0) & ((hs == 0.0) | (hs > 0.02))
+    f = np.where(cold, rng.uniform(1.0 - perturb, 1.0 + perturb, shape), 1.0)
+    b["fsurfn"] = solved["fsurfn"] * f
+    b["fcondtopn"] = solved["fcondtopn"] * f
+    b["flatn"] = solved["flatn"] * np.where(cold, rng.uniform(1.0 - perturb, 1.0 + perturb, shape), 1.0)
+    b["trcrn"][0] = solved["trcrn"][0]
+    return b

@@ -1,6 +1,6 @@
 /* TEST INFRASTRUCTURE ONLY (see cice_oracle.h).  CPU restatement of the
  * reference column thermodynamics, source/ice_therm_vertical.F90 (citations
- * are file:line under /root/reference), for heat_capacity = T, calc_Tsfc = T
+ * are file:line under /root/reference), for heat_capacity = T, calc_Tsfc = T and F
  * (the configuration of input_templates/gx3/ice_in and the COSIMA configs).
  *
  * The reference sweeps compressed cell lists phase by phase; every cell's
@@ -155,14 +155,18 @@ typedef struct { /* the (i,j) fields one column touches */
 } fluxes;
 
 /* temperature_changes :1288-2148 with conductivity :2169, surface_fluxes :2314,
- * get_matrix_elements_calc_Tsfc :2447, tridiag_solver :3069. Returns converged flag. */
+ * get_matrix_elements_calc_Tsfc :2447 (calc_Tsfc = T) or get_matrix_elements_know_Tsfc :2777
+ * (calc_Tsfc = F: fsurfn, fcondtopn, flatn are inputs, Tsf is not solved for),
+ * tridiag_solver :3069. Returns converged flag. */
 static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, fluxes *f) {
   const int nitermax = 100;
   const double Tsf_errmax = 5.0e-4;
   const double *Tmlt = c->Tmlt, *salin = c->salin;
   double *Tin = col->Tin, *Tsn = col->Tsn, *qin = col->qin, *qsn = col->qsn;
   const double hilyr = col->hilyr, hslyr = col->hslyr;
+  const int calc = c->calc_Tsfc;
   int converged = 0, l_snow = 0, l_cold = 1;
+  double dTi1_prev = c0;
   double dTsf_prev = c0, dfsens_dT = c0, dflat_dT = c0, dflwout_dT = c0;
   double Tin_init[NI], Tin_start[NI], Tsn_init[NS], Tsn_start[NS], etas[NS], kh[NMAT];
   const double dt_rhoi_hlyr = dt / (rhoi * hilyr); /* :1488 */
@@ -235,7 +239,7 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
   for (int niter = 1; niter <= nitermax && !converged; niter++) {
     niter_done = niter;
     double etai[NI], sbdiag[NMAT], diag[NMAT], spdiag[NMAT], rhs[NMAT], Tmat[NMAT];
-    double dfsurf_dT, avg_Tsi = c0, enew = c0, Tsf_start, dTsf, avg_Tsf;
+    double dfsurf_dT = c0, avg_Tsi = c0, enew = c0, Tsf_start = c0, dTsf = c0, avg_Tsf;
     double dTmat[NI], dqmat[NI];
     int reduce_kh[NI];
     converged = 1;
@@ -243,7 +247,7 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
       double ci = c->l_brine ? cp_ice - Lfresh * Tmlt[k] / (Tin[k] * Tin_init[k]) : cp_ice;
       etai[k] = dt_rhoi_hlyr / ci;
     }
-    { /* surface_fluxes :2389-2421 */
+    if (calc) { /* surface_fluxes :2389-2421 */
       double TsfK = col->Tsf + Tffresh;
       double tmpvar = c1 / TsfK;
       double qsat = qqqice * exp(-TTTice * tmpvar);
@@ -262,24 +266,32 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
       f->fsurfn = f->fswsfc + flwdabs + f->flwoutn + f->fsensn + f->flatn;
       dfsurf_dT = dflwout_dT + dfsens_dT + dflat_dT;
     }
-    /* :1719-1738 */
-    f->fcondtopn = l_snow ? kh[0] * (col->Tsf - Tsn[0]) : kh[NS] * (col->Tsf - Tin[0]);
-    if (f->fsurfn < f->fcondtopn) col->Tsf = dmin(col->Tsf, -puny);
-    Tsf_start = col->Tsf;
-    l_cold = (col->Tsf <= -puny);
+    if (calc) { /* :1719-1738 */
+      f->fcondtopn = l_snow ? kh[0] * (col->Tsf - Tsn[0]) : kh[NS] * (col->Tsf - Tin[0]);
+      if (f->fsurfn < f->fcondtopn) col->Tsf = dmin(col->Tsf, -puny);
+      Tsf_start = col->Tsf;
+      l_cold = (col->Tsf <= -puny);
+    }
 
-    /* get_matrix_elements_calc_Tsfc :2540-2751 (rows 0-based here) */
+    /* get_matrix_elements_calc_Tsfc :2540-2751 / _know_Tsfc :2871-3048 (rows 0-based here) */
     for (int k = 0; k <= NS; k++) {
       sbdiag[k] = c0; diag[k] = c1; spdiag[k] = c0; rhs[k] = c0;
     }
-    if (l_cold) {
+    if (!calc) {
+      if (l_snow) { /* :2892-2902 */
+        sbdiag[1] = c0;
+        spdiag[1] = -etas[0] * kh[1];
+        diag[1] = c1 + etas[0] * kh[1];
+        rhs[1] = Tsn_init[0] + etas[0] * f->Sswabs[0] + etas[0] * f->fcondtopn;
+      }
+    } else if (l_cold) {
       int kr = l_snow ? 0 : NS;
       sbdiag[kr] = c0;
       diag[kr] = dfsurf_dT - kh[kr];
       spdiag[kr] = kh[kr];
       rhs[kr] = dfsurf_dT * col->Tsf - f->fsurfn;
     }
-    if (l_snow) {
+    if (calc && l_snow) {
       if (l_cold) {
         sbdiag[1] = -etas[0] * kh[0];
         spdiag[1] = -etas[0] * kh[1];
@@ -302,7 +314,12 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
       }
     { /* top ice layer (nilyr > 1) */
       int k = NS, kr = NS + 1; /* kh[k] above, kh[k+1] below */
-      if (l_snow || l_cold) {
+      if (!calc && !l_snow) { /* :2956-2962 */
+        sbdiag[kr] = c0;
+        spdiag[kr] = -etai[0] * kh[k + 1];
+        diag[kr] = c1 + etai[0] * kh[k + 1];
+        rhs[kr] = Tin_init[0] + etai[0] * f->Iswabs[0] + etai[0] * f->fcondtopn;
+      } else if (!calc || l_snow || l_cold) {
         sbdiag[kr] = -etai[0] * kh[k];
         spdiag[kr] = -etai[0] * kh[k + 1];
         diag[kr] = c1 + etai[0] * (kh[k] + kh[k + 1]);
@@ -338,28 +355,26 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
       }
       for (int k = NMAT - 2; k >= 0; k--) Tmat[k] = Tmat[k] - wgamma[k + 1] * Tmat[k + 1];
     }
-    /* :1824-1884 */
-    if (l_cold)
-      col->Tsf = l_snow ? Tmat[0] : Tmat[NS];
-    else
-      col->Tsf = c0;
-    dTsf = col->Tsf - Tsf_start;
     avg_Tsf = c0;
-    if (col->Tsf > puny) {
-      col->Tsf = c0;
-      dTsf = -Tsf_start;
-      if (c->l_brine) avg_Tsi = c1;
-      converged = 0;
-    } else if (niter > 1 && Tsf_start <= -puny && fabs(dTsf) > puny && fabs(dTsf_prev) > puny &&
-               -dTsf / (dTsf_prev + puny * puny) > p5) {
-      if (c->l_brine) {
-        avg_Tsf = c1;
-        avg_Tsi = c1;
+    if (calc) { /* :1824-1884 */
+      col->Tsf = l_cold ? (l_snow ? Tmat[0] : Tmat[NS]) : c0;
+      dTsf = col->Tsf - Tsf_start;
+      if (col->Tsf > puny) {
+        col->Tsf = c0;
+        dTsf = -Tsf_start;
+        if (c->l_brine) avg_Tsi = c1;
+        converged = 0;
+      } else if (niter > 1 && Tsf_start <= -puny && fabs(dTsf) > puny && fabs(dTsf_prev) > puny &&
+                 -dTsf / (dTsf_prev + puny * puny) > p5) {
+        if (c->l_brine) {
+          avg_Tsf = c1;
+          avg_Tsi = c1;
+        }
+        dTsf = p5 * dTsf;
+        converged = 0;
       }
-      dTsf = p5 * dTsf;
-      converged = 0;
+      col->Tsf = col->Tsf + avg_Tsf * p5 * (Tsf_start - col->Tsf);
     }
-    col->Tsf = col->Tsf + avg_Tsf * p5 * (Tsf_start - col->Tsf);
     for (int k = 0; k < NS; k++) { /* :1890-1924 */
       Tsn[k] = l_snow ? Tmat[k + 1] : c0;
       if (c->l_brine) Tsn[k] = dmin(Tsn[k], c0);
@@ -377,6 +392,16 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
         Tin[k] = Tmlt[k];
         reduce_kh[k] = 1;
       }
+      if (k == 0 && !calc) { /* condition 2b :1961-1975 */
+        double dTi1 = Tin[k] - Tin_start[k];
+        if (niter > 1 && fabs(dTi1) > puny && fabs(dTi1_prev) > puny &&
+            -dTi1 / (dTi1_prev + puny * puny) > p5) {
+          if (c->l_brine) avg_Tsi = c1;
+          dTi1 = p5 * dTi1;
+          converged = 0;
+        }
+        dTi1_prev = dTi1;
+      }
       Tin[k] = Tin[k] + avg_Tsi * p5 * (Tin_start[k] - Tin[k]);
       if (c->l_brine)
         qin[k] = -rhoi * (cp_ice * (Tmlt[k] - Tin[k]) + Lfresh * (c1 - Tmlt[k] / Tin[k]) -
@@ -386,12 +411,13 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
       enew = enew + hilyr * (qin[k] - dqmat[k]);
       Tin_start[k] = Tin[k];
     }
-    /* :2017-2038 */
-    if (fabs(dTsf) > Tsf_errmax) converged = 0;
-    f->fsurfn = f->fsurfn + dTsf * dfsurf_dT;
-    f->fcondtopn = l_snow ? kh[0] * (col->Tsf - Tsn[0]) : kh[NS] * (col->Tsf - Tin[0]);
-    if (col->Tsf > -puny && f->fsurfn < f->fcondtopn) converged = 0;
-    dTsf_prev = dTsf;
+    if (calc) { /* :2017-2038 */
+      if (fabs(dTsf) > Tsf_errmax) converged = 0;
+      f->fsurfn = f->fsurfn + dTsf * dfsurf_dT;
+      f->fcondtopn = l_snow ? kh[0] * (col->Tsf - Tsn[0]) : kh[NS] * (col->Tsf - Tin[0]);
+      if (col->Tsf > -puny && f->fsurfn < f->fcondtopn) converged = 0;
+      dTsf_prev = dTsf;
+    }
     /* :2053-2073 */
     col->fcondbot = kh[NS + NI] * (Tin[NI - 1] - f->Tbot);
     double ferr = fabs((enew - col->einit) / dt - (f->fcondtopn - col->fcondbot + f->fswint));
@@ -406,10 +432,11 @@ static int temperature_changes(const orc_thermo_cfg *c, double dt, column *col, 
     }
   }
   orc_iter_hist[niter_done]++;
-  /* :2136-2145 */
-  f->flwoutn = f->flwoutn + dTsf_prev * dflwout_dT;
-  f->fsensn = f->fsensn + dTsf_prev * dfsens_dT;
-  f->flatn = f->flatn + dTsf_prev * dflat_dT;
+  if (calc) { /* :2136-2145 */
+    f->flwoutn = f->flwoutn + dTsf_prev * dflwout_dT;
+    f->fsensn = f->fsensn + dTsf_prev * dfsens_dT;
+    f->flatn = f->flatn + dTsf_prev * dflat_dT;
+  }
   return converged;
 }
 
@@ -640,12 +667,12 @@ int orc_thermo_vertical(const orc_thermo_cfg *c, int nx, int ny, double dt, int 
   long best_key = -1; /* stage*icells + ij of the failure the reference reports */
   *istop = 0;
   *jstop = 0;
-  if (!c->heat_capacity || !c->calc_Tsfc) return -1; /* not restated */
+  if (!c->heat_capacity) return -1; /* zero-layer thermodynamics not restated */
   for (size_t q = 0; q < np; q++) { /* :299-329 */
     fsensn[q] = fswabsn[q] = flwoutn[q] = evapn[q] = c0;
     freshn[q] = fsaltn[q] = fhocnn[q] = c0;
     meltt[q] = meltb[q] = melts[q] = congel[q] = snoice[q] = c0;
-    flatn[q] = fsurfn[q] = fcondtopn[q] = c0;
+    if (c->calc_Tsfc) flatn[q] = fsurfn[q] = fcondtopn[q] = c0; /* :321-329; else inputs */
   }
   for (int ij = 0; ij < icells; ij++) {
     const size_t q = (size_t)(indxj[ij] - 1) * nx + (indxi[ij] - 1);
@@ -667,7 +694,8 @@ int orc_thermo_vertical(const orc_thermo_cfg *c, int nx, int ny, double dt, int 
     f.fswsfc = fswsfc[q]; f.fswint = fswint[q]; f.fswthrun = fswthrun[q];
     for (int k = 0; k < NS; k++) f.Sswabs[k] = Sswabs[k * np + q];
     for (int k = 0; k < NI; k++) f.Iswabs[k] = Iswabs[k * np + q];
-    f.fsurfn = f.fcondtopn = f.fsensn = f.flatn = f.fswabsn = f.flwoutn = c0;
+    f.fsurfn = fsurfn[q]; f.fcondtopn = fcondtopn[q]; f.flatn = flatn[q];
+    f.fsensn = f.fswabsn = f.flwoutn = c0;
     int conv = temperature_changes(c, dt, &col, &f);
     /* inout fields are written back even for a failing column (the reference has
      * modified them by the time it stops) */

@@ -12,6 +12,7 @@ Run from the repo root in the build container:  python tests/golden/make_golden.
                     the reference's own arrays), outputs = module arrays after `call evp(dt)`.
   stress_stepu.npz  one call of `stress` (ksub = ndte, so the strain-rate diagnostics are
                     written) and of `stepu` on a 20x16 block with random index lists.
+  thermo_known_tsfc.npz  `thermo_vertical` with calc_Tsfc = F (surface fluxes given), 10x12 block
   thermo_cols.npz   `thermo_vertical` on a 10x12 block: conduct='MU71' 5 categories x 3 regimes,
                     conduct='bubbly' 2 categories.
   frzmlt.npz        `frzmlt_bottom_lateral` on a 14x18 block.
@@ -136,6 +137,31 @@ def thermo_cols(ref):
     np.savez_compressed(os.path.join(HERE, "thermo_cols.npz"), **data)
 
 
+def thermo_known_tsfc(ref):
+    """calc_Tsfc = F: inputs are the fluxes / surface temperature of the reference's own calc_Tsfc = T
+    solve of the same columns, perturbed as synth.known_tsfc_inputs describes."""
+    data = {"meta": meta()}
+    for conduct in ("MU71", "bubbly"):
+        for regime in ("winter", "summer", "mixed"):
+            for n in ((0, 2, 4) if conduct == "MU71" else (1,)):
+                a, icells, ii, jj = synth.thermo_columns(10, 12, n, regime=regime, seed=199)
+                ref.init_thermo(conduct=conduct)
+                t = {k: v.copy() for k, v in a.items()}
+                assert ref.thermo_vertical(DT, icells, ii, jj, t, yday=180.0)[0] == 0
+                b = synth.known_tsfc_inputs(a, t, seed=n)
+                tag = f"{conduct}_{regime}_{n}"
+                for k, v in b.items():
+                    data[f"in_{tag}_{k}"] = v.copy()
+                data[f"list_{tag}"] = np.array([icells] + list(ii[:icells]) + list(jj[:icells]), np.int32)
+                ref.init_thermo(calc_Tsfc=False, conduct=conduct)
+                st = ref.thermo_vertical(DT, icells, ii, jj, b, yday=180.0)
+                data[f"stop_{tag}"] = np.array(st, np.int32)
+                for k, v in b.items():
+                    data[f"out_{tag}_{k}"] = v
+    ref.init_thermo()
+    np.savez_compressed(os.path.join(HERE, "thermo_known_tsfc.npz"), **data)
+
+
 def frzmlt(ref):
     ref.init_thermo()
     rng = np.random.default_rng(8)
@@ -153,8 +179,10 @@ def frzmlt(ref):
 
 if __name__ == "__main__":
     ref = refapi.Ref("small")
-    stress_stepu(ref)
-    thermo_cols(ref)
-    frzmlt(ref)
-    evp_small(ref)      # last: init_domain is once per process
-    print("golden vectors written to", HERE)
+    todo = sys.argv[1:] or ["stress_stepu", "thermo_cols", "thermo_known_tsfc", "frzmlt", "evp_small"]
+    for name in ("stress_stepu", "thermo_cols", "thermo_known_tsfc", "frzmlt"):
+        if name in todo:
+            globals()[name](ref)
+    if "evp_small" in todo:
+        evp_small(ref)      # last: init_domain is once per process
+    print("golden vectors", todo, "written to", HERE)

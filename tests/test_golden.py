@@ -59,8 +59,8 @@ def test_stress_stepu_golden(orc):
     assert np.array_equal(np.array(io), z["su_out"])
 
 
-def thermo_cases():
-    z = load("thermo_cols.npz")
+def thermo_cases(fname="thermo_cols.npz"):
+    z = load(fname)
     tags = sorted(k[5:] for k in z.files if k.startswith("list_"))
     for tag in tags:
         conduct = tag.split("_")[0]
@@ -85,6 +85,19 @@ def test_thermo_golden(orc):
     orc.init_thermo()
 
 
+def test_thermo_known_tsfc_golden(orc):
+    """calc_Tsfc = F vectors minted by the compiled reference (get_matrix_elements_know_Tsfc path)."""
+    n = 0
+    for tag, conduct, a, out, icells, ii, jj, stop in thermo_cases("thermo_known_tsfc.npz"):
+        orc.init_thermo(calc_Tsfc=False, conduct=conduct)
+        assert orc.thermo_vertical(DT, icells, ii, jj, a, yday=180.0) == stop == (0, 0, 0)
+        for k in out:
+            assert np.array_equal(a[k], out[k]), (tag, k)
+        n += icells
+    assert n > 800
+    orc.init_thermo()
+
+
 def test_frzmlt_golden(orc):
     z = load("frzmlt.npz")
     orc.init_thermo()
@@ -97,5 +110,5 @@ def test_frzmlt_golden(orc):
 
 
 def test_golden_files_carry_provenance():
-    for f in ("evp_small.npz", "stress_stepu.npz", "thermo_cols.npz", "frzmlt.npz"):
+    for f in ("evp_small.npz", "stress_stepu.npz", "thermo_cols.npz", "thermo_known_tsfc.npz", "frzmlt.npz"):
         assert "amdflang" in str(load(f)["meta"][0]) or "flang" in str(load(f)["meta"][0])

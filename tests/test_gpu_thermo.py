@@ -59,6 +59,69 @@ def test_thermo_vertical_matches_oracle(ctx, orc, regime, conduct):
     orc.init_thermo()
 
 
+@pytest.mark.parametrize("conduct", ["MU71", "bubbly"])
+def test_known_Tsfc_variant_bit_exact(ctx, orc, conduct):
+    """calc_Tsfc = F (surface fluxes and Tsfc are the caller's; get_matrix_elements_know_Tsfc,
+    ice_therm_vertical.F90:2777): no exp() on this path, so device == checker bit for bit."""
+    for regime in ("winter", "summer", "mixed"):
+        for n in (0, 2, 4):
+            a, icells, ii, jj = synth.thermo_columns(37, 70, n, regime=regime, seed=11)
+            orc.init_thermo(conduct=conduct)
+            t = {k: v.copy() for k, v in a.items()}
+            assert orc.thermo_vertical(DT, icells, ii, jj, t, yday=200.0)[0] == 0
+            b = synth.known_tsfc_inputs(a, t, seed=n)
+            orc.init_thermo(calc_Tsfc=False, conduct=conduct)
+            ctx.thermo_init(calc_Tsfc=False, conduct=conduct)
+            bg = {k: v.copy() for k, v in b.items()}; bc = {k: v.copy() for k, v in b.items()}
+            lg = ctx.thermo_vertical(DT, icells, ii, jj, bg, yday=200.0)
+            lc = orc.thermo_vertical(DT, icells, ii, jj, bc, yday=200.0)
+            assert lg == lc == (0, 0, 0), (regime, n, lg, lc)
+            for k in CHECK:
+                assert np.array_equal(bg[k], bc[k]), (regime, conduct, n, k)
+            assert not np.array_equal(bc["eicen"], t["eicen"])
+    ctx.thermo_init(); orc.init_thermo()
+
+
+def test_known_Tsfc_batched(ctx, orc):
+    """The device-resident batch with calc_Tsfc = F: fsurfn, fcondtopn, flatn travel in with the state."""
+    ny, nx, nb = 26, 40, 2
+    batch, percat = _batch_inputs(ny, nx, nb, seed=33)
+    orc.init_thermo()
+    inputs = {}
+    for b in range(nb):
+        for n in range(5):
+            a, icells, ii, jj = percat[(b, n)]
+            a = {k: v.copy() for k, v in a.items()}
+            for k in lib.THERMO_FORCING:
+                a[k] = percat[(b, 0)][0][k].copy()
+            t = {k: v.copy() for k, v in a.items()}
+            assert orc.thermo_vertical(DT, icells, ii, jj, t, yday=150.0)[0] == 0
+            t["mlt_onset"] = a["mlt_onset"]; t["frz_onset"] = a["frz_onset"]
+            kb = synth.known_tsfc_inputs(a, t, seed=5 * b + n)
+            inputs[(b, n)] = kb
+            for k in ("fsurfn", "fcondtopn", "flatn"):
+                batch[k][b, n] = kb[k]
+            batch["trcrn"][b, n] = kb["trcrn"]
+    ctx.thermo_init(calc_Tsfc=False); orc.init_thermo(calc_Tsfc=False)
+    ctx.thermo_batch_alloc(nx, ny, nb)
+    ctx.thermo_batch_upload(batch)
+    st = ctx.thermo_batch_step(DT, yday=150.0)
+    assert st["l_stop"] == 0
+    ctx.thermo_batch_download(batch)
+    for b in range(nb):
+        mlt = percat[(b, 0)][0]["mlt_onset"].copy(); frz = percat[(b, 0)][0]["frz_onset"].copy()
+        for n in range(5):
+            _, icells, ii, jj = percat[(b, n)]
+            ac = inputs[(b, n)]
+            ac["mlt_onset"], ac["frz_onset"] = mlt, frz
+            assert orc.thermo_vertical(DT, icells, ii, jj, ac, yday=150.0)[0] == 0
+            for k in ("aicen", "vicen", "vsnon", "fswsfc", "fswint") + lib.THERMO_OUT:
+                assert np.array_equal(batch[k][b, n], ac[k]), (b, n, k)
+            assert np.array_equal(batch["eicen"][b, n * 4:(n + 1) * 4], ac["eicen"])
+            assert np.array_equal(batch["trcrn"][b, n], ac["trcrn"])
+    ctx.thermo_init(); orc.init_thermo()
+
+
 def test_empty_list_and_all_melt(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
     a, icells, ii, jj = synth.thermo_columns(12, 20, 0, regime="summer", seed=3)
@@ -226,6 +289,18 @@ def test_fortran_dropin_thermo_module(orc):
         assert ref.thermo_vertical(DT, icells, ii, jj, ag, yday=100.0) == \
             orc.thermo_vertical(DT, icells, ii, jj, ac, yday=100.0) == (0, 0, 0)
         _cmp(ag, ac, ("dropin", n))
+    # calc_Tsfc = F through the module variable (namelist calc_Tsfc, ice_init.F90:107)
+    a, icells, ii, jj = synth.thermo_columns(30, 44, 1, regime="mixed", seed=78)
+    t = {k: v.copy() for k, v in a.items()}
+    assert orc.thermo_vertical(DT, icells, ii, jj, t, yday=100.0)[0] == 0
+    b = synth.known_tsfc_inputs(a, t, seed=3)
+    ref.init_thermo(calc_Tsfc=False); orc.init_thermo(calc_Tsfc=False)
+    bg = {k: v.copy() for k, v in b.items()}; bc = {k: v.copy() for k, v in b.items()}
+    assert ref.thermo_vertical(DT, icells, ii, jj, bg, yday=100.0) == \
+        orc.thermo_vertical(DT, icells, ii, jj, bc, yday=100.0) == (0, 0, 0)
+    for k in CHECK:
+        assert np.array_equal(bg[k], bc[k]), ("dropin calc_Tsfc=F", k)
+    ref.init_thermo(); orc.init_thermo()
     # error path through the Fortran logical
     a, icells, ii, jj = synth.thermo_columns(20, 30, 2, regime="winter", seed=5)
     a["eicen"][1][jj[7] - 1, ii[7] - 1] *= 40.0

@@ -150,6 +150,30 @@ def test_thermo_vertical_bit_exact(ref_gx3, orc, conduct):
     ref_gx3.init_thermo(); orc.init_thermo()
 
 
+@pytest.mark.parametrize("conduct", ["MU71", "bubbly"])
+def test_thermo_vertical_known_Tsfc_bit_exact(ref_gx3, orc, conduct):
+    """calc_Tsfc = F (get_matrix_elements_know_Tsfc, condition 2b): the restatement == the reference."""
+    for regime in ("winter", "summer", "mixed"):
+        for n in (0, 2, 4):
+            a, icells, ii, jj = synth.thermo_columns(40, 50, n, regime=regime)
+            ref_gx3.init_thermo(conduct=conduct)
+            t = {k: v.copy() for k, v in a.items()}
+            assert ref_gx3.thermo_vertical(DT, icells, ii, jj, t, yday=123.0)[0] == 0
+            b = synth.known_tsfc_inputs(a, t, seed=n)
+            ref_gx3.init_thermo(calc_Tsfc=False, conduct=conduct)
+            orc.init_thermo(calc_Tsfc=False, conduct=conduct)
+            b1 = {k: v.copy() for k, v in b.items()}; b2 = {k: v.copy() for k, v in b.items()}
+            l1 = ref_gx3.thermo_vertical(DT, icells, ii, jj, b1, yday=123.0)
+            l2 = orc.thermo_vertical(DT, icells, ii, jj, b2, yday=123.0)
+            assert l1 == l2 == (0, 0, 0), (regime, n, l1, l2)
+            for k in b1:
+                assert np.array_equal(b1[k], b2[k]), (regime, n, k)
+            assert not np.array_equal(b1["eicen"], b["eicen"])
+            assert not np.array_equal(b1["eicen"], t["eicen"])         # the perturbed fluxes matter
+            assert not b1["fsensn"].any() and not b1["flwoutn"].any()  # never assigned (:299-306)
+    ref_gx3.init_thermo(); orc.init_thermo()
+
+
 def test_thermo_error_reporting(ref_gx3, orc):
     """Which failing cell comes back in (l_stop, istop, jstop)."""
     ref_gx3.init_thermo(); orc.init_thermo()
