@@ -52,6 +52,8 @@ def parse():
     p.add_argument("--slabs", type=int, default=0,
                    help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
                         "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
+    p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
+    p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/16); 0 = auto")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -84,11 +86,25 @@ def init_dist(n_gpus):
 def auto_overlap(nxg, rows):
     """Rows of overlap = subcycles between ghost exchanges.  Redundant work grows like
     2H/rows x t_kernel, exchange cost falls like t_comm/H (t_comm ~ 12 us measured through
-    pack + RCCL p2p + unpack); small slabs are latency-bound, so extra rows cost them nothing."""
-    t_kernel = nxg * rows * 62e-6            # us, from 537 us per 8.63 M cells
+    pack + RCCL p2p + unpack); small slabs are latency-bound, so extra rows cost them nothing.
+    Always even: the subcycle kernel then runs two subcycles per launch."""
+    t_kernel = nxg * rows * 50e-6            # us per subcycle, from 430 us per 8.63 M cells
     if nxg * rows <= 200 * 200:
-        return max(1, min(12, rows // 4))
-    return max(1, min(rows // 4, int(round((12.0 * rows / (2.0 * t_kernel)) ** 0.5))))
+        h = max(2, min(12, rows // 4))
+    else:
+        h = max(2, min(rows // 4, int(round((12.0 * rows / (2.0 * t_kernel)) ** 0.5))))
+    return h + (h & 1) if h + (h & 1) <= rows else max(2, h - (h & 1))
+
+
+def launches_per_step(ndte, fused, overlap):
+    """Kernel launches of one step's subcycle loop (Evp::launch_range): pairs of subcycles where the
+    domain allows, never across a wide-halo refresh."""
+    n, k = 0, 1
+    while k <= ndte:
+        pair = fused and k + 1 <= ndte and not (overlap > 0 and k % overlap == 0)
+        k += 2 if pair else 1
+        n += 1
+    return n
 
 
 def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
@@ -220,7 +236,7 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     return out
 
 
-def pmc_traffic(workload, waves, rows, derive):
+def pmc_traffic(workload, waves, rows, derive, fused=False, fw=0):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
     (profiles/r01_pmc_hbm_traffic_final.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and re-verified on the
@@ -228,6 +244,8 @@ def pmc_traffic(workload, waves, rows, derive):
     import csv
     path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.csv")
     want = f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>"
+    if fused:
+        want = f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>"
     try:
         for row in csv.DictReader(open(path)):
             if row["workload"] == workload and want in row["kernel"]:
@@ -303,6 +321,13 @@ def main():
     ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
     ctx.evp_set_option("derive_metrics", 0 if args.no_derive else 1)
     derive = bool(ctx.evp_get_info("derive_metrics"))
+    ctx.evp_set_option("fuse", 0 if args.no_fuse else 1)
+    if args.fused_waves:
+        ctx.evp_set_option("fused_waves", args.fused_waves)
+    fused = bool(ctx.evp_get_info("fused"))
+    if fused:
+        fw = ctx.evp_get_info("fused_waves")
+        tile = f"two subcycles per launch; workgroup {fw} wavefronts x 64 lanes owns {fw - 3} rows x 59 columns"
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
     nt, nu = ctx.evp_active_cells()
@@ -383,10 +408,14 @@ def main():
     if rank == 0:
         # dominant kernel: the fused subcycle kernel, one launch per subcycle over the rank's
         # active T-cells; HIP-event time of the launches on the library's stream / launches
-        us_per_launch = dev_ms * 1e3 / nsub_total
-        bytes_per_launch = EVP_BYTES_PER_CELL * (nt_all / world)
+        n_launch = launches_per_step(ndte, fused, dom.get("overlap", 0)) * args.steps
+        us_per_launch = dev_ms * 1e3 / n_launch
+        units_per_launch = (nt_all / world) * nsub_total / n_launch     # cell-subcycles one launch processes
+        bytes_per_launch = EVP_BYTES_PER_CELL * units_per_launch
         achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-        traffic, traffic_src = (pmc_traffic(args.workload, waves, rows, derive) if world == 1 else (None, None))
+        kname = ("k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
+                 else "k_subcycle (fused stress + stepu + on-rank halo)")
+        traffic, traffic_src = (pmc_traffic(args.workload, waves, rows, derive, fused, fw if fused else 0) if world == 1 else (None, None))
         out = {
             "metric": "EVP subcycles/sec", "value": value, "unit": "subcycles/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_evp / args.steps,
@@ -404,9 +433,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": "k_subcycle (fused stress + stepu + on-rank halo)",
+                         "kernel": kname,
                          "us_per_launch": us_per_launch, "bytes_per_unit": EVP_BYTES_PER_CELL,
-                         "units_per_launch": nt_all / world},
+                         "units_per_launch": units_per_launch, "unit_of_work": "active T-cell x subcycle",
+                         "subcycles_per_launch": nsub_total / n_launch},
         }
         if thermo:
             out["thermo"] = thermo

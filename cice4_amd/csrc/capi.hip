@@ -306,6 +306,8 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   if (!std::strcmp(key, "derive_metrics")) *value = c_->evp->derives_metrics() ? 1 : 0;
   else if (!std::strcmp(key, "waves")) *value = c_->evp->tile_waves();
   else if (!std::strcmp(key, "rows_per_wave")) *value = c_->evp->tile_rows();
+  else if (!std::strcmp(key, "fused")) *value = c_->evp->can_fuse() ? 1 : 0;
+  else if (!std::strcmp(key, "fused_waves")) *value = c_->evp->fused_waves();
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
   CICE_CATCH
 }

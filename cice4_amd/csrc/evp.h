@@ -8,6 +8,8 @@
 
 namespace cice {
 
+struct SubArgs;  // kernel argument block (evp.hip)
+
 struct EvpScalars {  // set_evp_parameters, ice_dyn_evp.F90:535-577
   double dtei, dte2T, denom1, denom2, rcon, ecci;
   int ndte, evp_damping;
@@ -34,6 +36,8 @@ class Evp {
   bool derives_metrics() const;
   int tile_waves() const { return waves; }
   int tile_rows() const { return rows_per_wave; }
+  bool can_fuse() const;     // two subcycles per launch on this domain
+  int fused_waves() const;   // wavefronts per workgroup of the fused kernel
 
   // one-block, host-pointer entries with the reference argument lists
   static void stress_host(hipStream_t s, double dt, int ndte, int damping, int nx, int ny, int ksub,
@@ -54,6 +58,9 @@ class Evp {
   bool ready = false, prepared = false;
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
+  bool fuse_on = true;
+  int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
+  int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop
   bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)
   size_t n = 0;  // nblocks*ny*nx
   int cur = 0;   // which ping-pong copy of u, v, sigma holds the current values
@@ -84,6 +91,10 @@ class Evp {
   int graph_key[4] = {-1, -1, -1, -1};
 
   void launch_subcycle(int ksub);
+  void launch_subcycle_pair(int ksub);
+  void launch_range(int ksub0, int nsub);
+  void after_subcycle(int ksub);
+  SubArgs make_args() const;
   void drop_graph();
 };
 

@@ -175,9 +175,12 @@ __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu,
   o.v = (cca * cc2 - ccb * cc1) / ab2;
 }
 
+}  // namespace
+
 struct SubArgs {
   EvpScalars sc;
   int nx, ny, tiles_x, tiles_y, nblocks;
+  int ew_cyclic;  // k_subcycle2: columns of a block form a ring
   size_t n;  // nblocks*ny*nx
   // no two of these arrays overlap (inputs and outputs of the double-buffered fields are
   // different allocations), which lets the compiler issue loads ahead of stores
@@ -203,6 +206,9 @@ struct SubArgs {
       *__restrict__ prs_sig, *__restrict__ strintx, *__restrict__ strinty, *__restrict__ strocnx,
       *__restrict__ strocny;
 };
+
+namespace {
+
 
 constexpr int TX = 64;  // T-cells per tile row = one wavefront
 
@@ -426,6 +432,243 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
     const double sx = p0 + pe1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];
     const double sy = p4 + s_edge[w + 1][2][lx] + pe6 + s_edge[w + 1][3][lx];
     stepu_store<LAST>(a, xl, qu_last, i, ju_last, ilo, ihi, jlo, jhi, us, vs, sx, sy);
+  }
+}
+
+// TWO EVP subcycles in one launch (ice_dyn_evp.F90:353-402 twice).
+//
+// sigma is 24 of the ~41 words a cell moves per subcycle and every other input is read-only, so
+// running subcycles k and k+1 back to back on a tile halves the traffic per subcycle (sigma, u, v
+// and the inputs cross HBM once per PAIR) and halves the launches.  The price is a redundant rim:
+// a workgroup of W wavefronts x 64 lanes owns (W-3) rows x 59 columns.
+//
+// Wavefront w keeps T-row jt+w, a lane keeps one column; everything a cell needs for the second
+// subcycle (its 12 stresses, metrics, strength, the U-cell inputs) is already in its lane's
+// registers.  Only the intermediate velocity has to travel: west neighbour by shuffle, row below
+// through LDS (one row of u, v per wavefront), exactly like `str`.
+//   stage 1: stress on every T-cell of the tile -> str -> u' on rows/lanes that have their N/E
+//            neighbours in the tile (w <= W-2, lane <= 62); nothing is stored;
+//   stage 2: stress with u' -> sigma'' (valid for 1 <= w <= W-2) -> u'' (valid for 1 <= w <= W-3);
+//            owners store sigma'', u'', v'' (+ the LAST diagnostics) and forward u'', v'' to
+//            the ghost cells that mirror them.
+// Ghost cells: rows beyond the block (j = jlo-1, jhi+1) hold values that do not change during the
+// subcycling (open/closed domain edge, or rows beyond the overlap of a wide-halo slab), so their u'
+// is their u.  Columns: the east ghost T-cell G = (ihi+1, j) has its own sigma (the reference
+// computes it separately, :850-859) but its velocity mirrors column ilo, and the west ghost
+// velocity mirrors column ihi.  Lanes therefore walk the block's columns as a ring
+// ..., ihi-1, ihi, G, ilo, ilo+1, ...: the first tile starts two positions before ilo (at ihi, G)
+// and the last one runs past G into ilo, ilo+1, so every tile computes the mirrored u' it needs
+// itself.  Two exceptions to "west neighbour = lane-1" follow from the ring: the lane at ilo takes
+// u' of ihi from lane-2 (G sits in between), and G takes its own-column u' from lane+1 (= ilo).
+// With an open/closed E-W edge there is no ring: the ghost columns keep their values.
+//
+// Used when no ghost ROW of a local block changes between two subcycles (one block over the full
+// width per rank, or wide-halo slabs with an even overlap); otherwise k_subcycle runs.
+constexpr int OWN_LANE0 = 2, OWN_LANES = 59;  // lanes 2..60 own their column
+
+template <int W, bool LAST, bool DAMP, bool DERIVE>
+__global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_subcycle2(const SubArgs a) {
+  __shared__ double s_str[W][4][TX];
+  __shared__ double s_uv[W][2][TX];
+  const int per_blk = a.tiles_x * a.tiles_y;
+  const int nt = per_blk * a.nblocks;
+  const int chunk = (nt + 7) >> 3;
+  const int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile_lin >= nt) return;  // whole workgroup
+  const int b = tile_lin / per_blk;
+  const int rem = tile_lin - b * per_blk;
+  const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
+  const int ilo = a.blk[6 * b + 0], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2],
+            jhi = a.blk[6 * b + 3];
+  const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nx = a.nx;
+  const size_t base = (size_t)b * nx * a.ny;
+  const bool cyc = a.ew_cyclic != 0;
+
+  // column: ring position k (0 = ilo, ncol = G) -> memory column
+  const int ncol = ihi - ilo + 1;
+  const int kraw = txi * OWN_LANES + lx - OWN_LANE0;
+  int col = -1;
+  if (cyc) {
+    int k = kraw % (ncol + 1);
+    if (k < 0) k += ncol + 1;
+    col = ilo + k;  // k == ncol -> ihi+1 = G
+  } else if (kraw >= -1 && kraw <= ncol) {
+    col = ilo + kraw;  // -1 -> the west ghost column
+  }
+  const bool col_ok = col >= 1;
+  const bool isG = col == ihi + 1;
+  const bool at_ilo = col == ilo;
+  const bool own_col = lx >= OWN_LANE0 && lx < OWN_LANE0 + OWN_LANES && kraw >= 0 && kraw <= ncol;
+  // row
+  const int j = jlo - 1 + tyi * (W - 3) + w;
+  const bool row_ok = j <= jhi + 1;                    // j >= jlo-1 = 1 always
+  const bool own_row = w >= 1 && w <= W - 3 && row_ok;
+  const bool tcell = col_ok && row_ok && j >= jlo && col >= ilo;       // (col <= ihi+1, j <= jhi+1 hold)
+  const bool ucell = col_ok && j >= jlo && j <= jhi && col >= ilo && col <= ihi;
+  const size_t q = base + (size_t)(j - 1) * nx + (size_t)(col_ok ? col - 1 : 0);
+  const bool ld = col_ok && row_ok;
+  const bool reload_w = lx == 0 || at_ilo;             // west neighbour from memory, not from lane-1
+
+  // ---- loads (once for both subcycles) ----
+  double un = c0, vn = c0, us = c0, vs = c0;
+  if (ld) {
+    un = a.u_in[q];
+    vn = a.v_in[q];
+    if (j >= 2) {
+      us = a.u_in[q - nx];
+      vs = a.v_in[q - nx];
+    }
+  }
+  double uw = __shfl_up(un, 1), vw = __shfl_up(vn, 1), usw = __shfl_up(us, 1), vsw = __shfl_up(vs, 1);
+  if (reload_w && ld && col >= 2) {
+    uw = a.u_in[q - 1];
+    vw = a.v_in[q - 1];
+    if (j >= 2) {
+      usw = a.u_in[q - nx - 1];
+      vsw = a.v_in[q - nx - 1];
+    }
+  }
+  const bool tact = tcell && a.icetmask[q] == 1;
+  const bool uact = ucell && a.iceumask[q] != 0;
+  double s[12];
+  // T-cell metrics: DERIVE keeps the four primary lengths and forms the nine metrics in each stage
+  // (registers); otherwise the nine loaded values are kept
+  double hn = c0, he = c0, hn_s = c0, hew = c0;
+  double Dxt = c0, Dyt = c0, Dxhy = c0, Dyhx = c0, Cxp = c0, Cyp = c0, Cxm = c0, Cym = c0, Tiny = c0,
+         St = c0, Tarear = c0;
+  {
+    if (DERIVE) {
+      if (ld) {
+        hn = a.HTN[q];
+        he = a.HTE[q];
+        if (j >= 2) hn_s = a.HTN[q - nx];
+      }
+      hew = __shfl_up(he, 1);
+      if (reload_w && ld && col >= 2) hew = a.HTE[q - 1];
+    }
+    if (tact) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
+      if (!DERIVE) {
+        Dxt = a.dxt[q]; Dyt = a.dyt[q]; Dxhy = a.dxhy[q]; Dyhx = a.dyhx[q]; Cxp = a.cxp[q];
+        Cyp = a.cyp[q]; Cxm = a.cxm[q]; Cym = a.cym[q]; Tiny = a.tinyarea[q];
+      }
+      St = a.strength[q];
+      if (LAST) Tarear = a.tarear[q];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) s[c] = c0;
+    }
+  }
+  auto metrics = [&]() {
+    if (DERIVE) {
+      Dxt = p5 * (hn + hn_s);                 // ice_grid.F90:1184 (dxt)
+      Dyt = p5 * (he + hew);                  // :1271 (dyt)
+      Dxhy = p5 * (he - hew);                 // :347
+      Dyhx = p5 * (hn - hn_s);                // :348
+      Cyp = 1.5 * he - p5 * hew;              // :354
+      Cxp = 1.5 * hn - p5 * hn_s;             // :355
+      Cym = -(1.5 * hew - p5 * he);           // :357
+      Cxm = -(1.5 * hn_s - p5 * hn);          // :358
+      Tiny = puny * (Dxt * Dyt);              // :334, :346
+    }
+  };
+
+  // ---- subcycle k: stress, str, u' ----
+  StressOut o;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o.str[c] = c0;
+  if (tact) {
+    metrics();
+    stress_cell<false, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm,
+                             Cym, 0.0, Tiny, St, s, o);
+  }
+  double e1 = __shfl_down(o.str[1], 1), e3 = __shfl_down(o.str[3], 1), e6 = __shfl_down(o.str[6], 1),
+         e7 = __shfl_down(o.str[7], 1);
+  s_str[w][0][lx] = o.str[2];
+  s_str[w][1][lx] = e3;
+  s_str[w][2][lx] = o.str[5];
+  s_str[w][3][lx] = e7;
+  __syncthreads();
+  double u1 = un, v1 = vn;   // velocity of this lane's own column after subcycle k
+  if (uact && lx < TX - 1 && w < W - 1) {
+    const double sx = o.str[0] + e1 + s_str[w + 1][0][lx] + s_str[w + 1][1][lx];   // :1415-1416 order
+    const double sy = o.str[4] + s_str[w + 1][2][lx] + e6 + s_str[w + 1][3][lx];   // :1417-1418 order
+    UIn x;   // fetched for each of the two momentum updates (L2 hits the second time): they would
+             // otherwise occupy 16-20 registers across both stress evaluations
+    load_uin<DERIVE>(a, q, x);
+    StepuOut r;
+    stepu_cell(un, vn, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
+               x.uarear, sx, sy, r);
+    u1 = r.u;
+    v1 = r.v;
+  }
+  // The ring applies to rows whose velocity is updated (jlo..jhi): there the ghost columns mirror
+  // the opposite edge after every subcycle (:397-402).  On the ghost rows nothing ever changes,
+  // and their corner ghosts keep whatever they hold.
+  const bool mirror_n = cyc && j >= jlo && j <= jhi, mirror_s = cyc && j - 1 >= jlo && j - 1 <= jhi;
+  const double gu = __shfl_down(u1, 1), gv = __shfl_down(v1, 1);   // G mirrors column ilo = next lane
+  const double un1 = (isG && mirror_n) ? gu : u1, vn1 = (isG && mirror_n) ? gv : v1;
+  s_uv[w][0][lx] = un1;
+  s_uv[w][1][lx] = vn1;
+  __syncthreads();
+
+  // ---- subcycle k+1 ----
+  double us1 = us, vs1 = vs;   // wavefront 0 owns nothing: any value will do there
+  if (w > 0) {
+    us1 = s_uv[w - 1][0][lx];
+    vs1 = s_uv[w - 1][1][lx];
+  }
+  double uw1 = __shfl_up(un1, 1), vw1 = __shfl_up(vn1, 1), usw1 = __shfl_up(us1, 1), vsw1 = __shfl_up(vs1, 1);
+  {
+    // at ilo the west neighbour is column ihi, two lanes to the left (G sits in between), or,
+    // where nothing mirrors, the ghost column's own unchanged value
+    const double uw2 = __shfl_up(un1, 2), vw2 = __shfl_up(vn1, 2), usw2 = __shfl_up(us1, 2),
+                 vsw2 = __shfl_up(vs1, 2);
+    if (at_ilo) {
+      uw1 = uw2; vw1 = vw2; usw1 = usw2; vsw1 = vsw2;
+      if (!mirror_n && ld) {   // unchanged ghost value: read it again rather than keep it in registers
+        uw1 = a.u_in[q - 1];
+        vw1 = a.v_in[q - 1];
+      }
+      if (!mirror_s && ld && j >= 2) {
+        usw1 = a.u_in[q - nx - 1];
+        vsw1 = a.v_in[q - nx - 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) o.str[c] = c0;
+  if (tact) {
+    metrics();
+    stress_cell<LAST, DAMP>(a.sc, un1, uw1, usw1, us1, vn1, vw1, vsw1, vs1, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp,
+                            Cxm, Cym, Tarear, Tiny, St, s, o);
+    if (own_col && own_row) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
+      if (LAST) {
+        a.divu[q] = o.divu;
+        a.rdg_conv[q] = o.rdg_conv;
+        a.rdg_shear[q] = o.rdg_shear;
+        a.shear[q] = o.shear;
+        a.prs_sig[q] = o.prs_sig;
+      }
+    }
+  }
+  e1 = __shfl_down(o.str[1], 1); e3 = __shfl_down(o.str[3], 1);
+  e6 = __shfl_down(o.str[6], 1); e7 = __shfl_down(o.str[7], 1);
+  s_str[w][0][lx] = o.str[2];   // stage-1 values were consumed before the previous barrier
+  s_str[w][1][lx] = e3;
+  s_str[w][2][lx] = o.str[5];
+  s_str[w][3][lx] = e7;
+  __syncthreads();
+  if (uact && own_col && own_row) {
+    const double sx = o.str[0] + e1 + s_str[w + 1][0][lx] + s_str[w + 1][1][lx];
+    const double sy = o.str[4] + s_str[w + 1][2][lx] + e6 + s_str[w + 1][3][lx];
+    UIn x;
+    load_uin<DERIVE>(a, q, x);
+    stepu_store<LAST>(a, x, q, col, j, ilo, ihi, jlo, jhi, u1, v1, sx, sy);
   }
 }
 
@@ -778,6 +1021,11 @@ void Evp::set_option(const char* key, int value) {
     derive_on = value != 0;
   } else if (!std::strcmp(key, "use_graph")) {
     use_graph = value != 0;
+  } else if (!std::strcmp(key, "fuse")) {          // two subcycles per launch where the domain allows
+    fuse_on = value != 0;
+  } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
+    CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 16, "fused_waves must be 0, 8, 12 or 16");
+    waves2 = value;
   } else {
     throw Error{CICE_EINVAL, std::string("unknown option ") + key};
   }
@@ -993,13 +1241,10 @@ static void launch_wr(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_
   else launch_wrd<W, R, false>(a, last, damp, g, s);
 }
 
-void Evp::launch_subcycle(int ksub) {
+SubArgs Evp::make_args() const {
   SubArgs a{};
   a.sc = sc; a.nx = dom.nx_block; a.ny = dom.ny_block; a.n = n; a.nblocks = dom.nblocks();
-  const int trows = waves * rows_per_wave;
-  // physical extent of a block (a wide-halo slab is bsy + 2*overlap rows tall)
-  a.tiles_x = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
-  a.tiles_y = ((dom.ny_block - 2) + (trows - 1) - 1) / (trows - 1);
+  a.ew_cyclic = dom.ew == BND_CYCLIC ? 1 : 0;
   const bool fwd = halo.fwd_ok();
   a.ring_slot = fwd ? halo.d_ring_slot() : nullptr; a.fwd = halo.d_fwd();
   a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
@@ -1014,6 +1259,15 @@ void Evp::launch_subcycle(int ksub) {
   a.divu = divu.p; a.rdg_conv = rdg_conv.p; a.rdg_shear = rdg_shear.p; a.shear = shear.p;
   a.prs_sig = prs_sig.p; a.strintx = strintx.p; a.strinty = strinty.p; a.strocnx = strocnx.p;
   a.strocny = strocny.p;
+  return a;
+}
+
+void Evp::launch_subcycle(int ksub) {
+  SubArgs a = make_args();
+  const int trows = waves * rows_per_wave;
+  // physical extent of a block (a wide-halo slab is bsy + 2*overlap rows tall)
+  a.tiles_x = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+  a.tiles_y = ((dom.ny_block - 2) + (trows - 1) - 1) / (trows - 1);
   const int nt = a.tiles_x * a.tiles_y * a.nblocks;
   const dim3 g(8 * ((nt + 7) / 8));
   const bool last = (ksub == sc.ndte), damp = sc.evp_damping != 0;
@@ -1030,7 +1284,14 @@ void Evp::launch_subcycle(int ksub) {
     case 1602: launch_wr<16, 2>(a, last, damp, g, stream); break;
     default: throw Error{CICE_EINVAL, "unsupported (waves, rows_per_wave) combination"};
   }
+  after_subcycle(ksub);
+}
+
+// The double-buffered fields now live in the other copy; ghost cells owned elsewhere.
+void Evp::after_subcycle(int ksub) {
+  const bool fwd = halo.fwd_ok();
   cur = 1 - cur;
+  ++flips;
   // On-rank ghost cells were written by the kernel itself.  Rows owned by other blocks/ranks:
   // classic domain -> every subcycle (:397-402); wide-halo domain -> u, v and sigma every
   // `overlap` subcycles and after the last one (the overlap rows are recomputed in between and
@@ -1040,6 +1301,98 @@ void Evp::launch_subcycle(int ksub) {
     else if (!fwd) halo.update_r8(uv[cur].p, 2, n, true);
   } else if (halo.has_refresh() || !fwd) {
     halo.update_r8(uv[cur].p, 2, n, /*wrap=*/!fwd);
+  }
+}
+
+template <int W, bool DERIVE>
+static void launch2_wd(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+  const dim3 blk(64 * W);
+  if (last) {
+    if (damp) hipLaunchKernelGGL((k_subcycle2<W, true, true, DERIVE>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle2<W, true, false, DERIVE>), g, blk, 0, s, a);
+  } else {
+    if (damp) hipLaunchKernelGGL((k_subcycle2<W, false, true, DERIVE>), g, blk, 0, s, a);
+    else hipLaunchKernelGGL((k_subcycle2<W, false, false, DERIVE>), g, blk, 0, s, a);
+  }
+}
+
+template <int W>
+static void launch2_w(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_t s) {
+  if (a.HTN) launch2_wd<W, true>(a, last, damp, g, s);
+  else launch2_wd<W, false>(a, last, damp, g, s);
+}
+
+// Two subcycles per launch are possible when no ghost ROW of a local block changes between two
+// consecutive subcycles: every block spans the full width (its E/W ghost columns mirror itself or
+// lie beyond an open edge and are handled inside the kernel), and its N/S ghost rows either lie
+// beyond an open/closed domain edge or belong to a wide-halo slab that is refreshed only every
+// `overlap` (even) subcycles.
+bool Evp::can_fuse() const {
+  if (!fuse_on || !halo.fwd_ok()) return false;
+  if (dom.nbx != 1) return false;
+  if (dom.overlap > 0) return dom.overlap % 2 == 0;
+  return dom.nby == 1 && dom.ns != BND_CYCLIC && !halo.has_refresh();
+}
+
+int Evp::fused_waves() const {
+  if (waves2) return waves2;
+  // Workgroups are dealt evenly to the CUs, so a launch lasts about ceil(workgroups / CUs) x W
+  // wavefront-times (measured: gx3 9.9 / 12.5 / 15.4 us, gx1 17.6 / 25.4 / 17.8 us, 0.1 degree
+  // 944 / 968 / 857 us for W = 8 / 12 / 16).  Taller workgroups own a larger share of their rows
+  // ((W-3)/W) but quantise worse on small grids.
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  const long long cols = dom.nx_block - 1, rows = dom.ny_block - 1;
+  const long long tx = (cols + OWN_LANES - 1) / OWN_LANES;
+  int best = 8;
+  long long best_cost = -1;
+  for (int w : {8, 16, 12}) {
+    const long long wg = tx * ((rows + (w - 3) - 1) / (w - 3)) * dom.nblocks();
+    const long long cost = ((wg + ncu - 1) / ncu) * w;
+    if (best_cost < 0 || cost < best_cost) {
+      best = w;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+// subcycles ksub and ksub+1
+void Evp::launch_subcycle_pair(int ksub) {
+  SubArgs a = make_args();
+  const int W = fused_waves();
+  a.tiles_x = ((dom.nx_block - 2) + 1 + OWN_LANES - 1) / OWN_LANES;
+  a.tiles_y = ((dom.ny_block - 2) + 1 + (W - 3) - 1) / (W - 3);
+  const int nt = a.tiles_x * a.tiles_y * a.nblocks;
+  const dim3 g(8 * ((nt + 7) / 8));
+  const bool last = (ksub + 1 == sc.ndte), damp = sc.evp_damping != 0;
+  switch (W) {
+    case 8: launch2_w<8>(a, last, damp, g, stream); break;
+    case 12: launch2_w<12>(a, last, damp, g, stream); break;
+    case 16: launch2_w<16>(a, last, damp, g, stream); break;
+    default: throw Error{CICE_EINVAL, "fused_waves must be 8, 12 or 16"};
+  }
+  after_subcycle(ksub + 1);
+}
+
+// subcycles ksub0 .. ksub0+nsub-1: pairs where possible
+void Evp::launch_range(int ksub0, int nsub) {
+  const bool fuse = can_fuse();
+  const int end = ksub0 + nsub - 1;
+  for (int k = ksub0; k <= end;) {
+    // a wide-halo refresh falls after subcycles that are multiples of `overlap` (even): a pair must
+    // not straddle one, i.e. it has to start on an odd subcycle
+    const bool pair = fuse && k + 1 <= end && !(dom.overlap > 0 && k % dom.overlap == 0);
+    if (pair) {
+      launch_subcycle_pair(k);
+      k += 2;
+    } else {
+      launch_subcycle(k);
+      k += 1;
+    }
   }
 }
 
@@ -1059,7 +1412,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   const bool graph_ok = use_graph && nsub > 1 && !(halo.multi_rank() && no_comm_graph);
   bool replayed = false;
   if (graph_ok) {
-    const int key[4] = {cur, ksub0, nsub, (waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)};
+    const int key[4] = {cur, ksub0, nsub,
+                        ((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2};
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();
@@ -1068,7 +1422,9 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
       try {
         CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         capturing = true;
-        for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+        flips = 0;
+        launch_range(ksub0, nsub);
+        graph_flips = flips;
         capturing = false;
         CICE_HIP(hipStreamEndCapture(stream, &gph));
         CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
@@ -1086,12 +1442,11 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     }
     if (graph_exec) {
       CICE_HIP(hipGraphLaunch(graph_exec, stream));
-      if (nsub & 1) cur = 1 - cur;
+      if (graph_flips & 1) cur = 1 - cur;
       replayed = true;
     }
   }
-  if (!replayed)
-    for (int k = 0; k < nsub; ++k) launch_subcycle(ksub0 + k);
+  if (!replayed) launch_range(ksub0, nsub);
   CICE_HIP(hipGetLastError());
   if (elapsed_ms) {
     CICE_HIP(hipEventRecord(e1, stream));

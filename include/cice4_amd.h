@@ -147,9 +147,13 @@ int cice_evp_prepare(cice_ctx *ctx, double dt);
 int cice_evp_subcycles(cice_ctx *ctx, int ksub0, int nsub, float *elapsed_ms);
 int cice_evp_finish(cice_ctx *ctx);
 /* tuning / A-B switches: "waves" (wavefronts per workgroup: 4, 8, 16), "rows_per_wave" (T-rows
- * per wavefront: 1, 2, 4, 8), "use_graph" (0/1), "derive_metrics" (0/1, see cice_evp_grid).
+ * per wavefront: 1, 2, 4, 8), "use_graph" (0/1), "derive_metrics" (0/1, see cice_evp_grid),
+ * "fuse" (0/1: two subcycles per launch where no ghost row of a local block changes between
+ * subcycles -- one full-width block per rank or wide-halo slabs with an even overlap),
+ * "fused_waves" (0 = auto, 8, 12, 16).
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
- * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave". */
+ * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
+ * (1 if this domain runs two subcycles per launch), "fused_waves". */
 int cice_evp_set_option(cice_ctx *ctx, const char *key, int value);
 int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare

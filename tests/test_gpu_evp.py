@@ -401,7 +401,7 @@ def _owned(dom, f):
     return g
 
 
-@pytest.mark.parametrize("overlap,selfcomm", [(0, False), (1, False), (4, False), (7, False), (4, True), (7, True)])
+@pytest.mark.parametrize("overlap,selfcomm", [(0, False), (1, False), (2, False), (4, False), (7, False), (4, True), (6, True), (7, True)])
 def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm):
     """Wide-halo j-slabs: the overlap rows are recomputed and refreshed (u, v, 12 sigma in one
     message) only every `overlap` subcycles.  Owned rows must equal the single-domain checker run
@@ -437,3 +437,63 @@ def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm
     nt1, nu1 = c1.evp_active_cells()
     assert nu == nu1                                # overlap rows are not counted twice
     assert nt1 <= nt <= nt1 + nb * (nxg + 2)        # T lists: each block also lists its N/E ghost ring
+
+
+def _evp_with(ctx, grid, s, ndte, damping, **opts):
+    sg = {k: v.copy() for k, v in s.items()}
+    ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+    for k, v in opts.items():
+        ctx.evp_set_option(k, v)
+    info = (ctx.evp_get_info("fused"), ctx.evp_get_info("fused_waves"))
+    ctx.evp(DT, sg)
+    return sg, info
+
+
+@pytest.mark.parametrize("nxg,nyg,ew", [(96, 70, 1), (20, 33, 1), (57, 18, 1), (58, 18, 1), (59, 18, 1),
+                                         (117, 9, 1), (118, 41, 1), (119, 5, 1), (200, 50, 1), (96, 70, 0),
+                                         (130, 27, 2), (7, 6, 1)])
+def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
+    """k_subcycle2 (two subcycles per launch, redundant rim, E-W ring handled inside the kernel) against
+    k_subcycle (one per launch) and the checker: bit for bit.  Widths around the 59-column tile
+    stride, blocks narrower than a tile (the ring wraps inside one wavefront), open / closed E-W
+    edges; even and odd ndte (an odd count ends with a single-subcycle launch); damping; all
+    workgroup heights; loaded vs recomputed metrics; graph replay and eager."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
+    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    for ndte, damping in ((NDTE, False), (7, True), (2, False)):
+        ref, info = _evp_with(ctx, grid, s, ndte, damping, fuse=0)
+        assert info[0] == 0
+        if (ndte, damping) == (NDTE, False):
+            orc.set_evp_parameters(DT, ndte, damping); orc.set_strength_parameters(1, 0, 0, 4.0)
+            so = {k: v.copy() for k, v in s.items()}
+            orc.evp(orc.make_domain(dom, grid), so)
+            orc.set_strength_parameters()
+            for k in keys:
+                assert np.array_equal(ref[k], so[k]), ("unfused vs checker", k)
+        for opts in (dict(fused_waves=8), dict(fused_waves=12), dict(fused_waves=16), dict(),
+                     dict(derive_metrics=0), dict(use_graph=0)):
+            got, info = _evp_with(ctx, grid, s, ndte, damping, fuse=1, **opts)
+            assert info[0] == 1 and info[1] in (8, 12, 16)
+            for k in keys:
+                assert np.array_equal(got[k], ref[k]), (ndte, damping, opts, k)
+
+
+def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
+    """Several blocks per rank without overlap rows, or a cyclic N-S edge: ghost rows are refreshed
+    after every subcycle, so the one-subcycle kernel must run."""
+    for args, kw in (((96, 70, 48, 35), dict(ew=1, ns=0)), ((96, 70, 96, 35), dict(ew=1, ns=0)),
+                     ((96, 70, 96, 70), dict(ew=1, ns=1))):
+        dom = ctx.domain_create(*args, **kw)
+        gg = synth.global_grid(args[0], args[1], perturb=0.1, seed=3)
+        grid = synth.block_fields(gg, dom)
+        ctx.evp_init(grid, ndte=4)
+        assert ctx.evp_get_info("fused") == 0
+    dom = ctx.domain_create_slabs(96, 72, 4, ew=1, ns=0, overlap=3)   # odd overlap
+    ctx.evp_init(synth.block_fields(synth.global_grid(96, 72, seed=3), dom), ndte=4)
+    assert ctx.evp_get_info("fused") == 0
+    dom = ctx.domain_create_slabs(96, 72, 4, ew=1, ns=0, overlap=4)
+    ctx.evp_init(synth.block_fields(synth.global_grid(96, 72, seed=3), dom), ndte=4)
+    assert ctx.evp_get_info("fused") == 1
