@@ -242,7 +242,7 @@ def pmc_traffic(workload, waves, rows, derive, fused=False, fw=0):
     same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and re-verified on the
     k_diag_copy8 calibration stream).  None if no pass exists for this kernel variant."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_final.csv")
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_fused.csv" if fused else "r01_pmc_hbm_traffic_final.csv")
     want = f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>"
     if fused:
         want = f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>"
