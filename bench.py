@@ -37,12 +37,26 @@ THERMO_BYTES_PER_COLUMN = 304.0  # per (cell,category) update (+376 B per cell s
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def workload(name):
+    if name in WORKLOADS:
+        return WORKLOADS[name]
+    try:
+        parts = [int(x) for x in name.lower().split("x")]
+        nxg, nyg = parts[0], parts[1]
+        ndte = parts[2] if len(parts) > 2 else 120
+    except (ValueError, IndexError):
+        raise SystemExit(f"unknown workload {name!r}")
+    return (nxg, nyg, ndte, f"diagnostic {nxg}x{nyg} rectangular synthetic grid, full ice cover, ncat=5, ndte={ndte}")
+
+
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="gx1", choices=sorted(WORKLOADS))
+    p.add_argument("--workload", default="gx1",
+                   help="gx3, gx1, tenth, or NXxNY[xNDTE] (diagnostic: a synthetic grid of that size, e.g. the "
+                        "320x72 slab one of 8 ranks works on at gx1)")
     p.add_argument("--waves", type=int, default=0, help="wavefronts per EVP workgroup (4/8/16); 0 = auto")
     p.add_argument("--rows", type=int, default=0, help="T-rows per wavefront (1/2/4/8); 0 = auto")
     p.add_argument("--no-graph", action="store_true")
@@ -108,7 +122,7 @@ def launches_per_step(ndte, fused, overlap):
 
 
 def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
-    nxg, nyg, ndte, _ = WORKLOADS[wl]
+    nxg, nyg, ndte, _ = workload(wl)
     if nyg % world:
         raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
     if world == 1 and slabs > 1:
@@ -421,7 +435,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_evp / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": WORKLOADS[args.workload][3], "nx_global": dom["nxg"],
+            "config": {"workload": workload(args.workload)[3], "nx_global": dom["nxg"],
                        "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
                        "decomposition": f"1x{world} j-slabs, one block per GPU" + (
                            f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
