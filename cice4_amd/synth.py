@@ -150,9 +150,10 @@ def block_fields(gg, dom, ew_cyclic=True):
 # ----------------------------------------------------------------------------
 # ice state for EVP
 # ----------------------------------------------------------------------------
-def evp_state(grid, dom, seed=20261003, cover="full", moving=True):
+def evp_state(grid, dom, seed=20261003, cover="full", moving=True, ice_mask=None):
     """Module-array-shaped inputs of evp(dt) (ice_dyn_evp.F90:119) for the blocks in dom.
-    cover: 'full' (ice on every ocean cell), 'patchy' (ice-free regions, thin-ice edges)."""
+    cover: 'full' (ice on every ocean cell), 'patchy' (ice-free regions, thin-ice edges).
+    ice_mask: optional boolean (nblocks, ny, nx): ice only there (e.g. the polar caps of a real grid)."""
     rng = np.random.default_rng(seed)
     nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
     shp = (nb, ny, nx)
@@ -176,6 +177,8 @@ def evp_state(grid, dom, seed=20261003, cover="full", moving=True):
         hole = field(1, 0.0, 1.0)
         conc = np.where(hole < 0.35, 0.0, conc * np.clip((hole - 0.35) / 0.15, 0.0, 1.0))
     conc = np.where(tm, conc, 0.0)
+    if ice_mask is not None:
+        conc = np.where(ice_mask, conc, 0.0)
     w = np.array([0.1, 0.2, 0.3, 0.25, 0.15])
     aicen = np.zeros((nb, NCAT, ny, nx)); vicen = np.zeros_like(aicen); vsnon = np.zeros_like(aicen)
     for n in range(NCAT):

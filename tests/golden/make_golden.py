@@ -12,6 +12,7 @@ Run from the repo root in the build container:  python tests/golden/make_golden.
                     the reference's own arrays), outputs = module arrays after `call evp(dt)`.
   stress_stepu.npz  one call of `stress` (ksub = ndte, so the strain-rate diagnostics are
                     written) and of `stepu` on a 20x16 block with random index lists.
+  evp_gx3.npz       whole `evp(dt)` on the reference's own gx3 displaced-pole grid and land mask (100x116)
   thermo_known_tsfc.npz  `thermo_vertical` with calc_Tsfc = F (surface fluxes given), 10x12 block
   thermo_cols.npz   `thermo_vertical` on a 10x12 block: conduct='MU71' 5 categories x 3 regimes,
                     conduct='bubbly' 2 categories.
@@ -73,6 +74,50 @@ def evp_small(ref):
         data["dom_" + k] = dom[k]
     data["meta"] = meta()
     np.savez_compressed(os.path.join(HERE, "evp_small.npz"), **data)
+
+
+GX3_GRID = ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear", "uarear",
+            "tinyarea", "fcor", "HTN", "HTE", "TLAT", "ULAT")
+
+
+def evp_gx3():
+    """evp(dt) on the reference's OWN gx3 grid: displaced-pole metrics and land mask read by the
+    reference's init_grid1/2 from input_templates/gx3/global_gx3.{grid,kmt} (100x116, one block), ice on
+    the two polar caps (|lat| > 55 deg, patchy), ndte = 120.  The grid arrays in the fixture are the
+    reference's module arrays after its own initialisation -- numbers, not files."""
+    ref = refapi.Ref("gx3")
+    d = os.path.join(os.environ.get("CICE_REFERENCE_ROOT", "/root/reference"), "input_templates", "gx3")
+    nb = ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE, grid="displaced_pole",
+                         grid_file=os.path.join(d, "global_gx3.grid"), kmt_file=os.path.join(d, "global_gx3.kmt"))
+    assert nb == 1
+    ref.set_strength_parameters()
+    ctx = lib.Context()
+    dom = ctx.domain_create(100, 116, 100, 116, ew=1, ns=0)
+    grid = {k: ref.get(k) for k in GX3_GRID}
+    grid["tmask"] = ref.get("tmask").astype(np.int32); grid["umask"] = ref.get("umask").astype(np.int32)
+    cap = np.abs(grid["TLAT"]) > np.deg2rad(55.0)
+    s = synth.evp_state(grid, dom, seed=3, cover="patchy", ice_mask=cap)
+    ins = ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty",
+           "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty") + synth.SIG_NAMES
+    for k in ins:
+        ref.set(k, s[k])
+    ref.set("iceumask", s["iceumask"].astype(float))
+    ny, nx = dom["ny"], dom["nx"]
+    ref.set("aicen", s["aicen"].reshape(-1, ny, nx)); ref.set("vicen", s["vicen"].reshape(-1, ny, nx))
+    ref.evp(DT)
+    outs = ("uvel", "vvel", "strength", "divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strocnxT",
+            "strocnyT", "strocnx", "strocny", "strintx", "strinty", "strairx", "strairy", "fm", "strtltx",
+            "strtlty") + synth.SIG_NAMES
+    data = {"grid_" + k: v for k, v in grid.items()}
+    data.update({"in_" + k: v for k, v in s.items()})
+    data.update({"out_" + k: ref.get(k) for k in outs})
+    data["out_iceumask"] = ref.get("iceumask").astype(np.int32)
+    for k in ("ilo", "ihi", "jlo", "jhi", "i0", "j0", "hsrc", "hdst"):
+        data["dom_" + k] = dom[k]
+    data["meta"] = meta()
+    np.savez_compressed(os.path.join(HERE, "evp_gx3.npz"), **data)
+    nice = int((s["aice"] > 0).sum())
+    print("evp_gx3: ocean T-cells", int(grid["tmask"].sum()), "ice cells", nice, "max |u|", float(np.abs(data["out_uvel"]).max()))
 
 
 def stress_stepu(ref):
@@ -179,10 +224,12 @@ def frzmlt(ref):
 
 if __name__ == "__main__":
     ref = refapi.Ref("small")
-    todo = sys.argv[1:] or ["stress_stepu", "thermo_cols", "thermo_known_tsfc", "frzmlt", "evp_small"]
+    todo = sys.argv[1:] or ["stress_stepu", "thermo_cols", "thermo_known_tsfc", "frzmlt", "evp_small", "evp_gx3"]
     for name in ("stress_stepu", "thermo_cols", "thermo_known_tsfc", "frzmlt"):
         if name in todo:
             globals()[name](ref)
+    if "evp_gx3" in todo:
+        evp_gx3()           # its own library (gx3 configuration)
     if "evp_small" in todo:
         evp_small(ref)      # last: init_domain is once per process
     print("golden vectors", todo, "written to", HERE)

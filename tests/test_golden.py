@@ -16,12 +16,12 @@ def load(name):
     return np.load(os.path.join(G, name))
 
 
-def evp_case():
-    z = load("evp_small.npz")
+def evp_case(fname="evp_small.npz", dims=(14, 12, 4, 24, 20)):
+    z = load(fname)
     grid = {k[5:]: z[k] for k in z.files if k.startswith("grid_")}
     s = {k[3:]: np.ascontiguousarray(z[k]) for k in z.files if k.startswith("in_")}
     out = {k[4:]: z[k] for k in z.files if k.startswith("out_")}
-    dom = dict(nx=14, ny=12, nblocks=4, nxg=24, nyg=20)
+    dom = dict(zip(("nx", "ny", "nblocks", "nxg", "nyg"), dims))
     for k in ("ilo", "ihi", "jlo", "jhi", "i0", "j0", "hsrc", "hdst"):
         dom[k] = z["dom_" + k]
     return dom, grid, s, out
@@ -34,6 +34,20 @@ def test_evp_small_golden(orc):
     for k, v in out.items():
         assert np.array_equal(s[k], v), k
     assert np.abs(out["uvel"]).max() > 0.01
+
+
+GX3 = ("evp_gx3.npz", (102, 118, 1, 100, 116))
+
+
+def test_evp_gx3_real_grid_golden(orc):
+    """The reference's own gx3 displaced-pole grid and land mask (grid arrays as its init_grid1/2 left
+    them), ice on both polar caps: the checker reproduces the reference's evp(dt) bit for bit."""
+    dom, grid, s, out = evp_case(*GX3)
+    orc.set_evp_parameters(DT, NDTE); orc.set_strength_parameters()
+    orc.evp(orc.make_domain(dom, grid), s)
+    for k, v in out.items():
+        assert np.array_equal(s[k], v), k
+    assert np.abs(out["uvel"]).max() > 0.01 and 0 < (out["iceumask"] != 0).sum() < 4000
 
 
 def test_stress_stepu_golden(orc):
@@ -110,5 +124,5 @@ def test_frzmlt_golden(orc):
 
 
 def test_golden_files_carry_provenance():
-    for f in ("evp_small.npz", "stress_stepu.npz", "thermo_cols.npz", "thermo_known_tsfc.npz", "frzmlt.npz"):
+    for f in ("evp_small.npz", "evp_gx3.npz", "stress_stepu.npz", "thermo_cols.npz", "thermo_known_tsfc.npz", "frzmlt.npz"):
         assert "amdflang" in str(load(f)["meta"][0]) or "flang" in str(load(f)["meta"][0])

@@ -7,7 +7,7 @@ import pytest
 
 from cice4_amd import synth
 from conftest import relerr
-from test_golden import DT, NDTE, evp_case, load, thermo_cases
+from test_golden import DT, GX3, NDTE, evp_case, load, thermo_cases
 from test_gpu_thermo import CHECK, frel
 
 pytestmark = pytest.mark.gpu
@@ -60,6 +60,42 @@ def test_evp_small_golden(ctx):
         worst = max(worst, e)
     assert np.abs(out["uvel"]).max() > 0.01
     print("evp_small golden: worst field-level relative error", worst)
+
+
+def test_evp_gx3_real_grid_golden(ctx):
+    """BASELINE.json configs[1]: gx3 (100x116) on one MI355X.  The reference's own displaced-pole grid
+    and land mask, ice on both polar caps, evp(dt) with 120 subcycles: the device path (two subcycles
+    per launch, metrics recomputed from HTN/HTE after the bit-for-bit check at init) against the
+    reference's output; the scheduling variants must agree with each other bit for bit."""
+    dom, grid, s0, out = evp_case(*GX3)
+    d = ctx.domain_create(dom["nxg"], dom["nyg"], dom["nxg"], dom["nyg"], ew=1, ns=0)
+    assert (d["nx"], d["ny"], d["nblocks"]) == (dom["nx"], dom["ny"], 1)
+    g = {k: np.ascontiguousarray(v) for k, v in grid.items()}
+    first = None
+    for opts in (dict(), dict(fuse=0), dict(derive_metrics=0), dict(fuse=0, derive_metrics=0, use_graph=0)):
+        s = {k: v.copy() for k, v in s0.items()}
+        ctx.evp_init(g, ndte=NDTE)
+        for k, v in opts.items():
+            ctx.evp_set_option(k, v)
+        if not opts:
+            assert ctx.evp_get_info("derive_metrics") == 1 and ctx.evp_get_info("fused") == 1
+        ctx.evp(DT, s)
+        if first is None:
+            first = s
+            worst = 0.0
+            for k, v in out.items():
+                if k == "iceumask":
+                    assert np.array_equal(s[k] != 0, v != 0)
+                    continue
+                e = relerr(s[k], v)
+                tol = TOL if (k in ("uvel", "vvel", "strength", "fm", "strairx", "strairy", "strtltx", "strtlty")
+                              or k.startswith("stress")) else 1e-8
+                assert e <= tol, (k, e)
+                worst = max(worst, e)
+            print("evp_gx3 golden: worst field-level relative error", worst)
+        else:
+            for k in out:
+                assert np.array_equal(s[k], first[k]), (opts, k)
 
 
 def test_thermo_golden(ctx):
