@@ -1,0 +1,47 @@
+"""Host-side pieces of bench.py that the reported numbers depend on (no GPU)."""
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+bench = importlib.import_module("bench")
+
+
+def test_launch_count_matches_the_pairing_rule():
+    # one launch per subcycle without pairing
+    assert bench.launches_per_step(120, False, 0) == 120
+    # pairs; an odd count ends with a single
+    assert bench.launches_per_step(120, True, 0) == 60
+    assert bench.launches_per_step(7, True, 0) == 4
+    assert bench.launches_per_step(1, True, 0) == 1
+    # wide-halo slabs: refresh after every `overlap`-th subcycle; pairs never straddle one
+    for ndte in (120, 240, 7):
+        for h in (2, 4, 6, 12):
+            n, k, refreshes = 0, 1, 0
+            while k <= ndte:                       # independent restatement of Evp::launch_range
+                if k + 1 <= ndte and k % h != 0:
+                    assert (k + 1) % h == 0 or k % h != 0
+                    k += 2
+                else:
+                    k += 1
+                n += 1
+            assert bench.launches_per_step(ndte, True, h) == n
+    assert bench.launches_per_step(120, True, 12) == 60   # even overlap: all pairs
+
+
+@pytest.mark.parametrize("nxg,rows", [(320, 48), (320, 96), (320, 192), (3600, 300), (3600, 1200), (100, 29), (100, 8)])
+def test_auto_overlap_is_even_and_fits(nxg, rows):
+    h = bench.auto_overlap(nxg, rows)
+    assert h >= 2 and h % 2 == 0 and h <= rows
+
+
+def test_workload_names():
+    assert bench.workload("gx1")[:3] == (320, 384, 120)
+    assert bench.workload("tenth")[:3] == (3600, 2400, 240)
+    assert bench.workload("320x72")[:3] == (320, 72, 120)
+    assert bench.workload("64x40x8")[:3] == (64, 40, 8)
+    with pytest.raises(SystemExit):
+        bench.workload("nonsense")
