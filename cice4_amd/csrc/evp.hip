@@ -195,6 +195,8 @@ struct SubArgs {
   double* __restrict__ v_out;
   const double* __restrict__ sig_in;
   double* __restrict__ sig_out;
+  const double* sig_in_p[12];   // the 12 planes of sig_in / sig_out as separate uniform pointers
+  double* sig_out_p[12];        // (k_subcycle2: SGPR base + lane offset addressing)
   const double *__restrict__ dxt, *__restrict__ dyt, *__restrict__ dxhy, *__restrict__ dyhx,
       *__restrict__ cxp, *__restrict__ cyp, *__restrict__ cxm, *__restrict__ cym,
       *__restrict__ tarear, *__restrict__ tinyarea, *__restrict__ strength;
@@ -466,6 +468,62 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
 // width per rank, or wide-halo slabs with an even overlap); otherwise k_subcycle runs.
 constexpr int OWN_LANE0 = 2, OWN_LANES = 59;  // lanes 2..60 own their column
 
+// Addressing inside k_subcycle2: every array is indexed as (uniform pointer to the block's plane)
+// + (one 32-bit byte offset per lane), which the compiler turns into SGPR-pair + VGPR-offset
+// addressing: no 64-bit vector arithmetic per access.  (A block plane is < 4 GB: Evp::init checks.)
+__device__ __forceinline__ double ld8(const double* p, unsigned off) {
+  return *(const double*)((const char*)p + off);
+}
+__device__ __forceinline__ void st8(double* p, unsigned off, double v) { *(double*)((char*)p + off) = v; }
+__device__ __forceinline__ int ld4(const int32_t* p, unsigned off) {
+  return *(const int32_t*)((const char*)p + off);
+}
+
+template <bool DERIVE>
+__device__ __forceinline__ void load_uin_o(const SubArgs& a, size_t base, unsigned qo, UIn& x) {
+  x.aiu = ld8(a.aiu + base, qo); x.uocn = ld8(a.uocn + base, qo); x.vocn = ld8(a.vocn + base, qo);
+  if (DERIVE) {  // evp_prep2's own expressions (ice_dyn_evp.F90:915-916) instead of two loads
+    x.waterx = x.uocn * cosw - x.vocn * sinw;
+    x.watery = x.vocn * cosw + x.uocn * sinw;
+  } else {
+    x.waterx = ld8(a.waterx + base, qo);
+    x.watery = ld8(a.watery + base, qo);
+  }
+  x.forcex = ld8(a.forcex + base, qo); x.forcey = ld8(a.forcey + base, qo);
+  x.umassdtei = ld8(a.umassdtei + base, qo); x.fm = ld8(a.fm + base, qo); x.uarear = ld8(a.uarear + base, qo);
+}
+
+// stepu_store with the same addressing
+template <bool LAST>
+__device__ __forceinline__ void stepu_store_o(const SubArgs& a, const UIn& x, size_t base, unsigned qo, int i,
+                                              int j, int ilo, int ihi, int jlo, int jhi, double uold,
+                                              double vold, double sx, double sy) {
+  StepuOut r;
+  stepu_cell(uold, vold, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei,
+             x.fm, x.uarear, sx, sy, r);
+  st8(a.u_out + base, qo, r.u);
+  st8(a.v_out + base, qo, r.v);
+  if (LAST) {
+    st8(a.strintx + base, qo, r.strintx);
+    st8(a.strinty + base, qo, r.strinty);
+    st8(a.strocnx + base, qo, r.taux);
+    st8(a.strocny + base, qo, r.tauy);
+  }
+  if (a.ring_slot && (i == ilo || i == ihi || j == jlo || j == jhi)) {
+    const int slot = a.ring_slot[base + (qo >> 3)];
+    if (slot >= 0) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int d = a.fwd[3 * slot + k];
+        if (d >= 0) {
+          a.u_out[d] = r.u;
+          a.v_out[d] = r.v;
+        }
+      }
+    }
+  }
+}
+
 template <int W, bool LAST, bool DAMP, bool DERIVE>
 __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_subcycle2(const SubArgs a) {
   __shared__ double s_str[W][4][TX];
@@ -506,31 +564,32 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
   const bool own_row = w >= 1 && w <= W - 3 && row_ok;
   const bool tcell = col_ok && row_ok && j >= jlo && col >= ilo;       // (col <= ihi+1, j <= jhi+1 hold)
   const bool ucell = col_ok && j >= jlo && j <= jhi && col >= ilo && col <= ihi;
-  const size_t q = base + (size_t)(j - 1) * nx + (size_t)(col_ok ? col - 1 : 0);
+  const unsigned qo = ((unsigned)(j - 1) * (unsigned)nx + (unsigned)(col_ok ? col - 1 : 0)) * 8u;   // byte offset in the block plane
+  const unsigned nx8 = (unsigned)nx * 8u;
   const bool ld = col_ok && row_ok;
   const bool reload_w = lx == 0 || at_ilo;             // west neighbour from memory, not from lane-1
 
   // ---- loads (once for both subcycles) ----
   double un = c0, vn = c0, us = c0, vs = c0;
   if (ld) {
-    un = a.u_in[q];
-    vn = a.v_in[q];
+    un = ld8(a.u_in + base, qo);
+    vn = ld8(a.v_in + base, qo);
     if (j >= 2) {
-      us = a.u_in[q - nx];
-      vs = a.v_in[q - nx];
+      us = ld8(a.u_in + base, qo - nx8);
+      vs = ld8(a.v_in + base, qo - nx8);
     }
   }
   double uw = __shfl_up(un, 1), vw = __shfl_up(vn, 1), usw = __shfl_up(us, 1), vsw = __shfl_up(vs, 1);
   if (reload_w && ld && col >= 2) {
-    uw = a.u_in[q - 1];
-    vw = a.v_in[q - 1];
+    uw = ld8(a.u_in + base, qo - 8u);
+    vw = ld8(a.v_in + base, qo - 8u);
     if (j >= 2) {
-      usw = a.u_in[q - nx - 1];
-      vsw = a.v_in[q - nx - 1];
+      usw = ld8(a.u_in + base, qo - nx8 - 8u);
+      vsw = ld8(a.v_in + base, qo - nx8 - 8u);
     }
   }
-  const bool tact = tcell && a.icetmask[q] == 1;
-  const bool uact = ucell && a.iceumask[q] != 0;
+  const bool tact = tcell && ld4(a.icetmask + base, qo >> 1) == 1;
+  const bool uact = ucell && ld4(a.iceumask + base, qo >> 1) != 0;
   double s[12];
   // T-cell metrics: DERIVE keeps the four primary lengths and forms the nine metrics in each stage
   // (registers); otherwise the nine loaded values are kept
@@ -540,22 +599,23 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
   {
     if (DERIVE) {
       if (ld) {
-        hn = a.HTN[q];
-        he = a.HTE[q];
-        if (j >= 2) hn_s = a.HTN[q - nx];
+        hn = ld8(a.HTN + base, qo);
+        he = ld8(a.HTE + base, qo);
+        if (j >= 2) hn_s = ld8(a.HTN + base, qo - nx8);
       }
       hew = __shfl_up(he, 1);
-      if (reload_w && ld && col >= 2) hew = a.HTE[q - 1];
+      if (reload_w && ld && col >= 2) hew = ld8(a.HTE + base, qo - 8u);
     }
     if (tact) {
 #pragma unroll
-      for (int c = 0; c < 12; ++c) s[c] = a.sig_in[(size_t)c * a.n + q];
+      for (int c = 0; c < 12; ++c) s[c] = ld8(a.sig_in_p[c] + base, qo);
       if (!DERIVE) {
-        Dxt = a.dxt[q]; Dyt = a.dyt[q]; Dxhy = a.dxhy[q]; Dyhx = a.dyhx[q]; Cxp = a.cxp[q];
-        Cyp = a.cyp[q]; Cxm = a.cxm[q]; Cym = a.cym[q]; Tiny = a.tinyarea[q];
+        Dxt = ld8(a.dxt + base, qo); Dyt = ld8(a.dyt + base, qo); Dxhy = ld8(a.dxhy + base, qo);
+        Dyhx = ld8(a.dyhx + base, qo); Cxp = ld8(a.cxp + base, qo); Cyp = ld8(a.cyp + base, qo);
+        Cxm = ld8(a.cxm + base, qo); Cym = ld8(a.cym + base, qo); Tiny = ld8(a.tinyarea + base, qo);
       }
-      St = a.strength[q];
-      if (LAST) Tarear = a.tarear[q];
+      St = ld8(a.strength + base, qo);
+      if (LAST) Tarear = ld8(a.tarear + base, qo);
     } else {
 #pragma unroll
       for (int c = 0; c < 12; ++c) s[c] = c0;
@@ -597,7 +657,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
     const double sy = o.str[4] + s_str[w + 1][2][lx] + e6 + s_str[w + 1][3][lx];   // :1417-1418 order
     UIn x;   // fetched for each of the two momentum updates (L2 hits the second time): they would
              // otherwise occupy 16-20 registers across both stress evaluations
-    load_uin<DERIVE>(a, q, x);
+    load_uin_o<DERIVE>(a, base, qo, x);
     StepuOut r;
     stepu_cell(un, vn, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                x.uarear, sx, sy, r);
@@ -629,12 +689,12 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
     if (at_ilo) {
       uw1 = uw2; vw1 = vw2; usw1 = usw2; vsw1 = vsw2;
       if (!mirror_n && ld) {   // unchanged ghost value: read it again rather than keep it in registers
-        uw1 = a.u_in[q - 1];
-        vw1 = a.v_in[q - 1];
+        uw1 = ld8(a.u_in + base, qo - 8u);
+        vw1 = ld8(a.v_in + base, qo - 8u);
       }
       if (!mirror_s && ld && j >= 2) {
-        usw1 = a.u_in[q - nx - 1];
-        vsw1 = a.v_in[q - nx - 1];
+        usw1 = ld8(a.u_in + base, qo - nx8 - 8u);
+        vsw1 = ld8(a.v_in + base, qo - nx8 - 8u);
       }
     }
   }
@@ -646,13 +706,13 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
                             Cxm, Cym, Tarear, Tiny, St, s, o);
     if (own_col && own_row) {
 #pragma unroll
-      for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
+      for (int c = 0; c < 12; ++c) st8(a.sig_out_p[c] + base, qo, s[c]);
       if (LAST) {
-        a.divu[q] = o.divu;
-        a.rdg_conv[q] = o.rdg_conv;
-        a.rdg_shear[q] = o.rdg_shear;
-        a.shear[q] = o.shear;
-        a.prs_sig[q] = o.prs_sig;
+        st8(a.divu + base, qo, o.divu);
+        st8(a.rdg_conv + base, qo, o.rdg_conv);
+        st8(a.rdg_shear + base, qo, o.rdg_shear);
+        st8(a.shear + base, qo, o.shear);
+        st8(a.prs_sig + base, qo, o.prs_sig);
       }
     }
   }
@@ -667,8 +727,8 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
     const double sx = o.str[0] + e1 + s_str[w + 1][0][lx] + s_str[w + 1][1][lx];
     const double sy = o.str[4] + s_str[w + 1][2][lx] + e6 + s_str[w + 1][3][lx];
     UIn x;
-    load_uin<DERIVE>(a, q, x);
-    stepu_store<LAST>(a, x, q, col, j, ilo, ihi, jlo, jhi, u1, v1, sx, sy);
+    load_uin_o<DERIVE>(a, base, qo, x);
+    stepu_store_o<LAST>(a, x, base, qo, col, j, ilo, ihi, jlo, jhi, u1, v1, sx, sy);
   }
 }
 
@@ -1250,6 +1310,10 @@ SubArgs Evp::make_args() const {
   a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
   a.u_in = uv[cur].p; a.v_in = uv[cur].p + n; a.u_out = uv[1 - cur].p; a.v_out = uv[1 - cur].p + n;
   a.sig_in = sig[cur].p; a.sig_out = sig[1 - cur].p;
+  for (int c = 0; c < 12; ++c) {
+    a.sig_in_p[c] = a.sig_in + (size_t)c * n;
+    a.sig_out_p[c] = a.sig_out + (size_t)c * n;
+  }
   a.dxt = dxt.p; a.dyt = dyt.p; a.dxhy = dxhy.p; a.dyhx = dyhx.p; a.cxp = cxp.p; a.cyp = cyp.p;
   a.cxm = cxm.p; a.cym = cym.p; a.tarear = tarear.p; a.tinyarea = tinyarea.p; a.strength = strength.p;
   const bool dv = derive_ok && derive_on;
