@@ -269,6 +269,19 @@ def pmc_traffic(workload, waves, rows, derive, fused=False, fw=0):
     return None, None
 
 
+def pmc_traffic_thermo(workload):
+    """HBM bytes per pass of k_thermo_dense from the committed PMC passes (same procedure as pmc_traffic)."""
+    import csv
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_thermo.csv")
+    try:
+        for row in csv.DictReader(open(path)):
+            if row["workload"] == workload and "k_thermo_dense" in row["kernel"]:
+                return float(row["total_MB_per_launch"]) * 1e6, os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    return None, None
+
+
 def cpu_baseline_worker(args):
     """Child process: no GPU is touched.  Rebuilds the same synthetic case on the host, times
     the checker, writes JSON to the given file.  Keeps the Fortran runtime's stdout away from
@@ -415,7 +428,10 @@ def main():
                       updates_per_pass=upd_pass, ms_per_pass=ms_pass, passes=npass,
                       roofline=dict(bound="hbm", achieved=rate * THERMO_BYTES_PER_COLUMN / 1e9,
                                     peak=HBM_PEAK_GBS, unit="GB/s",
-                                    frac=rate * THERMO_BYTES_PER_COLUMN / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                    frac=rate * THERMO_BYTES_PER_COLUMN / 1e9 / HBM_PEAK_GBS,
+                                    traffic=(pmc_traffic_thermo(args.workload)[0] if world == 1 else None),
+                                    traffic_unit="bytes per pass (all columns)",
+                                    traffic_source=(pmc_traffic_thermo(args.workload)[1] if world == 1 else None),
                                     kernel="k_thermo_dense",
                                     bytes_per_unit=THERMO_BYTES_PER_COLUMN))
 
