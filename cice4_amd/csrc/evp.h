@@ -55,7 +55,7 @@ class Evp {
   hipStream_t stream;
   cice_evp_config cfg{};
   EvpScalars sc{};
-  bool ready = false, prepared = false;
+  bool ready = false, prepared = false, counted = false;
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
   bool fuse_on = true;

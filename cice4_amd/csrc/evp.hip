@@ -1266,16 +1266,24 @@ void Evp::prepare(double dt) {
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
   CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
-  counters.zero(stream);
-  hipLaunchKernelGGL(k_count_active, g, blk256, 0, stream, a);
   CICE_HIP(hipGetLastError());
   prepared = true;
+  counted = false;   // the diagnostic counts are formed when somebody asks (active_cells)
 }
 
 bool Evp::derives_metrics() const { return derive_ok && derive_on; }
 
 void Evp::active_cells(long long* nt, long long* nu) {
   CICE_REQUIRE(prepared, "cice_evp_active_cells before cice_evp_prepare");
+  if (!counted) {   // the masks do not change during the subcycling
+    PrepArgs a{};
+    a.nx = dom.nx_block; a.ny = dom.ny_block; a.nblocks = dom.nblocks(); a.n = n; a.blk = blk.p;
+    a.icetmask = icetmask.p; a.iceumask = iceumask.p; a.counters = counters.p;
+    counters.zero(stream);
+    hipLaunchKernelGGL(k_count_active, grid1(n), dim3(256), 0, stream, a);
+    CICE_HIP(hipGetLastError());
+    counted = true;
+  }
   unsigned long long h[2];
   counters.download(h, stream);
   CICE_HIP(hipStreamSynchronize(stream));
