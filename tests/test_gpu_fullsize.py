@@ -98,6 +98,31 @@ def test_tenth_degree_evp(ctx, orc):
         assert np.array_equal(physical(dom12, s12[k]), one[k]), k
 
 
+def test_tenth_degree_24_hours(ctx):
+    """BASELINE.json configs[4]: 0.1 degree, ndte = 240, 24 h = 24 steps of dt = 3600 s with the state
+    resident on the device (velocity, stresses and masks carried from step to step).  Two subcycles per
+    launch (2,880 launches) must reproduce one per launch (5,760 launches) bit for bit, and the
+    solution has to stay bounded."""
+    nxg, nyg = 3600, 2400
+    dom, grid, s0 = setup(ctx, nxg, nyg, nxg, nyg)
+    res = []
+    for fuse in (1, 0):
+        s = {k: v.copy() for k, v in s0.items()}
+        ctx.evp_init(grid, ndte=240)
+        ctx.evp_set_option("fuse", fuse)
+        assert ctx.evp_get_info("fused") == fuse
+        ctx.evp_upload(s)
+        for _ in range(24):
+            ctx.evp_step(DT)
+        ctx.evp_download(s)
+        res.append({k: s[k] for k in PRIMARY + ("divu", "strocnxT", "iceumask")})
+        del s
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
+    u = physical(dom, res[0]["uvel"])
+    assert np.isfinite(u).all() and 0.01 < np.abs(u).max() < 5.0
+
+
 def test_tenth_degree_thermo_sample(ctx, orc):
     """Batched thermo step at 3600x2400 x 5 categories; a random 1-in-64 sample of the columns
     of every category is recomputed by the checker."""
