@@ -3,15 +3,15 @@
 // (nx_block,ny_block,nblocks) array, i fastest, so a wavefront reads 64 consecutive
 // i of one row = 512 contiguous bytes.
 //
-// The hot loop (ice_dyn_evp.F90:347-404: stress, stepu, two halo updates, ndte times)
-// is ONE kernel per subcycle: a workgroup takes a tile of 64 x TY T-cells, updates the
-// 12 stress components of the cells it owns, keeps the 8 `str` combinations of the
-// whole tile in LDS (they never touch HBM; the reference's `str(:,:,:) = 0` memset
-// disappears with them) and integrates the momentum equation for the 63 x (TY-1)
-// U-cells whose four surrounding T-cells are in the tile.  u, v and the stresses are
-// double-buffered so that tiles can recompute their neighbours' edge T-cells without
-// racing with the owner's update; the arithmetic per cell is exactly the reference's,
-// in its order, compiled without FMA contraction.
+// The hot loop (ice_dyn_evp.F90:347-404: stress, stepu, two halo updates, ndte times) is one
+// kernel per subcycle (k_subcycle) or -- where no ghost row of a local block changes between two
+// subcycles -- one kernel per PAIR of subcycles (k_subcycle2).  A wavefront keeps a row of T-cells,
+// a lane one column; the 8 `str` combinations of a cell live in registers and reach the momentum
+// equation of the neighbouring U-cells by wavefront shuffle (i+1) and LDS (j+1), so they never
+// touch HBM and the reference's `str(:,:,:) = 0` memset disappears with them.  u, v and the
+// stresses are double-buffered so that tiles can recompute their rim without racing with the
+// owner's update; the arithmetic per cell is exactly the reference's, in its order, compiled
+// without FMA contraction.
 #include "evp.h"
 
 #include <cmath>
