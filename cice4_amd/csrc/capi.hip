@@ -122,6 +122,15 @@ int cice_create(cice_ctx** ctx, int device) {
   return CICE_OK;
 }
 
+int cice_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
 int cice_destroy(cice_ctx* ctx) {
   if (!ctx) return CICE_EINVAL;
   ctx->evp.reset();

@@ -46,6 +46,9 @@ module cice4_amd_c
          type(c_ptr), intent(out) :: ctx
          integer(c_int), value :: device
       end function
+      integer(c_int) function cice_device_count() bind(C, name='cice_device_count')
+         import
+      end function
       integer(c_int) function cice_destroy(ctx) bind(C, name='cice_destroy')
          import
          type(c_ptr), value :: ctx
@@ -147,6 +150,9 @@ module cice4_amd_c
 
    ! one context per MPI task (= per GPU), shared by the drop-in modules
    type(c_ptr), save :: cice_gpu_ctx = c_null_ptr
+   ! set by the boundary module (rccl/ice_boundary.F90) once it has built the device topology for the
+   ! model's own block distribution; the dynamics module then reuses it instead of building a serial one
+   logical, save :: cice_gpu_domain_ready = .false.
 
 contains
 
@@ -193,5 +199,21 @@ contains
       if (present(device)) dev = device
       call cice_gpu_check(cice_create(cice_gpu_ctx, dev), 'cice_create')
    end subroutine cice_gpu_ensure
+
+#ifdef CICE4_AMD_MPI
+   ! MPI builds: the control plane stays MPI (the RCCL id travels by MPI_BCAST on the model's own
+   ! communicator), the data plane of the halo exchange becomes RCCL over xGMI.  Called by every task
+   ! right after cice_domain_create.
+   subroutine cice_gpu_comm_setup(my_task, nprocs, comm)
+      integer, intent(in) :: my_task, nprocs, comm
+      include 'mpif.h'
+      character(kind=c_char) :: uid(128)
+      integer :: ierr
+      uid = c_null_char
+      if (my_task == 0) call cice_gpu_check(cice_comm_unique_id(uid), 'cice_comm_unique_id')
+      call MPI_BCAST(uid, 128, MPI_CHARACTER, 0, comm, ierr)
+      call cice_gpu_check(cice_comm_init(cice_gpu_ctx, uid, my_task, nprocs), 'cice_comm_init')
+   end subroutine cice_gpu_comm_setup
+#endif
 
 end module cice4_amd_c

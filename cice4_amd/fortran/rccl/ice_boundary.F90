@@ -7,6 +7,9 @@
 ! by the halo kernel, off-rank rows by grouped RCCL send/recv over xGMI
 ! (include/cice4_amd.h: cice_domain_create, cice_halo_update_r8/i4).
 !
+! MPI builds (-DCICE4_AMD_MPI, with the reference's mpi/ice_communicate.F90): ice_HaloCreate also sets up
+! the RCCL communicator (id broadcast over MPI_COMM_ICE); off-rank ghost cells then travel by RCCL.
+!
 ! Scope: ghost width 1, cyclic / open / closed edges, cartesian block distribution without
 ! land-block elimination (SURVEY.md section 8f).  Tripole grids stop with a message.
 ! Ghost cells beyond an open or closed edge are left untouched, which is what the reference
@@ -85,7 +88,8 @@ contains
       if (mod(nprocs, npx) /= 0) call abort_ice('ice_HaloCreate: distribution is not cartesian')
       npy = nprocs/npx
 
-      call cice_gpu_ensure()
+      ! one task = one GPU: task t takes device mod(t, visible devices)
+      call cice_gpu_ensure(mod(my_task, max(1, cice_device_count())))
       call cice_gpu_check(cice_domain_create(cice_gpu_ctx, nx_global, ny_global, block_size_x, &
            block_size_y, halo%ewBnd, halo%nsBnd, my_task, npx, npy), 'cice_domain_create')
       call cice_gpu_check(cice_domain_info(cice_gpu_ctx, info), 'cice_domain_info')
@@ -104,6 +108,10 @@ contains
          endif
       enddo
       halo%numBlocks = numBlocks
+      cice_gpu_domain_ready = .true.
+#ifdef CICE4_AMD_MPI
+      call cice_gpu_comm_setup(my_task, nprocs, halo%communicator)
+#endif
    end function ice_HaloCreate
 
    integer (int_kind) function boundary_code(name)

@@ -43,6 +43,8 @@ typedef struct cice_ctx cice_ctx;
 /* One context = one rank = one GPU (the reference is one MPI task, no threads:
  * mpi/ice_communicate.F90:109-136).  device < 0: use HIP's current device. */
 int cice_create(cice_ctx **ctx, int device);
+/* number of HIP devices visible to this process (0 without a GPU): an MPI task picks my_task mod this */
+int cice_device_count(void);
 int cice_destroy(cice_ctx *ctx);
 const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
 int cice_device_sync(cice_ctx *ctx);

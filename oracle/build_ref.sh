@@ -48,6 +48,13 @@ SRCS="source/ice_kinds_mod.F90 serial/ice_communicate.F90 source/ice_domain_size
 # ice_grid, ice_state, ...) and the capture wrapper are the reference's / the same: this is the
 # drop-in test.
 DROPIN=${DROPIN:-0}
+# MPI=1: the reference's mpi/ modules (ice_communicate, ice_exit, ice_global_reductions, ice_broadcast,
+# ice_gather_scatter, ice_timers and -- unless DROPIN=1 replaces it -- ice_boundary) instead of serial/,
+# compiled against the image's MPICH through `include 'mpif.h'` -> libcice_<kind>mpi_<cfg>.so.
+# A process that loads it is a 1-rank MPI job (singleton MPI_Init); with DROPIN=1 this is the build an
+# MPI user of the reference would make (our ice_boundary then also sets up the RCCL communicator).
+MPI=${MPI:-0}
+MPIROOT=${MPIROOT:-/opt/conda}
 KIND=ref
 if [ "$DROPIN" = "1" ]; then
   KIND=dropin
@@ -56,11 +63,19 @@ if [ "$DROPIN" = "1" ]; then
   mkdir -p "$OBJ"
   FFLAGS="${FFLAGS//obj_$CFG/obj_${CFG}_dropin}"
 fi
+if [ "$MPI" = "1" ]; then
+  OBJ0=$OBJ
+  KIND=${KIND}mpi
+  OBJ=${OBJ}_mpi
+  rm -rf "$OBJ"; mkdir -p "$OBJ"
+  FFLAGS="${FFLAGS//$OBJ0/$OBJ} -I$MPIROOT/include -DCICE4_AMD_MPI"
+  SRCS="${SRCS//serial\//mpi/}"
+fi
 OBJS=""
 for s in $SRCS; do
   src="$REF/$s"
   o=$OBJ/$(basename "${s%.F90}").o
-  if [ "$DROPIN" = "1" ] && [ "$s" = "serial/ice_boundary.F90" ]; then
+  if [ "$DROPIN" = "1" ] && [ "$(basename $s)" = "ice_boundary.F90" ]; then
     $FC $FFLAGS -c "$HERE/../cice4_amd/fortran/cice4_amd_c.F90" -o "$OBJ/cice4_amd_c.o"
     OBJS="$OBJS $OBJ/cice4_amd_c.o"
     src="$HERE/../cice4_amd/fortran/rccl/ice_boundary.F90"
@@ -82,6 +97,9 @@ $FC $FFLAGS $EXTRA -c "$HERE/ref_capi.F90" -o "$OBJ/ref_capi.o"
 LINK=""
 if [ "$DROPIN" = "1" ]; then
   LINK="-L$HERE/../cice4_amd -lcice4_amd -Wl,-rpath,\$ORIGIN/../../cice4_amd"
+fi
+if [ "$MPI" = "1" ]; then
+  LINK="$LINK -L$MPIROOT/lib -lmpifort -lmpi -Wl,-rpath,$MPIROOT/lib"
 fi
 $FC -shared -Wl,-Bsymbolic -o "$OUT/libcice_${KIND}_$CFG.so" $OBJS "$OBJ/ref_capi.o" $LINK
 echo "built $OUT/libcice_${KIND}_$CFG.so"

@@ -224,18 +224,22 @@ def test_errors_are_reported_not_fatal(ctx):
         c2.domain_create(10, 10, 20, 20, ew=7)
 
 
-def test_fortran_dropin_module_inside_reference_callers(orc):
+@pytest.mark.parametrize("kind", ["dropin", "dropinmpi"])
+def test_fortran_dropin_module_inside_reference_callers(orc, kind):
     """The drop-in proof: the reference's own compiled modules (ice_state, ice_flux, ice_grid,
     ice_domain, ... and the capture wrapper that calls `evp(dt)`) linked with OUR
     cice4_amd/fortran/ice_dyn_evp.F90 instead of the reference's.  `call evp(dt)` then goes
     Fortran -> ISO_C_BINDING shim -> libcice4_amd.so -> GPU, on the reference's own module
     arrays and 2x2 block layout, and must reproduce the checker (pinned to the pure reference
-    bit for bit by tests/test_oracle_vs_ref.py)."""
+    bit for bit by tests/test_oracle_vs_ref.py).
+    kind 'dropinmpi': the same with the reference's mpi/ modules (MPICH, this process is a 1-rank MPI
+    job): our boundary module then also broadcasts the RCCL id over MPI_COMM_ICE and creates the RCCL
+    communicator, as every task of an MPI build does."""
     import tempfile
     from oracle import refapi
-    if not refapi.available("gx3b4", "dropin"):
-        pytest.skip("oracle/_ref/libcice_dropin_gx3b4.so not built")
-    ref = refapi.Ref("gx3b4", kind="dropin")
+    if not refapi.available("gx3b4", kind):
+        pytest.skip(f"oracle/_ref/libcice_{kind}_gx3b4.so not built")
+    ref = refapi.Ref("gx3b4", kind=kind)
     nb = ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
     dom = lib.Context().domain_create(100, 116, 50, 58, ew=1, ns=0)
     assert nb == 4 == dom["nblocks"]

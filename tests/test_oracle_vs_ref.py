@@ -224,3 +224,39 @@ def test_merge_fluxes(ref_gx3, orc):
     for k in a1:
         assert np.array_equal(a1[k], a2[k]), k
     assert any((a1[k] != acc0[k]).any() for k in a1)
+
+
+def test_mpi_build_of_the_reference_agrees(orc):
+    """The reference's mpi/ modules (MPICH, 1-rank job inside this process): its MPI ice_HaloUpdate equals
+    the product's halo lists, and its evp(dt) equals the checker bit for bit -- the checker is pinned to
+    both flavours of the reference."""
+    from oracle import refapi
+    if not refapi.available("gx3b4", "refmpi"):
+        pytest.skip("oracle/_ref/libcice_refmpi_gx3b4.so not built")
+    ref = refapi.Ref("gx3b4", kind="refmpi")
+    ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
+    dom = lib.Context().domain_create(100, 116, 50, 58, ew=1, ns=0)
+    rng = np.random.default_rng(1)
+    a = rng.uniform(1, 2, (4, ref.ny_block, ref.nx_block))
+    want = a.copy(); ref.halo_r8(want, 2, 2)
+    got = a.copy().reshape(-1); got[dom["hdst"]] = got[dom["hsrc"]]
+    assert np.array_equal(got.reshape(a.shape), want)
+    grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.15, land_frac=0.05), dom)
+    s = synth.evp_state(grid, dom, cover="patchy")
+    for k in ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear", "uarear",
+              "tinyarea", "fcor"):
+        ref.set(k, grid[k])
+    ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
+    ref.set_strength_parameters()
+    for k in ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty",
+              "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty") + synth.SIG_NAMES:
+        ref.set(k, s[k])
+    ref.set("iceumask", s["iceumask"].astype(float))
+    ny, nx = dom["ny"], dom["nx"]
+    ref.set("aicen", s["aicen"].reshape(-1, ny, nx)); ref.set("vicen", s["vicen"].reshape(-1, ny, nx))
+    ref.evp(DT)
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters()
+    so = {k: v.copy() for k, v in s.items()}
+    orc.evp(orc.make_domain(dom, grid), so)
+    for k in EVP_OUT:
+        assert np.array_equal(ref.get(k), so[k]), k
