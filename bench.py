@@ -72,6 +72,9 @@ def parse():
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
     p.add_argument("--no-thermo", action="store_true")
+    p.add_argument("--thermo-coherence", type=int, default=THERMO_COHERENCE,
+                   help="correlation length (cells) of the melting/cold, snow/bare, day/night regions of the synthetic "
+                        "thermo columns; 0 = every column drawn independently (white noise)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-dropin-timing", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
@@ -148,8 +151,15 @@ def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
     return dom, grid, state, ndte
 
 
-def thermo_case(dom, seed=20261003):
-    """Module-array-shaped inputs of the batched thermo step for this rank's blocks."""
+THERMO_COHERENCE = 24   # cells; see synth.thermo_columns(coherent=...)
+
+
+def thermo_case(dom, seed=20261003, coherent=None):
+    """Module-array-shaped inputs of the batched thermo step for this rank's blocks: full ice cover,
+    'mixed' regime (40 % melting / 60 % cold columns, snow-covered and bare, day and night), organised
+    in regions with a correlation length of `coherent` cells (0: drawn independently per cell)."""
+    if coherent is None:
+        coherent = THERMO_COHERENCE
     nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
     NC, NI, NS = 5, 4, 1
     z = lambda *s: np.zeros(s)
@@ -166,7 +176,8 @@ def thermo_case(dom, seed=20261003):
     for ib in range(nb):
         for n in range(NC):
             a, icells, ii, jj = synth.thermo_columns(ny, nx, n, regime="mixed",
-                                                     seed=seed + 31 * int(dom["gid"][ib]), ice_frac=1.0)
+                                                     seed=seed + 31 * int(dom["gid"][ib]), ice_frac=1.0,
+                                                     coherent=coherent)
             cols[(ib, n)] = (a, icells, ii, jj)
             for k in ("aicen", "vicen", "vsnon", "lhcoef", "shcoef", "fswsfc", "fswint", "fswthrun"):
                 b[k][ib, n] = a[k]
@@ -288,7 +299,7 @@ def cpu_baseline_worker(args):
     the parent's single JSON line."""
     ctx = lib.Context()                       # host-side domain logic only
     dom, grid, state, ndte = build_case(ctx, args.workload, 0, 1)
-    tcols = None if args.no_thermo else thermo_case(dom)[1]
+    tcols = None if args.no_thermo else thermo_case(dom, coherent=args.thermo_coherence)[1]
     res = cpu_baseline(args.workload, grid, state, dom, ndte, tcols, args.cpu_seconds)
     with open(args.cpu_baseline_worker, "w") as f:
         json.dump(res, f)
@@ -300,7 +311,8 @@ def run_cpu_baseline(args):
     with tempfile.NamedTemporaryFile(suffix=".json", delete=False) as tf:
         path = tf.name
     cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--cpu-seconds",
-           str(args.cpu_seconds), "--cpu-baseline-worker", path] + (["--no-thermo"] if args.no_thermo else [])
+           str(args.cpu_seconds), "--cpu-baseline-worker", path, "--thermo-coherence",
+           str(args.thermo_coherence)] + (["--no-thermo"] if args.no_thermo else [])
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
@@ -405,7 +417,7 @@ def main():
     tcols = None
     if not args.no_thermo:
         ctx.thermo_init()
-        tb, tcols = thermo_case(dom)
+        tb, tcols = thermo_case(dom, coherent=args.thermo_coherence)
         ctx.thermo_batch_alloc(dom["nx"], dom["ny"], dom["nblocks"])
         t_ms, nupd = 0.0, 0
         npass = max(2, min(args.steps, 10))
@@ -425,6 +437,9 @@ def main():
             ms_pass, upd_pass = t_ms / npass, nupd // npass
         rate = upd_pass / (ms_pass * 1e-3)
         thermo = dict(metric="grid-cell-cat-updates/sec", value=rate, unit="(cell,category) updates/s",
+                      columns=("synthetic, full cover, 40 % melting / 60 % cold, snow-covered and bare, day and night; "
+                               + (f"regions with correlation length {args.thermo_coherence} cells"
+                                  if args.thermo_coherence else "every column drawn independently (white noise)")),
                       updates_per_pass=upd_pass, ms_per_pass=ms_pass, passes=npass,
                       roofline=dict(bound="hbm", achieved=rate * THERMO_BYTES_PER_COLUMN / 1e9,
                                     peak=HBM_PEAK_GBS, unit="GB/s",

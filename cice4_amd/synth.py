@@ -237,19 +237,51 @@ def qin_from_T(T, Tmlt):
     return -rhoi * (cp_ice * (Tmlt - T) + Lfresh * (1.0 - Tmlt / T) - cp_ocn * Tmlt)
 
 
-def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac=0.9):
+def _smooth_uniform(rng, shp, length):
+    """A spatially correlated field with (close to) uniform(0,1) marginals: Gaussian-filtered white
+    noise (correlation length `length` cells, periodic), mapped through its own normal CDF."""
+    from math import sqrt
+    from scipy.ndimage import gaussian_filter
+    from scipy.special import erf
+    z = gaussian_filter(rng.standard_normal(shp), length, mode="wrap")
+    z = (z - z.mean()) / max(z.std(), 1e-300)
+    return 0.5 * (1.0 + erf(z / sqrt(2.0)))
+
+
+def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac=0.9, coherent=0):
     """Arguments of thermo_vertical (ice_therm_vertical.F90:108-132) for ONE category on an
     (nx,ny) block: state, forcing and flux arrays + the compressed (indxi,indxj) list built
     the way step_therm1 builds it (aicen > puny, j outer / i inner, physical cells only;
     drivers/cice4/CICE_RunMod.F90:380-389).
-    regime: 'winter' (cold, snow covered), 'summer' (melting, strong SW), 'mixed'."""
+    regime: 'winter' (cold, snow covered), 'summer' (melting, strong SW), 'mixed'.
+    coherent: 0 = every yes/no property of a column (melting or cold, snow or bare, precipitation, ...)
+    is drawn independently per cell (white noise: the harshest case for a SIMD machine and what the
+    parity tests use); L > 0 = the same properties with the same frequencies, but as regions with
+    correlation length L cells, the way weather and ice cover are organised (bench.py)."""
     rng = np.random.default_rng(seed + 1000 * ncat_index)
     shp = (ny, nx)
+    # coin(p): boolean field, true with probability p
+    if coherent:
+        coin_rng = np.random.default_rng(seed + 77)   # the same regions for every category
+        regions = {}
+
+        def coin(p, key=None, own=False):
+            r = rng if own else coin_rng
+            if key is None or key not in regions:
+                f = _smooth_uniform(r, shp, coherent)
+                if key is not None:
+                    regions[key] = f
+            else:
+                f = regions[key]
+            return f < p
+    else:
+        def coin(p, key=None, own=False):
+            return rng.uniform(0, 1, shp) < p
     hmax = hin_max()
     n = ncat_index
     _, Tmlt = salinity_profile()
     U = lambda lo, hi: rng.uniform(lo, hi, shp)
-    present = rng.uniform(0, 1, shp) < ice_frac
+    present = coin(ice_frac, own=True)
     present[0, :] = present[-1, :] = False
     present[:, 0] = present[:, -1] = False
     aicen = np.where(present, U(0.02, 0.95), 0.0)
@@ -261,13 +293,13 @@ def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac
     elif regime == "summer":
         warm = np.ones(shp, bool)
     else:
-        warm = rng.uniform(0, 1, shp) < 0.4
-    snowy = rng.uniform(0, 1, shp) < np.where(warm, 0.3, 0.85)
+        warm = coin(0.4, "warm")
+    snowy = coin(np.where(warm, 0.3, 0.85), own=True)
     hsn = np.where(snowy, U(0.002, 0.45), 0.0)
-    tiny_snow = rng.uniform(0, 1, shp) < 0.05
+    tiny_snow = coin(0.05, own=True)
     hsn = np.where(tiny_snow & snowy, U(1e-5, 2e-4), hsn)   # straddles hs_min = 1e-4
     Tsfc = np.where(warm, U(-2.0, 0.0), U(-32.0, -3.0))
-    Tsfc = np.where(warm & (rng.uniform(0, 1, shp) < 0.3), 0.0, Tsfc)
+    Tsfc = np.where(warm & coin(0.3, "melting"), 0.0, Tsfc)
     Tbot = np.full(shp, -1.8) + U(-0.05, 0.05)
     vicen = aicen * hin
     vsnon = aicen * hsn
@@ -289,14 +321,14 @@ def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac
     a["potT"] = np.where(warm, U(270, 277), U(238, 270))
     a["Qa"] = np.where(warm, U(0.002, 0.005), U(0.0002, 0.002))
     a["rhoa"] = U(1.25, 1.4)
-    a["fsnow"] = np.where(rng.uniform(0, 1, shp) < 0.5, 0.0, U(0, 4e-5))
+    a["fsnow"] = np.where(coin(0.5, "precip"), 0.0, U(0, 4e-5))
     a["fbot"] = -U(0.0, 25.0)
-    a["fbot"] = np.where(rng.uniform(0, 1, shp) < 0.2, 0.0, a["fbot"])
+    a["fbot"] = np.where(coin(0.2, "fbot0"), 0.0, a["fbot"])
     a["Tbot"] = Tbot
     wind = U(1.0, 12.0)
     a["shcoef"] = 1.2e-3 * 1005.0 * a["rhoa"] * wind
     a["lhcoef"] = 1.5e-3 * Lsub * a["rhoa"] * wind
-    sw = np.where(warm, U(50, 350), U(0, 60)) * (rng.uniform(0, 1, shp) > 0.2)
+    sw = np.where(warm, U(50, 350), U(0, 60)) * (~coin(0.2, "night"))
     alb = np.where(hsn > 0.01, U(0.7, 0.85), U(0.45, 0.65))
     absd = sw * (1 - alb)
     a["fswsfc"] = absd * np.where(hsn > 0.01, 0.9, 0.3)
@@ -314,8 +346,8 @@ def thermo_columns(ny, nx, ncat_index=0, seed=20261003, regime="mixed", ice_frac
     for nm in ("fsurfn", "fcondtopn", "fsensn", "flatn", "fswabsn", "flwoutn", "evapn", "freshn",
                "fsaltn", "fhocnn", "meltt", "melts", "meltb", "congel", "snoice"):
         a[nm] = U(-1, 1)      # intent(out): must be overwritten / zeroed by the routine
-    a["mlt_onset"] = np.where(rng.uniform(0, 1, shp) < 0.5, 0.0, 120.0)
-    a["frz_onset"] = np.where(rng.uniform(0, 1, shp) < 0.5, 0.0, 250.0)
+    a["mlt_onset"] = np.where(coin(0.5, "mlt"), 0.0, 120.0)
+    a["frz_onset"] = np.where(coin(0.5, "frz"), 0.0, 250.0)
     for k in a:
         a[k] = np.ascontiguousarray(a[k], np.float64)
     jj, ii = np.nonzero(a["aicen"][1:-1, 1:-1] > puny)
