@@ -107,7 +107,9 @@ def auto_overlap(nxg, rows):
     Always even: the subcycle kernel then runs two subcycles per launch."""
     t_kernel = nxg * rows * 50e-6            # us per subcycle, from 430 us per 8.63 M cells
     if nxg * rows <= 200 * 200:
-        h = max(2, min(12, rows // 4))
+        # latency-bound slabs (measured: 320x72 5.05 us, 320x120 5.28 us per subcycle): a row of overlap
+        # costs ~0.005 us per subcycle, an exchange ~10 us -> the optimum is flat around 24-32 rows
+        h = max(2, min(24, rows // 2))
     else:
         h = max(2, min(rows // 4, int(round((12.0 * rows / (2.0 * t_kernel)) ** 0.5))))
     return h + (h & 1) if h + (h & 1) <= rows else max(2, h - (h & 1))
