@@ -71,6 +71,16 @@ if [ "$MPI" = "1" ]; then
   FFLAGS="${FFLAGS//$OBJ0/$OBJ} -I$MPIROOT/include -DCICE4_AMD_MPI"
   SRCS="${SRCS//serial\//mpi/}"
 fi
+# our own sources unchanged since the last build of this variant: nothing to do (the variants that swap
+# in our modules are otherwise rebuilt from scratch, see above)
+TARGET="$OUT/libcice_${KIND}_$CFG.so"
+if [ "$DROPIN" = "1" ] || [ "$MPI" = "1" ]; then
+  if [ -f "$TARGET" ] && [ -z "$(find "$HERE/ref_capi.F90" "$HERE/build_ref.sh" "$HERE/../cice4_amd/fortran" \
+        -newer "$TARGET" -name '*.F90' -o -newer "$TARGET" -name '*.sh' 2>/dev/null | head -1)" ]; then
+    echo "up to date $TARGET"
+    exit 0
+  fi
+fi
 OBJS=""
 for s in $SRCS; do
   src="$REF/$s"
