@@ -212,6 +212,22 @@ struct SubArgs {
 namespace {
 
 
+// Neighbour-lane exchange without the LDS crossbar: DPP wave shifts (gfx9 family; checked against
+// __shfl_up/__shfl_down on gfx950 by scripts/probe/dpp_wave_shift_probe.hip).  Lane 0 of up1 and
+// lane 63 of down1 keep their own value, exactly like __shfl_up(x, 1) / __shfl_down(x, 1).
+__device__ __forceinline__ double up1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double down1(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
 constexpr int TX = 64;  // T-cells per tile row = one wavefront
 
 // Momentum update of one U-cell inside the fused kernel + forwarding of the new velocity to
@@ -579,7 +595,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
       vs = ld8(a.v_in + base, qo - nx8);
     }
   }
-  double uw = __shfl_up(un, 1), vw = __shfl_up(vn, 1), usw = __shfl_up(us, 1), vsw = __shfl_up(vs, 1);
+  double uw = up1(un), vw = up1(vn), usw = up1(us), vsw = up1(vs);
   if (reload_w && ld && col >= 2) {
     uw = ld8(a.u_in + base, qo - 8u);
     vw = ld8(a.v_in + base, qo - 8u);
@@ -603,7 +619,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
         he = ld8(a.HTE + base, qo);
         if (j >= 2) hn_s = ld8(a.HTN + base, qo - nx8);
       }
-      hew = __shfl_up(he, 1);
+      hew = up1(he);
       if (reload_w && ld && col >= 2) hew = ld8(a.HTE + base, qo - 8u);
     }
     if (tact) {
@@ -644,8 +660,8 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
     stress_cell<false, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm,
                              Cym, 0.0, Tiny, St, s, o);
   }
-  double e1 = __shfl_down(o.str[1], 1), e3 = __shfl_down(o.str[3], 1), e6 = __shfl_down(o.str[6], 1),
-         e7 = __shfl_down(o.str[7], 1);
+  double e1 = down1(o.str[1]), e3 = down1(o.str[3]), e6 = down1(o.str[6]),
+         e7 = down1(o.str[7]);
   s_str[w][0][lx] = o.str[2];
   s_str[w][1][lx] = e3;
   s_str[w][2][lx] = o.str[5];
@@ -668,7 +684,7 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
   // the opposite edge after every subcycle (:397-402).  On the ghost rows nothing ever changes,
   // and their corner ghosts keep whatever they hold.
   const bool mirror_n = cyc && j >= jlo && j <= jhi, mirror_s = cyc && j - 1 >= jlo && j - 1 <= jhi;
-  const double gu = __shfl_down(u1, 1), gv = __shfl_down(v1, 1);   // G mirrors column ilo = next lane
+  const double gu = down1(u1), gv = down1(v1);   // G mirrors column ilo = next lane
   const double un1 = (isG && mirror_n) ? gu : u1, vn1 = (isG && mirror_n) ? gv : v1;
   s_uv[w][0][lx] = un1;
   s_uv[w][1][lx] = vn1;
@@ -680,12 +696,12 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
     us1 = s_uv[w - 1][0][lx];
     vs1 = s_uv[w - 1][1][lx];
   }
-  double uw1 = __shfl_up(un1, 1), vw1 = __shfl_up(vn1, 1), usw1 = __shfl_up(us1, 1), vsw1 = __shfl_up(vs1, 1);
+  double uw1 = up1(un1), vw1 = up1(vn1), usw1 = up1(us1), vsw1 = up1(vs1);
   {
     // at ilo the west neighbour is column ihi, two lanes to the left (G sits in between), or,
     // where nothing mirrors, the ghost column's own unchanged value
-    const double uw2 = __shfl_up(un1, 2), vw2 = __shfl_up(vn1, 2), usw2 = __shfl_up(us1, 2),
-                 vsw2 = __shfl_up(vs1, 2);
+    const double uw2 = up1(up1(un1)), vw2 = up1(up1(vn1)), usw2 = up1(up1(us1)),
+                 vsw2 = up1(up1(vs1));
     if (at_ilo) {
       uw1 = uw2; vw1 = vw2; usw1 = usw2; vsw1 = vsw2;
       if (!mirror_n && ld) {   // unchanged ghost value: read it again rather than keep it in registers
@@ -716,8 +732,8 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
       }
     }
   }
-  e1 = __shfl_down(o.str[1], 1); e3 = __shfl_down(o.str[3], 1);
-  e6 = __shfl_down(o.str[6], 1); e7 = __shfl_down(o.str[7], 1);
+  e1 = down1(o.str[1]); e3 = down1(o.str[3]);
+  e6 = down1(o.str[6]); e7 = down1(o.str[7]);
   s_str[w][0][lx] = o.str[2];   // stage-1 values were consumed before the previous barrier
   s_str[w][1][lx] = e3;
   s_str[w][2][lx] = o.str[5];
