@@ -716,7 +716,9 @@ __global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_su
   }
 #pragma unroll
   for (int c = 0; c < 8; ++c) o.str[c] = c0;
-  if (tact) {
+  // the second stress evaluation of the first and the last wavefront feeds nothing: sigma'' is owned by
+  // wavefronts 1..W-3 and u'' of wavefront w needs str of wavefronts w and w+1 <= W-2
+  if (tact && w >= 1 && w <= W - 2) {
     metrics();
     stress_cell<LAST, DAMP>(a.sc, un1, uw1, usw1, us1, vn1, vw1, vsw1, vs1, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp,
                             Cxm, Cym, Tarear, Tiny, St, s, o);
