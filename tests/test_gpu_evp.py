@@ -501,3 +501,16 @@ def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
     dom = ctx.domain_create_slabs(96, 72, 4, ew=1, ns=0, overlap=4)
     ctx.evp_init(synth.block_fields(synth.global_grid(96, 72, seed=3), dom), ndte=4)
     assert ctx.evp_get_info("fused") == 1
+
+
+def test_pairing_fuzz():
+    """scripts/fuzz_pairing.py: 30 random grids / boundary types / subcycle counts / workgroup heights,
+    with the never-written ghost cells made different from the cells they would mirror: two subcycles per
+    launch == one per launch, bit for bit."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pairing.py"), "30", "11"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "FUZZ-OK 30" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
