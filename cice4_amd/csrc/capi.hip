@@ -23,6 +23,7 @@ struct cice_ctx {
   bool have_domain = false;
   std::unique_ptr<Halo> halo;
   std::unique_ptr<Evp> evp;
+  std::vector<void*> pinned;   // cice_host_register
   // thermo
   ThermoParams tp{};
   bool have_thermo = false;
@@ -131,8 +132,19 @@ int cice_device_count(void) {
   return n;
 }
 
+int cice_host_register(cice_ctx* ctx, void* host, size_t bytes) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(host && bytes, "NULL array");
+  c_->need_device();
+  if (hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess) c_->pinned.push_back(host);
+  else (void)hipGetLastError();   // already registered, or not registrable: stays pageable
+  CICE_CATCH
+}
+
 int cice_destroy(cice_ctx* ctx) {
   if (!ctx) return CICE_EINVAL;
+  for (void* h : ctx->pinned)
+    if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
   ctx->evp.reset();
   ctx->halo.reset();
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -298,6 +310,30 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   c_->evp->upload(*f);
   c_->evp->step(dt);
   c_->evp->download(*f);
+  CICE_CATCH
+}
+int cice_evp_pin_fields(cice_ctx* ctx, const cice_evp_fields* f) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(f, "NULL argument");
+  const size_t n = (size_t)c_->dom.nblocks() * c_->dom.nx_block * c_->dom.ny_block;
+  auto pin = [&](const void* h, size_t bytes) {
+    if (!h) return;
+    if (hipHostRegister(const_cast<void*>(h), bytes, hipHostRegisterDefault) == hipSuccess)
+      c_->pinned.push_back(const_cast<void*>(h));
+    else
+      (void)hipGetLastError();
+  };
+  const double* r8[] = {f->aice, f->vice, f->vsno, f->aice0, f->strairxT, f->strairyT, f->uocn, f->vocn,
+                        f->ss_tltx, f->ss_tlty, f->uvel, f->vvel, f->stressp_1, f->stressp_2, f->stressp_3,
+                        f->stressp_4, f->stressm_1, f->stressm_2, f->stressm_3, f->stressm_4, f->stress12_1,
+                        f->stress12_2, f->stress12_3, f->stress12_4, f->fm, f->strtltx, f->strtlty, f->strocnx,
+                        f->strocny, f->strintx, f->strinty, f->strairx, f->strairy, f->strength, f->divu,
+                        f->shear, f->rdg_conv, f->rdg_shear, f->prs_sig, f->strocnxT, f->strocnyT};
+  for (const double* h : r8) pin(h, n * 8);
+  pin(f->aicen, n * NCAT * 8);
+  pin(f->vicen, n * NCAT * 8);
+  pin(f->iceumask, n * 4);
   CICE_CATCH
 }
 int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) NEED_EVP; c_->evp->prepare(dt); CICE_CATCH }

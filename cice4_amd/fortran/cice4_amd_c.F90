@@ -49,6 +49,11 @@ module cice4_amd_c
       integer(c_int) function cice_device_count() bind(C, name='cice_device_count')
          import
       end function
+      integer(c_int) function cice_host_register(ctx, host, bytes) bind(C, name='cice_host_register')
+         import
+         type(c_ptr), value :: ctx, host
+         integer(c_size_t), value :: bytes
+      end function
       integer(c_int) function cice_destroy(ctx) bind(C, name='cice_destroy')
          import
          type(c_ptr), value :: ctx
@@ -107,6 +112,11 @@ module cice4_amd_c
          import
          type(c_ptr), value :: ctx
          real(c_double), value :: dt
+         type(cice_evp_fields), intent(in) :: f
+      end function
+      integer(c_int) function cice_evp_pin_fields(ctx, f) bind(C, name='cice_evp_pin_fields')
+         import
+         type(c_ptr), value :: ctx
          type(cice_evp_fields), intent(in) :: f
       end function
       integer(c_int) function cice_thermo_init(ctx, cfg, salin, Tmlt) bind(C, name='cice_thermo_init')
@@ -174,6 +184,14 @@ contains
       type(c_ptr) :: p
       p = c_loc(a)
    end function addr_l4
+
+   ! page-lock a module array (its address does not change during the run): asynchronous DMA afterwards
+   subroutine cice_gpu_pin_r8(a, n)
+      real(c_double), target, intent(in) :: a(*)
+      integer, intent(in) :: n
+      integer(c_int) :: rc
+      rc = cice_host_register(cice_gpu_ctx, c_loc(a), int(n, c_size_t) * 8_c_size_t)
+   end subroutine cice_gpu_pin_r8
 
    subroutine cice_gpu_check(rc, where)
       integer(c_int), intent(in) :: rc

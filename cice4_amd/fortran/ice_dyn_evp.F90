@@ -38,6 +38,7 @@
       real (kind=dbl_kind) :: ecci, dtei, dte2T, denom1, denom2, rcon
 
       real (kind=dbl_kind), allocatable :: fcor_blk(:,:,:)
+      logical, save, private :: fields_pinned = .false.
 
       contains
 
@@ -71,6 +72,10 @@
       f%rdg_conv = addr_r8(rdg_conv); f%rdg_shear = addr_r8(rdg_shear)
       f%prs_sig = addr_r8(prs_sig)
       f%strocnxT = addr_r8(strocnxT); f%strocnyT = addr_r8(strocnyT)
+      if (.not. fields_pinned) then   ! module arrays never move: page-lock them once (asynchronous DMA)
+         call cice_gpu_check(cice_evp_pin_fields(cice_gpu_ctx, f), 'cice_evp_pin_fields')
+         fields_pinned = .true.
+      endif
       call cice_gpu_check(cice_evp(cice_gpu_ctx, dt, f), 'evp')
       call ice_timer_stop(timer_dynamics)
       end subroutine evp

@@ -235,6 +235,11 @@ class Context:
         f = self._evp_fields(s)
         self._ck(self.lib.cice_evp(self.h, C.c_double(dt), C.byref(f)))
 
+    def evp_pin_fields(self, s):
+        """Page-lock the arrays of s (they must stay alive and keep their addresses)."""
+        f = self._evp_fields(s)
+        self._ck(self.lib.cice_evp_pin_fields(self.h, C.byref(f)))
+
     def evp_upload(self, s):
         f = self._evp_fields(s)
         self._ck(self.lib.cice_evp_upload(self.h, C.byref(f)))
@@ -325,6 +330,10 @@ class Context:
         for n, _t in ThermoFields._fields_:
             setattr(f, n, _f8(a[n]) if n in a else None)
         return f
+
+    def host_register(self, arr):
+        """Page-lock a numpy array that will be passed to evp()/thermo entries repeatedly."""
+        self._ck(self.lib.cice_host_register(self.h, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
 
     def thermo_batch_upload(self, a):
         f = self._thermo_fields(a)

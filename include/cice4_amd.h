@@ -19,6 +19,7 @@
  */
 #ifndef CICE4_AMD_H
 #define CICE4_AMD_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -45,6 +46,12 @@ typedef struct cice_ctx cice_ctx;
 int cice_create(cice_ctx **ctx, int device);
 /* number of HIP devices visible to this process (0 without a GPU): an MPI task picks my_task mod this */
 int cice_device_count(void);
+/* Page-lock a host array that will be handed to the drop-in entries again and again (the model's module
+ * arrays keep their addresses for the whole run): transfers then run as asynchronous DMA instead of
+ * through the runtime's staging buffer -- a latency matter, 71 separate 1-MB fields per evp(dt) at gx1.
+ * Purely an optimisation: arrays that cannot be registered are used pageable.  Registered ranges are
+ * released by cice_destroy. */
+int cice_host_register(cice_ctx *ctx, void *host, size_t bytes);
 int cice_destroy(cice_ctx *ctx);
 const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
 int cice_device_sync(cice_ctx *ctx);
@@ -132,6 +139,8 @@ typedef struct {
   double *strairx, *strairy, *strength, *divu, *shear, *rdg_conv, *rdg_shear, *prs_sig,
       *strocnxT, *strocnyT;
 } cice_evp_fields;
+/* cice_host_register for every array of the struct (once, for arrays that keep their addresses) */
+int cice_evp_pin_fields(cice_ctx *ctx, const cice_evp_fields *f);
 
 /* Drop-in for `call evp(dt)` (ice_dyn_evp.F90:119-432): upload, run on the GPU,
  * download.  Equivalent to cice_evp_upload + cice_evp_step + cice_evp_download. */
