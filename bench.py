@@ -67,7 +67,7 @@ def parse():
                    help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
                         "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
     p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
-    p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/16); 0 = auto")
+    p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/13/14/16); 0 = auto")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")

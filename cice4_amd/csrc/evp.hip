@@ -541,7 +541,7 @@ __device__ __forceinline__ void stepu_store_o(const SubArgs& a, const UIn& x, si
 }
 
 template <int W, bool LAST, bool DAMP, bool DERIVE>
-__global__ __launch_bounds__(64 * W, (W <= 8 ? 4 : (W <= 12 ? 3 : 2))) void k_subcycle2(const SubArgs a) {
+__global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const SubArgs a) {
   __shared__ double s_str[W][4][TX];
   __shared__ double s_uv[W][2][TX];
   const int per_blk = a.tiles_x * a.tiles_y;
@@ -1102,7 +1102,8 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "fuse")) {          // two subcycles per launch where the domain allows
     fuse_on = value != 0;
   } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
-    CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 16, "fused_waves must be 0, 8, 12 or 16");
+    CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 13 || value == 14 || value == 16,
+                 "fused_waves must be 0, 8, 12, 13, 14 or 16");
     waves2 = value;
   } else {
     throw Error{CICE_EINVAL, std::string("unknown option ") + key};
@@ -1429,7 +1430,8 @@ int Evp::fused_waves() const {
   // Workgroups are dealt evenly to the CUs, so a launch lasts about ceil(workgroups / CUs) x W
   // wavefront-times (measured: gx3 9.9 / 12.5 / 15.4 us, gx1 17.6 / 25.4 / 17.8 us, 0.1 degree
   // 944 / 968 / 857 us for W = 8 / 12 / 16).  Taller workgroups own a larger share of their rows
-  // ((W-3)/W) but quantise worse on small grids.
+  // ((W-3)/W) but quantise worse on small grids.  W = 13 is there for gx1: 234 workgroups, one round,
+  // and its four SIMDs carry 4 (two of them the light rim wavefronts), 3, 3, 3 wavefronts: +4 %.
   int ncu = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -1439,7 +1441,7 @@ int Evp::fused_waves() const {
   const long long tx = (cols + OWN_LANES - 1) / OWN_LANES;
   int best = 8;
   long long best_cost = -1;
-  for (int w : {8, 16, 12}) {
+  for (int w : {8, 16, 12, 13, 14}) {
     const long long wg = tx * ((rows + (w - 3) - 1) / (w - 3)) * dom.nblocks();
     const long long cost = ((wg + ncu - 1) / ncu) * w;
     if (best_cost < 0 || cost < best_cost) {
@@ -1462,8 +1464,10 @@ void Evp::launch_subcycle_pair(int ksub) {
   switch (W) {
     case 8: launch2_w<8>(a, last, damp, g, stream); break;
     case 12: launch2_w<12>(a, last, damp, g, stream); break;
+    case 13: launch2_w<13>(a, last, damp, g, stream); break;
+    case 14: launch2_w<14>(a, last, damp, g, stream); break;
     case 16: launch2_w<16>(a, last, damp, g, stream); break;
-    default: throw Error{CICE_EINVAL, "fused_waves must be 8, 12 or 16"};
+    default: throw Error{CICE_EINVAL, "fused_waves must be 8, 12, 13, 14 or 16"};
   }
   after_subcycle(ksub + 1);
 }

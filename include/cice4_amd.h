@@ -161,7 +161,7 @@ int cice_evp_finish(cice_ctx *ctx);
  * per wavefront: 1, 2, 4, 8), "use_graph" (0/1), "derive_metrics" (0/1, see cice_evp_grid),
  * "fuse" (0/1: two subcycles per launch where no ghost row of a local block changes between
  * subcycles -- one full-width block per rank or wide-halo slabs with an even overlap),
- * "fused_waves" (0 = auto, 8, 12, 16).
+ * "fused_waves" (0 = auto, 8, 12, 13, 14, 16).
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
  * (1 if this domain runs two subcycles per launch), "fused_waves". */

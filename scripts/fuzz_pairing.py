@@ -37,7 +37,7 @@ def main():
         ndte = int(rng.choice([1, 2, 3, 8, 11, 24]))
         damping = bool(rng.integers(0, 2))
         cover = str(rng.choice(["full", "patchy"]))
-        fw = int(rng.choice([0, 8, 12, 16]))
+        fw = int(rng.choice([0, 8, 12, 13, 14, 16]))
         dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=0)
         gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=100 + case)
         grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
