@@ -24,6 +24,10 @@ struct cice_ctx {
   std::unique_ptr<Halo> halo;
   std::unique_ptr<Evp> evp;
   std::vector<void*> pinned;   // cice_host_register
+  // staging of the host-pointer entries (thermo_vertical is called ncat x nblocks times per step with
+  // the same block size: allocated once, grown only when a larger block comes along)
+  DevBuf<double> tv_stage, fz_stage;
+  DevBuf<int32_t> tv_list;
   // thermo
   ThermoParams tp{};
   bool have_thermo = false;
@@ -466,10 +470,10 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
          A_FLW = A_ESNON + NSLYR, A_POTT, A_QA, A_RHOA, A_FSNOW, A_FBOT, A_TBOT, A_LH, A_SH, A_FSWSFC,
          A_FSWINT, A_FSWTHRU, A_SSW, A_ISW = A_SSW + NSLYR, A_OUT = A_ISW + NILYR, A_MLT = A_OUT + 15,
          A_FRZ, A_END };
-  DevBuf<double> d;
-  d.alloc((size_t)A_END * np);
-  DevBuf<int32_t> li;
-  li.alloc(2 * np);
+  DevBuf<double>& d = c_->tv_stage;
+  if (d.n < (size_t)A_END * np) d.alloc((size_t)A_END * np);
+  DevBuf<int32_t>& li = c_->tv_list;
+  if (li.n < 2 * np) li.alloc(2 * np);
   auto up = [&](int plane, const double* h, int planes = 1) {
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
     CICE_HIP(hipMemcpyAsync(d.p + (size_t)plane * np, h, (size_t)planes * np * 8, hipMemcpyHostToDevice, s));
@@ -705,8 +709,8 @@ int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, 
   hipStream_t s = c_->stream;
   const size_t np = (size_t)nx * ny;
   const int NE = NCAT * NILYR, NSN = NCAT * NSLYR;
-  DevBuf<double> d;
-  d.alloc((size_t)(9 + NE + NSN) * np);
+  DevBuf<double>& d = c_->fz_stage;
+  if (d.n < (size_t)(9 + NE + NSN) * np) d.alloc((size_t)(9 + NE + NSN) * np);
   auto up = [&](size_t plane, const double* h, size_t planes = 1) {
     CICE_REQUIRE(h != nullptr, "frzmlt_bottom_lateral: NULL array");
     CICE_HIP(hipMemcpyAsync(d.p + plane * np, h, planes * np * 8, hipMemcpyHostToDevice, s));
