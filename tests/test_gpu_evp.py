@@ -515,3 +515,24 @@ def test_pairing_fuzz():
     p = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_pairing.py"), "30", "11"],
                        capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "FUZZ-OK 30" in p.stdout, p.stdout[-1500:] + p.stderr[-1500:]
+
+
+def test_page_locked_host_arrays_give_the_same_result(orc):
+    """cice_evp_pin_fields / cice_host_register only change how the host arrays travel."""
+    c = lib.Context(); c.sync()
+    dom = c.domain_create(64, 40, 64, 40, ew=1, ns=0)
+    grid = synth.block_fields(synth.global_grid(64, 40, perturb=0.1, land_frac=0.05, seed=4), dom)
+    s = synth.evp_state(grid, dom, seed=4, cover="patchy")
+    c.evp_init(grid, ndte=8)
+    a = {k: v.copy() for k, v in s.items()}
+    c.evp(DT, a)
+    b = {k: v.copy() for k, v in s.items()}
+    c.evp_pin_fields(b)
+    extra = np.zeros(1000)
+    c.host_register(extra); c.host_register(extra)      # registering twice is harmless
+    c.evp(DT, b)
+    c.evp(DT, b)                                        # second call on the same (pinned) arrays: state carried
+    c.evp(DT, a)
+    for k in EVP_OUT_FIELDS:
+        assert np.array_equal(a[k], b[k]), k
+    del c
