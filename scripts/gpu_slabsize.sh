@@ -1,14 +1,12 @@
 #!/bin/bash
-# kernel-only time of the slab one rank of N works on at gx1 (H overlap rows each side)
+# kernel-only time of the slab one rank of N works on at gx1 (overlap rows included), and 0.1 degree over 8
 set -e
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 B="--no-cpu-baseline --no-dropin-timing --no-thermo"
 : > gpurun_out/slabsize.jsonl
-for wl in 320x384 320x232 320x120 320x72 320x56 3600x312; do
-  for opt in "" "--no-fuse" "--fused-waves 8" "--fused-waves 16"; do
-    timeout -k 10 300 python bench.py --workload $wl $B $opt >> gpurun_out/slabsize.jsonl 2>> gpurun_out/slabsize.err
-  done
+for wl in 320x384 320x232 320x144 320x96 3600x312; do
+  timeout -k 10 300 python bench.py --workload $wl $B >> gpurun_out/slabsize.jsonl 2>> gpurun_out/slabsize.err
 done
 python - <<'PY'
 import json
