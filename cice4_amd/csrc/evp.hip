@@ -544,6 +544,11 @@ template <int W, bool LAST, bool DAMP, bool DERIVE>
 __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const SubArgs a) {
   __shared__ double s_str[W][4][TX];
   __shared__ double s_uv[W][2][TX];
+  // W = 16 (the large grids, where a CU works through many workgroups one at a time): the eight U-cell
+  // inputs are parked in LDS between the two momentum updates instead of being fetched again -- 0.1 degree
+  // +6 %; at gx1 (W = 13) the extra LDS traffic costs 2 %, so the smaller shapes fetch twice (L2 hits)
+  constexpr bool PARK = DERIVE && W >= 16;
+  __shared__ double s_x[PARK ? W : 1][8][TX];
   const int per_blk = a.tiles_x * a.tiles_y;
   const int nt = per_blk * a.nblocks;
   const int chunk = (nt + 7) >> 3;
@@ -674,6 +679,10 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
     UIn x;   // fetched for each of the two momentum updates (L2 hits the second time): they would
              // otherwise occupy 16-20 registers across both stress evaluations
     load_uin_o<DERIVE>(a, base, qo, x);
+    if (PARK) {
+      s_x[w][0][lx] = x.aiu; s_x[w][1][lx] = x.uocn; s_x[w][2][lx] = x.vocn; s_x[w][3][lx] = x.forcex;
+      s_x[w][4][lx] = x.forcey; s_x[w][5][lx] = x.umassdtei; s_x[w][6][lx] = x.fm; s_x[w][7][lx] = x.uarear;
+    }
     StepuOut r;
     stepu_cell(un, vn, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                x.uarear, sx, sy, r);
@@ -745,7 +754,14 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
     const double sx = o.str[0] + e1 + s_str[w + 1][0][lx] + s_str[w + 1][1][lx];
     const double sy = o.str[4] + s_str[w + 1][2][lx] + e6 + s_str[w + 1][3][lx];
     UIn x;
-    load_uin_o<DERIVE>(a, base, qo, x);
+    if (PARK) {   // this lane wrote them itself before the first momentum update
+      x.aiu = s_x[w][0][lx]; x.uocn = s_x[w][1][lx]; x.vocn = s_x[w][2][lx]; x.forcex = s_x[w][3][lx];
+      x.forcey = s_x[w][4][lx]; x.umassdtei = s_x[w][5][lx]; x.fm = s_x[w][6][lx]; x.uarear = s_x[w][7][lx];
+      x.waterx = x.uocn * cosw - x.vocn * sinw;
+      x.watery = x.vocn * cosw + x.uocn * sinw;
+    } else {
+      load_uin_o<DERIVE>(a, base, qo, x);
+    }
     stepu_store_o<LAST>(a, x, base, qo, col, j, ilo, ihi, jlo, jhi, u1, v1, sx, sy);
   }
 }
