@@ -60,6 +60,7 @@ class Evp {
   bool use_graph = true;
   bool fuse_on = true;
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
+  mutable int waves2_auto = 0;  // the automatic choice, once made
   int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop
   bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)
   size_t n = 0;  // nblocks*ny*nx

@@ -1443,6 +1443,7 @@ bool Evp::can_fuse() const {
 
 int Evp::fused_waves() const {
   if (waves2) return waves2;
+  if (waves2_auto) return waves2_auto;   // domain and device do not change under an Evp
   // Workgroups are dealt evenly to the CUs, so a launch lasts about ceil(workgroups / CUs) x W
   // wavefront-times (measured: gx3 9.9 / 12.5 / 15.4 us, gx1 17.6 / 25.4 / 17.8 us, 0.1 degree
   // 944 / 968 / 857 us for W = 8 / 12 / 16).  Taller workgroups own a larger share of their rows
@@ -1465,6 +1466,7 @@ int Evp::fused_waves() const {
       best_cost = cost;
     }
   }
+  waves2_auto = best;
   return best;
 }
 
