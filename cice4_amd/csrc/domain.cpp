@@ -41,8 +41,11 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
       b.ilo = 2; b.jlo = 2;
       b.ihi = 1 + std::min(bsx, nxg - b.i0);  // padded last block: ice_blocks.F90:171-178
       b.jhi = 1 + std::min(bsy, nyg - b.j0);
-      // contiguous rectangles of blocks per rank (cartesian distribution)
-      int px = (int)((long long)ib * npx / nbx), py = (int)((long long)jb * npy / nby);
+      // contiguous rectangles of blocks per rank, dealt the way create_distrb_cart does
+      // (ice_distribution.F90:719-732): ceil(nblocks / nprocs) block columns (rows) per process
+      // column (row), the last ones taking what is left -- possibly nothing
+      const int per_x = (nbx - 1) / npx + 1, per_y = (nby - 1) / npy + 1;
+      const int px = ib / per_x, py = jb / per_y;
       b.owner = py * npx + px;
       b.local_id = nlocal[b.owner]++;
       b.own_jlo = b.jlo; b.own_jhi = b.jhi;

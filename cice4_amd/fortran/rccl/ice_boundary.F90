@@ -30,7 +30,7 @@ module ice_boundary
    use ice_domain_size, only: nx_global, ny_global, block_size_x, block_size_y
    use ice_blocks, only: nx_block, ny_block, nghost, nblocks_x, nblocks_y, block, get_block
    use ice_distribution, only: distrb, ice_distributionGet, ice_distributionGetBlockLoc, &
-                               ice_distributionGetBlockID
+                               ice_distributionGetBlockID, nprocsX, nprocsY
    use ice_exit, only: abort_ice
    use cice4_amd_c
 
@@ -77,16 +77,23 @@ contains
 
       call ice_distributionGet(dist, nprocs=nprocs, communicator=halo%communicator, &
                                numLocalBlocks=numBlocks)
-      ! process grid of the cartesian distribution: distinct owners along the first block row
-      npx = 0; last = -1
+      ! process grid of the cartesian distribution (set by create_distrb_cart, ice_distribution.F90:701)
+      npx = nprocsX; npy = nprocsY
+      if (npx < 1 .or. npy < 1 .or. npx*npy /= nprocs) then
+         ! not set (another distribution type): distinct owners along the first block row
+         npx = 0; last = -1
+         do ib = 1, nblocks_x
+            call ice_distributionGetBlockLoc(dist, ib, proc, lid)
+            if (proc /= last) npx = npx + 1
+            last = proc
+         enddo
+         if (mod(nprocs, npx) /= 0) call abort_ice('ice_HaloCreate: distribution is not cartesian')
+         npy = nprocs/npx
+      endif
       do ib = 1, nblocks_x
          call ice_distributionGetBlockLoc(dist, ib, proc, lid)
          if (proc == 0) call abort_ice('ice_HaloCreate: land-block elimination is not supported')
-         if (proc /= last) npx = npx + 1
-         last = proc
       enddo
-      if (mod(nprocs, npx) /= 0) call abort_ice('ice_HaloCreate: distribution is not cartesian')
-      npy = nprocs/npx
 
       ! one task = one GPU: task t takes device mod(t, visible devices)
       call cice_gpu_ensure(mod(my_task, max(1, cice_device_count())))

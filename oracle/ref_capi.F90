@@ -337,6 +337,30 @@ contains
       ref_init_domain = nblocks
    end function ref_init_domain
 
+   ! block decomposition and distribution only (init_domain_blocks + init_domain_distribution with an
+   ! all-ocean mask): what decides which task owns which block.  Works under mpiexec with the MPI build.
+   integer(c_int) function ref_init_topology(info) bind(C, name='ref_init_topology')
+      use ice_domain, only: init_domain_blocks, init_domain_distribution, nblocks
+      use ice_communicate, only: my_task
+      use ice_distribution, only: nprocsX, nprocsY
+      integer(c_int), intent(out) :: info(4)
+      real(dbl_kind), allocatable :: kmtg(:,:), ulatg(:,:)
+      call ref_boot
+      call init_domain_blocks
+      allocate(kmtg(nx_global,ny_global), ulatg(nx_global,ny_global))
+      kmtg = c1
+      ulatg = 1.3_dbl_kind
+      call init_domain_distribution(kmtg, ulatg)
+      deallocate(kmtg, ulatg)
+      info(1) = my_task; info(2) = nprocsX; info(3) = nprocsY; info(4) = nblocks
+      ref_init_topology = nblocks
+   end function ref_init_topology
+
+   subroutine ref_end_run() bind(C, name='ref_end_run')
+      use ice_exit, only: end_run
+      call end_run
+   end subroutine ref_end_run
+
    subroutine ref_block_info(iblk, info, iglob, jglob) bind(C, name='ref_block_info')
       use ice_blocks
       use ice_domain, only: blocks_ice
