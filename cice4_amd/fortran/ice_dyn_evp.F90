@@ -143,7 +143,7 @@
               1_c_int, 1_c_int), 'cice_domain_create')
       call cice_gpu_check(cice_domain_info(cice_gpu_ctx, info), 'cice_domain_info')
       if (info(1) /= nx_block .or. info(2) /= ny_block .or. info(3) /= nblocks .or. &
-          nblocks /= max_blocks) then
+          nblocks > max_blocks) then
          write(nu_diag,*) 'init_evp: GPU block layout differs from the host layout', info(1:3), &
                           nx_block, ny_block, nblocks, max_blocks
          error stop 'init_evp'

@@ -155,6 +155,15 @@ contains
       call cice_gpu_check(cice_halo_update_i4(cice_gpu_ctx, buf, nlev), who)
    end subroutine update_levels_i4
 
+   ! arrays are dimensioned max_blocks in their last dimension; this task's blocks are the first numBlocks
+   integer (int_kind) function local_blocks(halo, nlast, who)
+      type (ice_halo), intent(in) :: halo
+      integer (int_kind), intent(in) :: nlast
+      character (*), intent(in) :: who
+      if (nlast < halo%numBlocks) call abort_ice(who//': fewer blocks in the array than on this task')
+      local_blocks = halo%numBlocks
+   end function local_blocks
+
    subroutine check_shape(n1, n2, who)
       integer (int_kind), intent(in) :: n1, n2
       character (*), intent(in) :: who
@@ -170,11 +179,13 @@ contains
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (dbl_kind), intent(in), optional :: fillValue
       real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR8')
-      allocate(buf(nx_block,ny_block,size(array,3),1))
-      buf(:,:,:,1) = array
-      call update_levels_r8(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DR8')
-      array = buf(:,:,:,1)
+      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR8')
+      allocate(buf(nx_block,ny_block,nb,1))
+      buf(:,:,:,1) = array(:,:,1:nb)
+      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR8')
+      array(:,:,1:nb) = buf(:,:,:,1)
    end subroutine ice_HaloUpdate2DR8
 
    subroutine ice_HaloUpdate2DR4(array, halo, fieldLoc, fieldKind, fillValue)
@@ -183,11 +194,13 @@ contains
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
       real (dbl_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR4')
-      allocate(buf(nx_block,ny_block,size(array,3),1))
-      buf(:,:,:,1) = real(array, dbl_kind)          ! exact; the update only copies
-      call update_levels_r8(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DR4')
-      array = real(buf(:,:,:,1), real_kind)
+      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR4')
+      allocate(buf(nx_block,ny_block,nb,1))
+      buf(:,:,:,1) = real(array(:,:,1:nb), dbl_kind)          ! exact; the update only copies
+      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR4')
+      array(:,:,1:nb) = real(buf(:,:,:,1), real_kind)
    end subroutine ice_HaloUpdate2DR4
 
    subroutine ice_HaloUpdate2DI4(array, halo, fieldLoc, fieldKind, fillValue)
@@ -196,11 +209,13 @@ contains
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       integer (int_kind), intent(in), optional :: fillValue
       integer (int_kind), allocatable :: buf(:,:,:,:)
+      integer (int_kind) :: nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DI4')
-      allocate(buf(nx_block,ny_block,size(array,3),1))
-      buf(:,:,:,1) = array
-      call update_levels_i4(buf, size(array,3), 1, halo, 'ice_HaloUpdate2DI4')
-      array = buf(:,:,:,1)
+      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DI4')
+      allocate(buf(nx_block,ny_block,nb,1))
+      buf(:,:,:,1) = array(:,:,1:nb)
+      call update_levels_i4(buf, nb, 1, halo, 'ice_HaloUpdate2DI4')
+      array(:,:,1:nb) = buf(:,:,:,1)
    end subroutine ice_HaloUpdate2DI4
 
 !=======================================================================
@@ -213,7 +228,7 @@ contains
       real (dbl_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, n, nz, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR8')
-      nz = size(array,3); nb = size(array,4)
+      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DR8')
       allocate(buf(nx_block,ny_block,nb,nz))
       do k = 1, nz
       do n = 1, nb
@@ -236,7 +251,7 @@ contains
       real (dbl_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, n, nz, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR4')
-      nz = size(array,3); nb = size(array,4)
+      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DR4')
       allocate(buf(nx_block,ny_block,nb,nz))
       do k = 1, nz
       do n = 1, nb
@@ -259,7 +274,7 @@ contains
       integer (int_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, n, nz, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DI4')
-      nz = size(array,3); nb = size(array,4)
+      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DI4')
       allocate(buf(nx_block,ny_block,nb,nz))
       do k = 1, nz
       do n = 1, nb
@@ -284,7 +299,7 @@ contains
       real (dbl_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, l, n, nz, nt, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR8')
-      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DR8')
       allocate(buf(nx_block,ny_block,nb,nz*nt))
       do l = 1, nt
       do k = 1, nz
@@ -311,7 +326,7 @@ contains
       real (dbl_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, l, n, nz, nt, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR4')
-      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DR4')
       allocate(buf(nx_block,ny_block,nb,nz*nt))
       do l = 1, nt
       do k = 1, nz
@@ -338,7 +353,7 @@ contains
       integer (int_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, l, n, nz, nt, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DI4')
-      nz = size(array,3); nt = size(array,4); nb = size(array,5)
+      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DI4')
       allocate(buf(nx_block,ny_block,nb,nz*nt))
       do l = 1, nt
       do k = 1, nz

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # edge, ice_domain.F90:313-347); for ghost copies the reference treats 'closed' exactly like 'open'
 # (no neighbour: ice_blocks.F90:455-458,482-485,504-507,522-525), which is what 'open' covers here.
 CASES = [("gx3b4", "cyclic", "open"), ("pad", "cyclic", "open"), ("pad", "open", "open"),
-         ("pad", "open", "cyclic"), ("pad", "cyclic", "cyclic")]
+         ("pad", "open", "cyclic"), ("pad", "cyclic", "cyclic"), ("padx", "cyclic", "open")]   # padx: max_blocks > blocks
 
 
 def run_case(mode, cfg, ew, ns, *extra):

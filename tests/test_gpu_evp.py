@@ -224,48 +224,62 @@ def test_errors_are_reported_not_fatal(ctx):
         c2.domain_create(10, 10, 20, 20, ew=7)
 
 
-@pytest.mark.parametrize("kind", ["dropin", "dropinmpi"])
-def test_fortran_dropin_module_inside_reference_callers(orc, kind):
+@pytest.mark.parametrize("cfg,kind", [("gx3b4", "dropin"), ("gx3b4", "dropinmpi"), ("padx", "dropin")])
+def test_fortran_dropin_module_inside_reference_callers(orc, cfg, kind):
     """The drop-in proof: the reference's own compiled modules (ice_state, ice_flux, ice_grid,
     ice_domain, ... and the capture wrapper that calls `evp(dt)`) linked with OUR
     cice4_amd/fortran/ice_dyn_evp.F90 instead of the reference's.  `call evp(dt)` then goes
     Fortran -> ISO_C_BINDING shim -> libcice4_amd.so -> GPU, on the reference's own module
-    arrays and 2x2 block layout, and must reproduce the checker (pinned to the pure reference
+    arrays and block layout, and must reproduce the checker (pinned to the pure reference
     bit for bit by tests/test_oracle_vs_ref.py).
     kind 'dropinmpi': the same with the reference's mpi/ modules (MPICH, this process is a 1-rank MPI
     job): our boundary module then also broadcasts the RCCL id over MPI_COMM_ICE and creates the RCCL
-    communicator, as every task of an MPI build does."""
+    communicator, as every task of an MPI build does.
+    cfg 'padx': 3x3 blocks with padded last blocks in arrays dimensioned max_blocks = 12 > 9, as on a
+    task of an MPI run that owns fewer blocks than the largest share."""
     import tempfile
+    from __graft_entry__ import REF_CONFIGS
     from oracle import refapi
-    if not refapi.available("gx3b4", kind):
-        pytest.skip(f"oracle/_ref/libcice_{kind}_gx3b4.so not built")
-    ref = refapi.Ref("gx3b4", kind=kind)
+    if not refapi.available(cfg, kind):
+        pytest.skip(f"oracle/_ref/libcice_{kind}_{cfg}.so not built")
+    nxg, nyg, bsx, bsy, mxb = REF_CONFIGS[cfg]
+    ref = refapi.Ref(cfg, kind=kind)
     nb = ref.init_domain(tempfile.mkdtemp(), dt=DT, ndte=NDTE)
-    dom = lib.Context().domain_create(100, 116, 50, 58, ew=1, ns=0)
-    assert nb == 4 == dom["nblocks"]
-    grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.15, land_frac=0.05), dom)
+    dom = lib.Context().domain_create(nxg, nyg, bsx, bsy, ew=1, ns=0)
+    assert nb == dom["nblocks"] <= mxb == ref.max_blocks
+    ny, nx = dom["ny"], dom["nx"]
+
+    def full(a):       # host arrays carry max_blocks blocks; the task's blocks are the first nb
+        out = np.zeros((mxb * (a.shape[0] // nb),) + a.shape[1:], a.dtype)
+        out[:a.shape[0]] = a
+        return out
+
+    def mine(a, per=1):
+        return a[:nb * per]
+
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05), dom)
     s = synth.evp_state(grid, dom, cover="patchy")
     for k in ("dxt", "dyt", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym", "tarea", "uarea", "tarear",
               "uarear", "tinyarea", "fcor", "HTN", "HTE"):
-        ref.set(k, grid[k])
-    ref.set("tmask", grid["tmask"].astype(float)); ref.set("umask", grid["umask"].astype(float))
+        ref.set(k, full(grid[k]))
+    ref.set("tmask", full(grid["tmask"].astype(float))); ref.set("umask", full(grid["umask"].astype(float)))
     ref.set_strength_parameters(1, 0, 0, 4.0)      # exp-free strength: bit-for-bit comparison
     ref.evp_gpu_setup()
     for k in ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty",
               "uvel", "vvel", "fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx",
               "strinty") + synth.SIG_NAMES:
-        ref.set(k, s[k])
-    ref.set("iceumask", s["iceumask"].astype(float))
-    ny, nx = dom["ny"], dom["nx"]
-    ref.set("aicen", s["aicen"].reshape(-1, ny, nx)); ref.set("vicen", s["vicen"].reshape(-1, ny, nx))
+        ref.set(k, full(s[k]))
+    ref.set("iceumask", full(s["iceumask"].astype(float)))
+    ref.set("aicen", full(s["aicen"].reshape(-1, ny, nx))); ref.set("vicen", full(s["vicen"].reshape(-1, ny, nx)))
     ref.evp(DT)
     orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     so = {k: v.copy() for k, v in s.items()}
     orc.evp(orc.make_domain(dom, grid), so)
     orc.set_strength_parameters()
     for k in EVP_OUT_FIELDS:
-        assert np.array_equal(ref.get(k), so[k]), k
-    assert np.array_equal(ref.get("iceumask"), so["iceumask"])
+        assert np.array_equal(mine(ref.get(k)), so[k]), k
+    assert np.array_equal(mine(ref.get("iceumask")), so["iceumask"])
+    assert np.abs(so["uvel"]).max() > 0.01
 
 
 def test_standalone_fortran_driver(ctx, tmp_path):
