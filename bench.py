@@ -341,6 +341,8 @@ def main():
     except Exception:
         torch, have_torch_gpu = None, False
 
+    if os.environ.get("CICE4_AMD_BENCH_DEVICE") is not None:   # diagnostic: several ranks on one device
+        local = int(os.environ["CICE4_AMD_BENCH_DEVICE"])
     ctx = lib.Context(device=local)
     ctx.sync()                       # fails loudly without a GPU / HIP library
     calib = None
