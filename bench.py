@@ -332,6 +332,11 @@ def main():
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args)
         return
+    # NOTE on load order: torch is imported before the product library touches the device.  Both bring a
+    # HIP runtime and a librccl.so.1; whichever is loaded first serves the whole process, and loading the
+    # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With
+    # torch first, libcice4_amd.so runs on torch's bundled runtime and RCCL -- the combination
+    # scripts/gpu_slabs_selfcomm.sh exercises (graph capture of the grouped send/recv included).
     rank, world, local, dist = init_dist(args.gpus)
     try:
         import torch
