@@ -1,0 +1,80 @@
+"""One rank of `mpiexec -n P python tests/mpi_halo_case.py <cfg> <P> <processor_shape>`:
+the PURE reference in its MPI build exchanges ghost cells among the P ranks (mpi/ice_boundary.F90,
+real MPI messages); the product's per-rank lists (on-rank copies + per-peer send/receive address
+lists, cice_domain_create with this rank's coordinates) must fill every ghost cell with the same
+value.  The field is a function of the GLOBAL cell index, so what a peer would send is known here
+from that peer's own lists without any second exchange.  CPU only.  Prints 'HALO-OK <rank> ...'."""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import ctypes as C  # noqa: E402
+import numpy as np  # noqa: E402
+
+from __graft_entry__ import REF_CONFIGS  # noqa: E402
+from cice4_amd import lib  # noqa: E402
+from oracle import refapi  # noqa: E402
+
+
+def field_of(dom, nxg, nyg, what):
+    """Local array (nblocks, ny, nx) of a function of the global index on the physical cells."""
+    nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
+    a = np.zeros((nb, ny, nx))
+    for b in range(nb):
+        ii = np.arange(nx) - (dom["ilo"][b] - 1) + dom["i0"][b]
+        jj = np.arange(ny) - (dom["jlo"][b] - 1) + dom["j0"][b]
+        gi, gj = np.meshgrid(ii, jj, indexing="xy")
+        a[b] = what(gi, gj)
+    return a
+
+
+def main():
+    cfg, nprocs, shape = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    nxg, nyg, bsx, bsy, mxb = REF_CONFIGS[cfg]
+    ref = refapi.Ref(cfg, kind="refmpi")
+    wd = tempfile.mkdtemp()
+    with open(os.path.join(wd, "ice_in"), "w") as f:
+        f.write("&domain_nml\n  nprocs = %d\n  processor_shape = '%s'\n  distribution_type = 'cartesian'\n"
+                "  distribution_wght = 'latitude'\n  ew_boundary_type = 'cyclic'\n  ns_boundary_type = 'open'\n/\n"
+                % (nprocs, shape))
+    os.chdir(wd)
+    info = np.zeros(4, np.int32)
+    ref.lib.ref_init_topology.restype = C.c_int
+    nb = ref.lib.ref_init_topology(info.ctypes.data_as(C.c_void_p))
+    rank, npx, npy = int(info[0]), int(info[1]), int(info[2])
+    f = lambda gi, gj: 1000.0 * gj + gi + 0.25          # injective on the global grid
+    ctx = lib.Context()
+    dom = ctx.domain_create(nxg, nyg, bsx, bsy, ew=1, ns=0, rank=rank, npx=npx, npy=npy)
+    assert dom["nblocks"] == nb
+    ny, nx = dom["ny"], dom["nx"]
+    phys = field_of(dom, nxg, nyg, f)
+    start = np.full((mxb, ny, nx), -7.0)                 # ghosts (and unused blocks) start as garbage
+    for b in range(nb):
+        sl = (slice(dom["jlo"][b] - 1, dom["jhi"][b]), slice(dom["ilo"][b] - 1, dom["ihi"][b]))
+        start[b][sl] = phys[b][sl]
+    want = start.copy()
+    ref.halo_r8(want, 1, 1)                              # the reference's MPI exchange
+    got = start.copy().reshape(-1)
+    got[dom["hdst"]] = got[dom["hsrc"]]                  # on-rank part
+    recv = dict(ctx.halo_msgs(1))
+    nmsg = 0
+    for peer, raddr in recv.items():
+        pc = lib.Context()
+        pdom = pc.domain_create(nxg, nyg, bsx, bsy, ew=1, ns=0, rank=peer, npx=npx, npy=npy)
+        saddr = dict(pc.halo_msgs(0))[rank]              # what that peer sends to me, in its order
+        assert len(saddr) == len(raddr)
+        pphys = field_of(pdom, nxg, nyg, f).reshape(-1)  # sources are physical cells of the peer
+        got[raddr] = pphys[saddr]
+        nmsg += 1
+    got = got.reshape(start.shape)
+    assert np.array_equal(got, want), np.argwhere(got != want)[:5]
+    assert not np.array_equal(want, start)
+    print("HALO-OK", rank, f"{npx}x{npy}", "blocks", nb, "peers", nmsg, flush=True)
+    ref.lib.ref_end_run()
+
+
+if __name__ == "__main__":
+    main()
