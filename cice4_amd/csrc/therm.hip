@@ -618,10 +618,22 @@ __device__ __forceinline__ void thickness_changes(const ThermoParams& P, double 
   for (int k = 0; k < NI; ++k) c.efinal = c.efinal + c.hilyr * c.qin[k];
 }
 
+template <bool CALC>
+__device__ __forceinline__ void zero_outputs(const ThermoArgs& a, size_t c2d) {  // :299-329
+  a.fsensn[c2d] = c0; a.fswabsn[c2d] = c0; a.flwoutn[c2d] = c0; a.evapn[c2d] = c0;
+  a.freshn[c2d] = c0; a.fsaltn[c2d] = c0; a.fhocnn[c2d] = c0;
+  a.meltt[c2d] = c0; a.meltb[c2d] = c0; a.melts[c2d] = c0; a.congel[c2d] = c0; a.snoice[c2d] = c0;
+  if (CALC) {  // :321-329; inputs otherwise
+    a.flatn[c2d] = c0; a.fsurfn[c2d] = c0; a.fcondtopn[c2d] = c0;
+  }
+}
+
 // One column of thermo_vertical :108-515.  q: cell offset inside the (nx,ny) plane;
 // n, b: category and block (0-based); order: rank of this column in the reference's
 // failure-reporting order.
-template <bool CALC>
+// ZERO: the caller has NOT zeroed the 15 output planes of this column (batched kernel): every exit
+// of the routine then leaves them as the reference's initial zeroing (:299-329) plus its own stores would.
+template <bool CALC, bool ZERO>
 __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int b,
                                        unsigned long long order) {
   const ThermoParams& P = a.p;
@@ -646,6 +658,7 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   const unsigned stage0 = init_profile(P, aic, a.vicen[c2d], a.vsnon[c2d], a.trcrn[tq], ei, es, c);
   if (stage0) {
     atomicMin(a.errkey, ((unsigned long long)cb << 44) | ((unsigned long long)stage0 << 40) | order);
+    if (ZERO) zero_outputs<CALC>(a, c2d);
     return;
   }
   const double worki = c.hin, works = c.hsn;
@@ -671,6 +684,10 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   a.flatn[c2d] = f.flatn; a.fswabsn[c2d] = f.fswabsn; a.flwoutn[c2d] = f.flwoutn;
   if (!conv) {
     atomicMin(a.errkey, ((unsigned long long)cb << 44) | ((unsigned long long)ST_NOCONV << 40) | order);
+    if (ZERO) {
+      a.evapn[c2d] = c0; a.freshn[c2d] = c0; a.fsaltn[c2d] = c0; a.fhocnn[c2d] = c0; a.meltt[c2d] = c0;
+      a.melts[c2d] = c0; a.meltb[c2d] = c0; a.congel[c2d] = c0; a.snoice[c2d] = c0;
+    }
     return;
   }
   g.fbot = a.fbot[f2d]; g.fsnow = a.fsnow[f2d];
@@ -688,6 +705,9 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
     const double ferr = fabs(c.efinal - c.einit - einp) / a.dt;
     if (ferr > ferrmax) {
       atomicMin(a.errkey, ((unsigned long long)cb << 44) | ((unsigned long long)ST_ECONS << 40) | order);
+      if (ZERO) {
+        a.freshn[c2d] = c0; a.fsaltn[c2d] = c0;
+      }
       return;
     }
   }
@@ -716,15 +736,6 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   }
 }
 
-template <bool CALC>
-__device__ __forceinline__ void zero_outputs(const ThermoArgs& a, size_t c2d) {  // :299-329
-  a.fsensn[c2d] = c0; a.fswabsn[c2d] = c0; a.flwoutn[c2d] = c0; a.evapn[c2d] = c0;
-  a.freshn[c2d] = c0; a.fsaltn[c2d] = c0; a.fhocnn[c2d] = c0;
-  a.meltt[c2d] = c0; a.meltb[c2d] = c0; a.melts[c2d] = c0; a.congel[c2d] = c0; a.snoice[c2d] = c0;
-  if (CALC) {  // :321-329; inputs otherwise
-    a.flatn[c2d] = c0; a.fsurfn[c2d] = c0; a.fcondtopn[c2d] = c0;
-  }
-}
 
 // reference-signature form: one lane per entry of the compressed cell list
 template <bool CALC>
@@ -732,7 +743,7 @@ __global__ __launch_bounds__(256) void k_thermo_list(const ThermoArgs a) {
   const int ij = blockIdx.x * blockDim.x + threadIdx.x;
   if (ij >= a.icells) return;
   const size_t q = (size_t)(a.indxj[ij] - 1) * a.nx + (a.indxi[ij] - 1);
-  column<CALC>(a, q, 0, 0, (unsigned long long)ij);
+  column<CALC, false>(a, q, 0, 0, (unsigned long long)ij);
 }
 
 template <bool CALC>
@@ -756,11 +767,12 @@ __global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_dense(co
   const int n = blockIdx.y, b = blockIdx.z;
   if (q >= np) return;
   const size_t c2d = ((size_t)b * a.ncat + n) * np + q;
-  zero_outputs<CALC>(a, c2d);
   const int j = (int)(q / a.nx) + 1, i = (int)(q - (size_t)(j - 1) * a.nx) + 1;
   const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
   const bool active = i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.aicen[c2d] > puny;
-  if (active) column<CALC>(a, q, n, b, (unsigned long long)q);
+  // every point's 15 output planes are written exactly once: by its column, or zeroed here
+  if (active) column<CALC, true>(a, q, n, b, (unsigned long long)q);
+  else zero_outputs<CALC>(a, c2d);
   unsigned long long cnt = __popcll(__ballot(active));
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
 }
