@@ -7,6 +7,7 @@
 #include <string>
 
 #include "../../include/cice4_amd.h"
+#include "libm_exact.h"
 
 namespace cice {
 

@@ -969,7 +969,7 @@ __global__ __launch_bounds__(256) void k_strength(const PrepArgs a) {
   double st = c0;
   const bool phys = (i >= ilo && i <= ihi && j >= jlo && j <= jhi);
   if (a.kstrength != 1) {
-    if (phys) st = 2.75e4 * a.vice[t] * exp(-20.0 * (c1 - a.aice[t]));
+    if (phys) st = 2.75e4 * a.vice[t] * exp_libm(-20.0 * (c1 - a.aice[t]));
   } else if (i >= ilo && i <= ihi + 1 && j >= jlo && j <= jhi + 1 && a.icetmask[t] == 1) {
     constexpr double Cf = 17.0, Cp = p5 * gravit * (rhow - rhoi) * rhoi / rhow;
     constexpr double Gstar = 0.15, astar = 0.05, maxraft = 1.0, Hstar = 25.0;
@@ -1001,9 +1001,9 @@ __global__ __launch_bounds__(256) void k_strength(const PrepArgs a) {
           apartic[n] = Gstari * (Gstar - gm) * (c2 - (gm + Gstar) * Gstari);
       }
     } else {
-      const double xtmp = c1 / (c1 - exp(-astari));
+      const double xtmp = c1 / (c1 - exp_libm(-astari));
 #pragma unroll
-      for (int n = -1; n <= NCAT; ++n) Gsum[n + 1] = exp(-Gsum[n + 1] * astari) * xtmp;
+      for (int n = -1; n <= NCAT; ++n) Gsum[n + 1] = exp_libm(-Gsum[n + 1] * astari) * xtmp;
 #pragma unroll
       for (int n = 0; n <= NCAT; ++n) apartic[n] = Gsum[n] - Gsum[n + 1];
     }

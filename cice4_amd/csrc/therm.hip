@@ -225,7 +225,7 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
     if (CALC) {  // surface_fluxes :2389-2421
       const double TsfK = c.Tsf + Tffresh;
       const double tmpvar = c1 / TsfK;
-      const double qsat = qqqice * exp(-TTTice * tmpvar);
+      const double qsat = qqqice * exp_libm(-TTTice * tmpvar);
       const double Qsfc = qsat / f.rhoa;
       const double dQsfcdT = TTTice * tmpvar * tmpvar * Qsfc;
       const double flwdabs = emissivity * f.flw;

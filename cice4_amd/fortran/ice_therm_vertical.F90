@@ -5,7 +5,7 @@
 ! betak, kimin, salin, Tmlt, ustar_min, conduct, l_brine, heat_capacity,
 ! calc_Tsfc (ice_init.F90:107,941; ice_shortwave.F90:990; ice_diagnostics.F90:128;
 ! CICE_RunMod.F90:1029), thermo_vertical (CICE_RunMod.F90:502),
-! init_thermo_vertical (CICE_InitMod.F90), frzmlt_bottom_lateral
+! surface_fluxes (CICE_RunMod.F90:1216), init_thermo_vertical (CICE_InitMod.F90), frzmlt_bottom_lateral
 ! (CICE_RunMod.F90:363), calculate_Tin_from_qin (ice_history.F90:1731).
 ! The column physics runs on the GPU (libcice4_amd.so) through cice4_amd_c;
 ! nothing of the reference's implementation is kept here.
@@ -109,6 +109,44 @@
          jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside), &
          'frzmlt_bottom_lateral')
       end subroutine frzmlt_bottom_lateral
+
+!=======================================================================
+! Host-side helper kept because the stand-alone driver's explicit_calc_Tsfc (CICE_RunMod.F90:1216,
+! only reached with calc_Tsfc = F) calls it by name with this argument list: radiative and turbulent
+! surface fluxes and their Tsf derivatives for the first `isolve` entries of the (i, j, m) lists.
+      subroutine surface_fluxes (nx_block, ny_block, isolve, icells, indxii, indxjj, indxij, &
+                                 Tsf, fswsfc, rhoa, flw, potT, Qa, shcoef, lhcoef, &
+                                 flwoutn, fsensn, flatn, fsurfn, &
+                                 dflwout_dT, dfsens_dT, dflat_dT, dfsurf_dT)
+      integer (kind=int_kind), intent(in) :: nx_block, ny_block, isolve, icells
+      integer (kind=int_kind), dimension(icells), intent(in) :: indxii, indxjj
+      integer (kind=int_kind), dimension(icells) :: indxij
+      real (kind=dbl_kind), dimension(icells), intent(in) :: Tsf
+      real (kind=dbl_kind), dimension(nx_block,ny_block), intent(in) :: &
+         fswsfc, rhoa, flw, potT, Qa, shcoef, lhcoef
+      real (kind=dbl_kind), dimension(nx_block,ny_block), intent(inout) :: &
+         fsensn, flatn, flwoutn, fsurfn
+      real (kind=dbl_kind), dimension(icells), intent(inout) :: dfsens_dT, dflat_dT, dflwout_dT
+      real (kind=dbl_kind), dimension(isolve), intent(inout) :: dfsurf_dT
+      integer (kind=int_kind) :: n, i, j, m
+      real (kind=dbl_kind) :: TK, rTK, Qs, es
+
+      es = emissivity*stefan_boltzmann
+      do n = 1, isolve
+         i = indxii(n);  j = indxjj(n);  m = indxij(n)
+         TK  = Tsf(m) + Tffresh
+         rTK = c1/TK
+         Qs  = qqqice*exp(-TTTice*rTK) / rhoa(i,j)
+         flwoutn(i,j) = -es * TK**4
+         fsensn(i,j)  = shcoef(i,j) * (potT(i,j) - TK)
+         flatn(i,j)   = lhcoef(i,j) * (Qa(i,j) - Qs)
+         dflwout_dT(m) = -es * c4*TK**3
+         dfsens_dT(m)  = -shcoef(i,j)
+         dflat_dT(m)   = -lhcoef(i,j) * (TTTice*rTK*rTK*Qs)
+         fsurfn(i,j)   = fswsfc(i,j) + emissivity*flw(i,j) + flwoutn(i,j) + fsensn(i,j) + flatn(i,j)
+         dfsurf_dT(n)  = dflwout_dT(m) + dfsens_dT(m) + dflat_dT(m)
+      enddo
+      end subroutine surface_fluxes
 
 !=======================================================================
 ! Host-side helper kept for ice_history (enthalpy -> temperature, quadratic formula).

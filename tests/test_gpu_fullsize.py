@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from cice4_amd import lib, synth
-from conftest import relerr
+from conftest import relerr, TOL_EXP
 
 pytestmark = pytest.mark.gpu
 DT = 3600.0
@@ -46,11 +46,11 @@ def test_gx1_whole_evp_against_checker(ctx, orc):
     ctx.evp(DT, sg)
     for k in PRIMARY + ("divu", "shear", "strength", "strocnxT", "strocnyT"):
         assert np.array_equal(sg[k], so[k]), k           # exp-free strength: bit for bit
-    # default strength: ice_strength calls exp(), where the device libm and the host libm differ
-    # by an ulp.  The stated bound is 1e-10; where this case's own sensitivity to a +-1-ulp
-    # change of strength (measured on the checker) is larger than that, the bound is that
-    # sensitivity: no implementation with a different libm -- including the reference built on
-    # another host -- can do better.
+    # default strength: ice_strength calls exp().  The checker's own result moves by 1.8e-11 (u), 3.4e-11 (v),
+    # 6.0e-10 (sigma) when `strength` changes by 1 ulp (perturb_strength_ulp probe, printed below), so a
+    # device exp that is merely accurate cannot hold 1e-10 here (round 1: 6.8e-11 / 1.3e-10 / 2.2e-9).
+    # The device now evaluates exp() with glibc's own algorithm -> bit for bit (TOL_EXP = 0), unconditionally
+    # <= 1e-10 on a host with the other glibc build.
     orc.set_strength_parameters()
     so = {k: v.copy() for k, v in s.items()}
     orc.evp(orc.make_domain(dom, grid), so)
@@ -59,9 +59,8 @@ def test_gx1_whole_evp_against_checker(ctx, orc):
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=120)
     ctx.evp(DT, sg)
-    for k in PRIMARY:
-        sens = relerr(sp[k], so[k])
-        assert relerr(sg[k], so[k]) <= max(1e-10, 8.0 * sens), (k, relerr(sg[k], so[k]), sens)
+    for k in PRIMARY + ("strength", "divu", "shear", "strocnxT", "strocnyT"):
+        assert relerr(sg[k], so[k]) <= TOL_EXP, (k, relerr(sg[k], so[k]))
     print("gx1 1-ulp-strength sensitivity of the checker:", {k: float(relerr(sp[k], so[k])) for k in ("uvel", "vvel", "stressp_1")},
           "gpu-vs-checker:", {k: float(relerr(sg[k], so[k])) for k in ("uvel", "vvel", "stressp_1")})
 
@@ -170,4 +169,4 @@ def test_tenth_degree_thermo_sample(ctx, orc):
                        ("congel", b["congel"][0, n]), ("flatn", b["flatn"][0, n])):
             cpu = {"Tsfc": a["trcrn"][0], "eicen3": a["eicen"][2], "esnon": a["esnon"][0]}.get(k, a.get(k))
             d = np.abs(gpu[jj, ii] - cpu[jj, ii]).max(); den = max(np.abs(cpu[jj, ii]).max(), 1e-4)
-            assert d / den <= 1e-10, (n, k, d / den)
+            assert d / den <= TOL_EXP, (n, k, d / den)

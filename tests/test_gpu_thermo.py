@@ -1,17 +1,18 @@
 """GPU parity tests of the column thermodynamics (through the C-ABI) against the CPU
-checker.  Each iteration of the temperature solve evaluates exp() (saturation humidity),
-where the device libm and glibc differ by ulps, so the bound is the field-level relative
-error <= 1e-10 of BASELINE.json (observed ~1e-14); error reporting (l_stop, istop, jstop)
-must be identical."""
+checker.  Each iteration of the temperature solve evaluates exp() (saturation humidity); the
+device evaluates it with glibc's own algorithm (cice4_amd/csrc/libm_exact.h), so the results are
+BIT-IDENTICAL to the checker's (conftest.TOL_EXP = 0 on a host with glibc's FMA build of exp, 1e-10
+elsewhere); only frzmlt_bottom_lateral (`**1.36` -> pow) keeps the 1e-10 bound.  Error reporting
+(l_stop, istop, jstop) must be identical."""
 import numpy as np
 import pytest
 
 from cice4_amd import lib, synth
-from conftest import relerr
+from conftest import relerr, TOL_EXP, TOL_POW
 
 pytestmark = pytest.mark.gpu
 DT = 3600.0
-TOL = 1e-10
+TOL = TOL_EXP
 CHECK = ("aicen", "trcrn", "vicen", "vsnon", "eicen", "esnon", "fswsfc", "fswint", "Sswabs", "Iswabs",
          "fsurfn", "fcondtopn", "fsensn", "flatn", "fswabsn", "flwoutn", "evapn", "freshn", "fsaltn",
          "fhocnn", "meltt", "melts", "meltb", "congel", "snoice", "mlt_onset", "frz_onset")
@@ -269,7 +270,7 @@ def test_frzmlt_bottom_lateral(ctx, orc):
     g = ctx.frzmlt_bottom_lateral(2, nx - 1, 2, ny - 1, DT, aice, frzmlt, eicen, esnon, sst, Tf, sx, sy)
     c = orc.frzmlt_bottom_lateral(2, nx - 1, 2, ny - 1, DT, aice, frzmlt, eicen, esnon, sst, Tf, sx, sy)
     for a, b, nm in zip(g, c, ("Tbot", "fbot", "rside")):
-        assert relerr(a, b) <= TOL, nm
+        assert relerr(a, b) <= TOL_POW, nm
 
 
 def test_fortran_dropin_thermo_module(orc):
@@ -314,4 +315,4 @@ def test_fortran_dropin_thermo_module(orc):
             -rng.uniform(0, 5e7, (5, ny, nx)), np.full((ny, nx), -1.8) + rng.uniform(0, 1.5, (ny, nx)),
             np.full((ny, nx), -1.8), rng.uniform(-0.2, 0.2, (ny, nx)), rng.uniform(-0.2, 0.2, (ny, nx)))
     for x, y, nm in zip(ref.frzmlt_bottom_lateral(*args), orc.frzmlt_bottom_lateral(*args), ("Tbot", "fbot", "rside")):
-        assert relerr(x, y) <= TOL, nm
+        assert relerr(x, y) <= TOL_POW, nm
