@@ -74,6 +74,9 @@ def parse():
     p.add_argument("--ramp-seconds", type=float, default=0.3,
                    help="untimed device warm-up before the W warm-up steps (clock ramp)")
     p.add_argument("--no-thermo", action="store_true")
+    p.add_argument("--no-tenth", action="store_true",
+                   help="gx1 run: skip the short 0.1-degree (3600x2400, ndte=240) sub-record")
+    p.add_argument("--tenth-steps", type=int, default=3)
     p.add_argument("--thermo-coherence", type=int, default=THERMO_COHERENCE,
                    help="correlation length (cells) of the melting/cold, snow/bare, day/night regions of the synthetic "
                         "thermo columns; 0 = every column drawn independently (white noise)")
@@ -262,38 +265,62 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
                              kind="reference" if ref is not None else "port",
                              sample=f"{passes} pass(es) of thermo_vertical over 5 categories of block 0 "
                                     f"({nupd} column updates), 1 thread of {ncpu} host cores")
+    # --- all host cores available to this process: the C restatement ("port"; bit-identical to the reference,
+    # tests/test_oracle_vs_ref.py) with its stress / stepu loops spread over the cores by OpenMP, and
+    # thermo_vertical on one slice of the cell list per thread.  A reported baseline, not a target.
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (ncpu or 1)
+    if ncores > 1:
+        try:
+            orc_mp = orc_mod.Oracle(omp=True)
+            orc_mp.set_evp_parameters(DT, ndte)
+            orc_mp.set_strength_parameters()
+            d = orc_mp.make_domain(dom, grid)
+            s = {k: v.copy() for k, v in state.items()}
+            orc_mp.evp_subcycles_only(d, s, 4)                       # thread start-up, first touch
+            nsub = max(8, int(budget_s * 0.25 * 90 * min(ncores, 8) * (320 * 384) / (dom["nxg"] * dom["nyg"])))
+            t = orc_mp.evp_subcycles_only(d, s, nsub)
+            out["evp_all_cores"] = dict(value=nsub / t, unit="EVP subcycles/s", cores=ncores, kind="port",
+                                        sample=f"{nsub} subcycles of the C restatement (stress + stepu + halo), OpenMP over "
+                                               f"{ncores} threads (the cores this process may use; host has {ncpu}), {wl} full cover")
+        except OSError:
+            pass
+        if tcols is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            orc.init_thermo()
+            jobs = []
+            for n in range(5):
+                a, icells, ii, jj = tcols[(0, n)]
+                cut = np.linspace(0, icells, ncores + 1).astype(int)
+                for c0_, c1_ in zip(cut[:-1], cut[1:]):
+                    if c1_ > c0_:     # own arrays per slice: thermo_vertical zeroes its outputs over the whole block
+                        li = np.zeros_like(ii); lj = np.zeros_like(jj)
+                        li[:c1_ - c0_] = ii[c0_:c1_]; lj[:c1_ - c0_] = jj[c0_:c1_]
+                        jobs.append(({k: v.copy() for k, v in a.items()}, int(c1_ - c0_), li, lj))
+            nupd = sum(j[1] for j in jobs)
+            with ThreadPoolExecutor(ncores) as ex:                   # ctypes releases the GIL during the call
+                t0 = time.perf_counter()
+                list(ex.map(lambda j: orc.thermo_vertical(DT, j[1], j[2], j[3], j[0]), jobs))
+                t = time.perf_counter() - t0
+            out["thermo_all_cores"] = dict(value=nupd / t, unit="(cell,category) updates/s", cores=ncores, kind="port",
+                                           sample=f"one pass of the C restatement's thermo_vertical over 5 categories of block 0 "
+                                                  f"({nupd} column updates), cell lists cut into {ncores} slices, one thread each")
     return out
 
 
-def pmc_traffic(workload, waves, rows, derive, fused=False, fw=0):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_pmc_hbm_traffic_final.csv: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this
-    same command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes and re-verified on the
-    k_diag_copy8 calibration stream).  None if no pass exists for this kernel variant."""
+def pmc_traffic(workload, kernel_substr):
+    """HBM bytes per launch of a kernel from an ARCHIVED rocprofv3 PMC pass (profiles/r0N_pmc_hbm_traffic*.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes and re-verified on the k_diag_copy8 calibration stream).  Not measured in this run: the source
+    file (newest round first) is named next to the value; None if no pass exists for this kernel variant."""
     import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_fused.csv" if fused else "r01_pmc_hbm_traffic_final.csv")
-    want = f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>"
-    if fused:
-        want = f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>"
-    try:
-        for row in csv.DictReader(open(path)):
-            if row["workload"] == workload and want in row["kernel"]:
-                return float(row["total_MB_per_launch"]) * 1e6, os.path.relpath(path, ROOT)
-    except OSError:
-        pass
-    return None, None
-
-
-def pmc_traffic_thermo(workload):
-    """HBM bytes per pass of k_thermo_dense from the committed PMC passes (same procedure as pmc_traffic)."""
-    import csv
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_thermo.csv")
-    try:
-        for row in csv.DictReader(open(path)):
-            if row["workload"] == workload and "k_thermo_dense" in row["kernel"]:
-                return float(row["total_MB_per_launch"]) * 1e6, os.path.relpath(path, ROOT)
-    except OSError:
-        pass
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic*.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["workload"] == workload and kernel_substr in row["kernel"]:
+                    return float(row["total_MB_per_launch"]) * 1e6, "archived PMC pass " + os.path.relpath(path, ROOT)
+        except (OSError, KeyError):
+            continue
     return None, None
 
 
@@ -320,6 +347,7 @@ def run_cpu_baseline(args):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
+    env["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, env=env)
     with open(path) as f:
         res = json.load(f)
@@ -327,56 +355,32 @@ def run_cpu_baseline(args):
     return res
 
 
-def main():
-    args = parse()
-    if args.cpu_baseline_worker:
-        cpu_baseline_worker(args)
-        return
-    # NOTE on load order: torch is imported before the product library touches the device.  Both bring a
-    # HIP runtime and a librccl.so.1; whichever is loaded first serves the whole process, and loading the
-    # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With
-    # torch first, libcice4_amd.so runs on torch's bundled runtime and RCCL -- the combination
-    # scripts/gpu_slabs_selfcomm.sh exercises (graph capture of the grouped send/recv included).
-    rank, world, local, dist = init_dist(args.gpus)
-    try:
-        import torch
-        have_torch_gpu = torch.cuda.is_available()
-        if have_torch_gpu:
-            torch.cuda.set_device(local)
-    except Exception:
-        torch, have_torch_gpu = None, False
-
-    if os.environ.get("CICE4_AMD_BENCH_DEVICE") is not None:   # diagnostic: several ranks on one device
-        local = int(os.environ["CICE4_AMD_BENCH_DEVICE"])
-    ctx = lib.Context(device=local)
-    ctx.sync()                       # fails loudly without a GPU / HIP library
-    calib = None
-    if args.calibrate:
-        nd = 32 * 1024 * 1024        # 256 MiB read + 256 MiB written per launch
-        ms = ctx.diag_stream_copy(nd)
-        calib = {"kernel": "k_diag_copy8", "bytes_read": nd * 8, "bytes_written": nd * 8, "ms": ms,
-                 "GBps": 2 * nd * 8 / (ms * 1e-3) / 1e9}
-    dom, grid, state, ndte = build_case(ctx, args.workload, rank, world, args.overlap, args.slabs)
-    if world > 1:
+def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, warmup, ramp_seconds, tune=True):
+    """W warm-up + exactly K timed steps of the EVP hot loop on resident state for workload `wl`.
+    Returns everything the JSON line needs (rank-local cell counts already reduced over the ranks)."""
+    dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs)
+    if world > 1 and not getattr(ctx, "_comm_ready", False):
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
+        ctx._comm_ready = True
     ctx.evp_init(grid, ndte=ndte)
-    if args.waves:
+    if tune and args.waves:
         ctx.evp_set_option("waves", args.waves)
-    if args.rows:
+    if tune and args.rows:
         ctx.evp_set_option("rows_per_wave", args.rows)
     waves, rows = ctx.evp_get_info("waves"), ctx.evp_get_info("rows_per_wave")   # library's own choice by grid size
     tile = f"64x{waves * rows} T-cells ({waves} wavefronts x {rows} rows)"
-    ctx.evp_set_option("use_graph", 0 if args.no_graph else 1)
+    if args.no_graph:
+        ctx.evp_set_option("use_graph", 0)
     ctx.evp_set_option("derive_metrics", 0 if args.no_derive else 1)
     derive = bool(ctx.evp_get_info("derive_metrics"))
     ctx.evp_set_option("fuse", 0 if args.no_fuse else 1)
-    if args.fused_waves:
+    if tune and args.fused_waves:
         ctx.evp_set_option("fused_waves", args.fused_waves)
     fused = bool(ctx.evp_get_info("fused"))
+    fw = ctx.evp_get_info("fused_waves") if fused else 0
     if fused:
-        fw = ctx.evp_get_info("fused_waves")
         tile = f"two subcycles per launch; workgroup {fw} wavefronts x 64 lanes owns {fw - 3} rows x 59 columns"
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
@@ -397,33 +401,148 @@ def main():
     t_ramp = time.perf_counter()
     ctx.evp_subcycles(1, ndte)
     sync_all()
-    n_ramp = [int(min(5000, max(0, args.ramp_seconds / max(time.perf_counter() - t_ramp, 1e-6))))]
+    n_ramp = [int(min(5000, max(0, ramp_seconds / max(time.perf_counter() - t_ramp, 1e-6))))]
     if dist is not None:
         dist.broadcast_object_list(n_ramp, src=0)
     for _ in range(n_ramp[0]):
         ctx.evp_subcycles(1, ndte)
     sync_all()
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         ctx.evp_subcycles(1, ndte)
     sync_all()
     t0 = time.perf_counter()
     dev_ms = 0.0
-    for _ in range(args.steps):
+    for _ in range(steps):
         dev_ms += ctx.evp_subcycles(1, ndte, timed=True)
     sync_all()
     t_evp = time.perf_counter() - t0
     if dist is not None:
-        import torch as _t
-        tt = _t.tensor([t_evp, dev_ms], dtype=_t.float64)
+        tt = torch.tensor([t_evp, dev_ms], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         t_evp, dev_ms = float(tt[0]), float(tt[1])
-        cells = _t.tensor([nt, nu], dtype=_t.int64)
+        cells = torch.tensor([nt, nu], dtype=torch.int64)
         dist.all_reduce(cells, op=dist.ReduceOp.SUM)
         nt_all, nu_all = int(cells[0]), int(cells[1])
     else:
         nt_all, nu_all = nt, nu
-    nsub_total = ndte * args.steps
+    nsub_total = ndte * steps
     value = nsub_total / t_evp
+    # dominant kernel: the subcycle kernel; HIP-event time of the launches on the library's stream / launches
+    n_launch = launches_per_step(ndte, fused, dom.get("overlap", 0)) * steps
+    us_per_launch = dev_ms * 1e3 / n_launch
+    sub_per_launch = nsub_total / n_launch
+    cells_rank = nt_all / world
+    # Compulsory HBM bytes of ONE LAUNCH as the kernel is built: the 12 stresses and u, v are read and written
+    # once and the 20 read-only inputs are read once per launch, however many subcycles the launch runs
+    # (k_subcycle: 1, k_subcycle2: 2) = 384 B per active T-cell per launch.  SURVEY section 8(d) counts the same
+    # 384 B per cell per SUBCYCLE; for a two-subcycle launch that figure is twice what has to cross HBM (it gave
+    # "fractions" > 1 in round 1), so it is reported separately as `survey_8d` and is NOT a roofline fraction.
+    bytes_per_launch = EVP_BYTES_PER_CELL * cells_rank
+    achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    kname = ("k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
+             else "k_subcycle (fused stress + stepu + on-rank halo)")
+    ksub = (f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
+            else f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>")
+    traffic, traffic_src = pmc_traffic(wl, ksub) if world == 1 else (None, None)
+    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "basis": "compulsory bytes of one launch: 384 B per active T-cell per launch (sigma, u, v read+written, "
+                         "20 inputs read, once per launch whatever the number of subcycles in it)",
+                "kernel": kname, "us_per_launch": us_per_launch, "bytes_per_launch": bytes_per_launch,
+                "bytes_per_unit": EVP_BYTES_PER_CELL, "unit_of_work": "active T-cell x launch",
+                "units_per_launch": cells_rank, "subcycles_per_launch": sub_per_launch,
+                "compulsory_bytes_fused": bytes_per_launch,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "frac_measured_traffic": (traffic / (us_per_launch * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                "survey_8d": {"bytes_per_unit": EVP_BYTES_PER_CELL, "unit_of_work": "active T-cell x subcycle",
+                              "units_per_launch": cells_rank * sub_per_launch,
+                              "algorithmic_GBps": achieved * sub_per_launch,
+                              "ratio_to_peak": achieved * sub_per_launch / HBM_PEAK_GBS,
+                              "note": "north_star's per-subcycle figure (what an unfused subcycle would have to move per "
+                                      "second at this rate); exceeds what this kernel moves by the factor subcycles_per_launch"}}
+    config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
+              "subcycles_per_step": ndte,
+              "decomposition": f"1x{world} j-slabs, one block per GPU" + (
+                  f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
+                  f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
+              "tile": tile, "metrics_recomputed_from_HTN_HTE": derive,
+              "active_T_cells": nt_all, "active_U_cells": nu_all, "cell_subcycles_per_s": value * nt_all}
+    return dict(dom=dom, grid=grid, state=state, ndte=ndte, value=value, t_evp=t_evp, config=config,
+                roofline=roofline, steps=steps, warmup=warmup)
+
+
+def measure_thermo(ctx, args, wl, dom, world, dist, torch, steps):
+    """K batched passes of the column thermodynamics over every (cell, category) of the rank; state restored
+    before each pass (not timed)."""
+    ctx.thermo_init()
+    tb, tcols = thermo_case(dom, coherent=args.thermo_coherence)
+    ctx.thermo_batch_alloc(dom["nx"], dom["ny"], dom["nblocks"])
+    t_ms, nupd = 0.0, 0
+    npass = max(2, min(steps, 10))
+    for p in range(npass + 1):
+        ctx.thermo_batch_upload(tb)
+        st = ctx.thermo_batch_step(DT, yday=150.0, timed=True)
+        if st["l_stop"]:
+            raise SystemExit(f"thermo step failed at i={st['istop']} j={st['jstop']} n={st['nstop']}")
+        if p > 0:   # first pass is warm-up
+            t_ms += st["ms"]; nupd += st["n_updates"]
+    if dist is not None:
+        v = torch.tensor([t_ms / npass], dtype=torch.float64); dist.all_reduce(v, op=dist.ReduceOp.MAX)
+        c = torch.tensor([nupd // npass], dtype=torch.int64); dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        ms_pass, upd_pass = float(v[0]), int(c[0])
+    else:
+        ms_pass, upd_pass = t_ms / npass, nupd // npass
+    rate = upd_pass / (ms_pass * 1e-3)
+    traffic, traffic_src = pmc_traffic(wl, "k_thermo_dense") if world == 1 else (None, None)
+    thermo = dict(metric="grid-cell-cat-updates/sec", value=rate, unit="(cell,category) updates/s",
+                  columns=("synthetic, full cover, 40 % melting / 60 % cold, snow-covered and bare, day and night; "
+                           + (f"regions with correlation length {args.thermo_coherence} cells"
+                              if args.thermo_coherence else "every column drawn independently (white noise)")),
+                  updates_per_pass=upd_pass, ms_per_pass=ms_pass, passes=npass,
+                  roofline=dict(bound="hbm", achieved=rate * THERMO_BYTES_PER_COLUMN / 1e9,
+                                peak=HBM_PEAK_GBS, unit="GB/s",
+                                frac=rate * THERMO_BYTES_PER_COLUMN / 1e9 / HBM_PEAK_GBS,
+                                traffic=traffic, traffic_unit="bytes per pass (all columns)", traffic_source=traffic_src,
+                                frac_measured_traffic=(traffic * world / (ms_pass * 1e-3) / 1e9 / HBM_PEAK_GBS / world
+                                                       if traffic else None),
+                                kernel="k_thermo_dense", bytes_per_unit=THERMO_BYTES_PER_COLUMN,
+                                note="fp64-issue-bound, not HBM-bound (DESIGN.md section 3.3); the fraction says how far "
+                                     "the column solver is from streaming its state at HBM speed"))
+    return thermo, tcols
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_worker:
+        cpu_baseline_worker(args)
+        return
+    # NOTE on load order: torch is imported before the product library touches the device.  Both bring a
+    # HIP runtime and a librccl.so.1; whichever is loaded first serves the whole process, and loading the
+    # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With
+    # torch first, libcice4_amd.so runs on torch's bundled runtime and RCCL -- the combination
+    # scripts/gpu_slabs_selfcomm.sh exercises.
+    rank, world, local, dist = init_dist(args.gpus)
+    try:
+        import torch
+        have_torch_gpu = torch.cuda.is_available()
+        if have_torch_gpu:
+            torch.cuda.set_device(local)
+    except Exception:
+        torch, have_torch_gpu = None, False
+
+    if os.environ.get("CICE4_AMD_BENCH_DEVICE") is not None:   # diagnostic: several ranks on one device
+        local = int(os.environ["CICE4_AMD_BENCH_DEVICE"])
+    ctx = lib.Context(device=local)
+    ctx.sync()                       # fails loudly without a GPU / HIP library
+    calib = None
+    if args.calibrate:
+        nd = 32 * 1024 * 1024        # 256 MiB read + 256 MiB written per launch
+        ms = ctx.diag_stream_copy(nd)
+        calib = {"kernel": "k_diag_copy8", "bytes_read": nd * 8, "bytes_written": nd * 8, "ms": ms,
+                 "GBps": 2 * nd * 8 / (ms * 1e-3) / 1e9}
+    m = measure_evp(ctx, args, args.workload, rank, world, dist, torch, have_torch_gpu, args.steps, args.warmup,
+                    args.ramp_seconds)
+    dom, state, ndte = m["dom"], m["state"], m["ndte"]
 
     # ---- the drop-in form evp(dt) with host arrays on both sides (PCIe-inclusive; never `value`)
     pcie = None
@@ -437,80 +556,35 @@ def main():
         t1 = (time.perf_counter() - t1) / 2
         pcie = {"what": "cice_evp(dt): H2D of 33 fields + prepare + ndte subcycles + finish + D2H of 38 fields, "
                         "host arrays page-locked once (cice_evp_pin_fields), as the Fortran drop-in does", "ms_per_call": 1e3 * t1, "subcycles_per_s": ndte / t1}
+        del st2
 
-    # ---- thermo (secondary figure): K batched passes, state restored before each (not timed)
-    thermo = None
-    tcols = None
-    if not args.no_thermo:
-        ctx.thermo_init()
-        tb, tcols = thermo_case(dom, coherent=args.thermo_coherence)
-        ctx.thermo_batch_alloc(dom["nx"], dom["ny"], dom["nblocks"])
-        t_ms, nupd = 0.0, 0
-        npass = max(2, min(args.steps, 10))
-        for p in range(npass + 1):
-            ctx.thermo_batch_upload(tb)
-            st = ctx.thermo_batch_step(DT, yday=150.0, timed=True)
-            if st["l_stop"]:
-                raise SystemExit(f"thermo step failed at i={st['istop']} j={st['jstop']} n={st['nstop']}")
-            if p > 0:   # first pass is warm-up
-                t_ms += st["ms"]; nupd += st["n_updates"]
-        if dist is not None:
-            import torch as _t
-            v = _t.tensor([t_ms / npass], dtype=_t.float64); dist.all_reduce(v, op=dist.ReduceOp.MAX)
-            c = _t.tensor([nupd // npass], dtype=_t.int64); dist.all_reduce(c, op=dist.ReduceOp.SUM)
-            ms_pass, upd_pass = float(v[0]), int(c[0])
-        else:
-            ms_pass, upd_pass = t_ms / npass, nupd // npass
-        rate = upd_pass / (ms_pass * 1e-3)
-        thermo = dict(metric="grid-cell-cat-updates/sec", value=rate, unit="(cell,category) updates/s",
-                      columns=("synthetic, full cover, 40 % melting / 60 % cold, snow-covered and bare, day and night; "
-                               + (f"regions with correlation length {args.thermo_coherence} cells"
-                                  if args.thermo_coherence else "every column drawn independently (white noise)")),
-                      updates_per_pass=upd_pass, ms_per_pass=ms_pass, passes=npass,
-                      roofline=dict(bound="hbm", achieved=rate * THERMO_BYTES_PER_COLUMN / 1e9,
-                                    peak=HBM_PEAK_GBS, unit="GB/s",
-                                    frac=rate * THERMO_BYTES_PER_COLUMN / 1e9 / HBM_PEAK_GBS,
-                                    traffic=(pmc_traffic_thermo(args.workload)[0] if world == 1 else None),
-                                    traffic_unit="bytes per pass (all columns)",
-                                    traffic_source=(pmc_traffic_thermo(args.workload)[1] if world == 1 else None),
-                                    kernel="k_thermo_dense",
-                                    bytes_per_unit=THERMO_BYTES_PER_COLUMN))
+    # ---- thermo (secondary figure)
+    thermo, tcols = (None, None) if args.no_thermo else measure_thermo(ctx, args, args.workload, dom, world, dist, torch, args.steps)
+
+    # ---- the 0.1-degree configuration (BASELINE.json configs[4]) inside the same line: a short run, EVP only + thermo
+    tenth = None
+    if args.workload == "gx1" and not args.no_tenth and args.slabs == 0:
+        del state
+        m["state"] = m["grid"] = None
+        t = measure_evp(ctx, args, "tenth", rank, world, dist, torch, have_torch_gpu, args.tenth_steps, 1, 0.3, tune=False)
+        tenth = {"metric": "EVP subcycles/sec", "value": t["value"], "unit": "subcycles/s", "n_gpus": world,
+                 "steps": t["steps"], "warmup": t["warmup"], "ms_per_step": 1e3 * t["t_evp"] / t["steps"],
+                 "config": t["config"], "roofline": t["roofline"]}
+        if not args.no_thermo:
+            tenth["thermo"] = measure_thermo(ctx, args, "tenth", t["dom"], world, dist, torch, 2)[0]
+        del t
 
     if rank == 0:
-        # dominant kernel: the fused subcycle kernel, one launch per subcycle over the rank's
-        # active T-cells; HIP-event time of the launches on the library's stream / launches
-        n_launch = launches_per_step(ndte, fused, dom.get("overlap", 0)) * args.steps
-        us_per_launch = dev_ms * 1e3 / n_launch
-        units_per_launch = (nt_all / world) * nsub_total / n_launch     # cell-subcycles one launch processes
-        bytes_per_launch = EVP_BYTES_PER_CELL * units_per_launch
-        achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-        kname = ("k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
-                 else "k_subcycle (fused stress + stepu + on-rank halo)")
-        traffic, traffic_src = (pmc_traffic(args.workload, waves, rows, derive, fused, fw if fused else 0) if world == 1 else (None, None))
         out = {
-            "metric": "EVP subcycles/sec", "value": value, "unit": "subcycles/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_evp / args.steps,
+            "metric": "EVP subcycles/sec", "value": m["value"], "unit": "subcycles/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * m["t_evp"] / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": workload(args.workload)[3], "nx_global": dom["nxg"],
-                       "ny_global": dom["nyg"], "ndte": ndte, "subcycles_per_step": ndte,
-                       "decomposition": f"1x{world} j-slabs, one block per GPU" + (
-                           f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
-                           f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
-                       "tile": tile,
-                       "metrics_recomputed_from_HTN_HTE": derive,
-                       "active_T_cells": nt_all, "active_U_cells": nu_all,
-                       "cell_subcycles_per_s": value * nt_all},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "kernel": kname,
-                         "us_per_launch": us_per_launch, "bytes_per_unit": EVP_BYTES_PER_CELL,
-                         "units_per_launch": units_per_launch, "unit_of_work": "active T-cell x subcycle",
-                         "subcycles_per_launch": nsub_total / n_launch},
+            "data": "synthetic", "config": m["config"], "roofline": m["roofline"],
         }
         if thermo:
             out["thermo"] = thermo
+        if tenth:
+            out["tenth"] = tenth
         if calib:
             out["calibration"] = calib
         if pcie:
@@ -518,8 +592,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cb = run_cpu_baseline(args)
             out["cpu_baseline"] = dict(cb["evp"])
+            if "evp_all_cores" in cb:
+                out["cpu_baseline"]["all_cores"] = cb["evp_all_cores"]
             if "thermo" in cb and thermo:
                 out["thermo"]["cpu_baseline"] = cb["thermo"]
+                if "thermo_all_cores" in cb:
+                    out["thermo"]["cpu_baseline"]["all_cores"] = cb["thermo_all_cores"]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

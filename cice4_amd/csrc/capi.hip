@@ -26,7 +26,7 @@ struct cice_ctx {
   std::vector<void*> pinned;   // cice_host_register
   // staging of the host-pointer entries (thermo_vertical is called ncat x nblocks times per step with
   // the same block size: allocated once, grown only when a larger block comes along)
-  DevBuf<double> tv_stage, fz_stage;
+  DevBuf<double> tv_stage, fz_stage, halo_stage;
   DevBuf<int32_t> tv_list;
   // thermo
   ThermoParams tp{};
@@ -40,8 +40,17 @@ struct cice_ctx {
         lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, out15, mlt_onset, frz_onset;
   } tb;
   // device is required lazily: domain queries work on a CPU-only host
+  // Every C-ABI entry binds the calling thread to this context's device first (CICE_TRY): the host
+  // process may have changed the current device since the last call (another context on another GPU,
+  // torch.cuda.set_device, another thread).
+  void bind_device() {
+    if (stream) CICE_HIP(hipSetDevice(device));
+  }
   void need_device() {
-    if (stream) return;
+    if (stream) {
+      CICE_HIP(hipSetDevice(device));
+      return;
+    }
     int cnt = 0;
     CICE_HIP(hipGetDeviceCount(&cnt));
     if (cnt < 1) throw Error{CICE_EDEVICE, "no HIP device visible"};
@@ -64,7 +73,8 @@ static std::string g_create_err;
 #define CICE_TRY(ctx_) \
   cice_ctx* c_ = (ctx_); \
   if (!c_) return CICE_EINVAL; \
-  try {
+  try {                        \
+    c_->bind_device();
 #define CICE_CATCH                                            \
   }                                                           \
   catch (const Error& e) {                                    \
@@ -96,21 +106,37 @@ __global__ __launch_bounds__(256) void k_diag_copy16(const double2* __restrict__
   }
 }
 
+// Host-pointer form of ice_HaloUpdate (what rccl/ice_boundary.F90 calls with a module array): the field is
+// staged through a persistent device buffer (grown only when a larger field comes along) and ALL its levels
+// travel in one update = one message per neighbour (bound_state's 65 levels included, ice_state.F90:162-217).
 template <class T>
 static void halo_host(cice_ctx* c, T* field, int nlev) {
   c->need_halo();
   CICE_REQUIRE(field && nlev >= 1, "bad argument");
   const size_t n = (size_t)c->dom.nblocks() * c->dom.nx_block * c->dom.ny_block;
-  DevBuf<T> d;
-  d.alloc(n * nlev);
-  d.upload(field, c->stream);
-  for (int k = 0; k < nlev; k += 4) {
-    const int nf = std::min(4, nlev - k);
-    if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(d.p) + (size_t)k * n, nf, n);
-    else c->halo->update_i4(reinterpret_cast<int32_t*>(d.p) + (size_t)k * n, nf, n);
-  }
-  d.download(field, c->stream);
+  const size_t words = (n * nlev * sizeof(T) + 7) / 8;
+  if (c->halo_stage.n < words) c->halo_stage.alloc(words);
+  T* d = reinterpret_cast<T*>(c->halo_stage.p);
+  CICE_HIP(hipMemcpyAsync(d, field, n * nlev * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(d), nlev, n);
+  else c->halo->update_i4(reinterpret_cast<int32_t*>(d), nlev, n);
+  CICE_HIP(hipMemcpyAsync(field, d, n * nlev * sizeof(T), hipMemcpyDeviceToHost, c->stream));
   CICE_HIP(hipStreamSynchronize(c->stream));
+}
+
+// Device-resident form: the field already lives in device memory (nlev levels of nblocks*ny_block*nx_block
+// elements, level stride = one such plane set); nothing crosses PCIe, no allocation, asynchronous on the
+// library's stream.
+template <class T>
+static void halo_dev(cice_ctx* c, T* dev_field, int nlev) {
+  c->need_halo();
+  CICE_REQUIRE(dev_field && nlev >= 1, "bad argument");
+  hipPointerAttribute_t at{};
+  CICE_REQUIRE(hipPointerGetAttributes(&at, dev_field) == hipSuccess && at.type == hipMemoryTypeDevice,
+               "cice_halo_update_dev: not a device pointer");
+  const size_t n = (size_t)c->dom.nblocks() * c->dom.nx_block * c->dom.ny_block;
+  if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(dev_field), nlev, n);
+  else c->halo->update_i4(reinterpret_cast<int32_t*>(dev_field), nlev, n);
 }
 
 extern "C" {
@@ -414,6 +440,36 @@ int cice_halo_update_r8(cice_ctx* ctx, double* field, int nlev) {
 int cice_halo_update_i4(cice_ctx* ctx, int32_t* field, int nlev) {
   CICE_TRY(ctx) halo_host<int32_t>(c_, field, nlev); CICE_CATCH
 }
+int cice_halo_update_dev_r8(cice_ctx* ctx, double* dev_field, int nlev) {
+  CICE_TRY(ctx) halo_dev<double>(c_, dev_field, nlev); CICE_CATCH
+}
+int cice_halo_update_dev_i4(cice_ctx* ctx, int32_t* dev_field, int nlev) {
+  CICE_TRY(ctx) halo_dev<int32_t>(c_, dev_field, nlev); CICE_CATCH
+}
+// device memory for callers that keep fields resident (cice_halo_update_dev_*): plain hipMalloc/hipFree on
+// the context's device plus explicit copies ordered on the library's stream
+int cice_device_alloc(cice_ctx* ctx, size_t bytes, void** dev) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(dev != nullptr, "NULL argument");
+  c_->need_device();
+  CICE_HIP(hipMalloc(dev, bytes));
+  CICE_CATCH
+}
+int cice_device_free(cice_ctx* ctx, void* dev) {
+  CICE_TRY(ctx)
+  c_->need_device();
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_HIP(hipFree(dev));
+  CICE_CATCH
+}
+int cice_device_copy(cice_ctx* ctx, void* dst, const void* src, size_t bytes, int to_device) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(dst && src, "NULL argument");
+  c_->need_device();
+  CICE_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, c_->stream));
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_CATCH
+}
 
 // ---- thermodynamics --------------------------------------------------------------------------
 int cice_thermo_init(cice_ctx* ctx, const cice_thermo_config* cfg, double* salin, double* Tmlt) {
@@ -469,6 +525,14 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
   CICE_REQUIRE(nx >= 1 && ny >= 1, "bad dimensions");
   const size_t np = (size_t)nx * ny;
   CICE_REQUIRE(icells >= 0 && (size_t)icells <= np, "icells out of range");
+  CICE_REQUIRE(icells == 0 || (indxi && indxj), "thermo_vertical: NULL index list");
+  {  // every array is checked before anything is queued on the stream
+    const void* all[] = {aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot,
+                         lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, fsurfn, fcondtopn, fsensn,
+                         flatn, fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, meltt, melts, meltb, congel,
+                         snoice, mlt_onset, frz_onset};
+    for (const void* q : all) CICE_REQUIRE(q != nullptr, "thermo_vertical: NULL array");
+  }
   for (int e = 0; e < icells; ++e)
     CICE_REQUIRE(indxi[e] >= 1 && indxi[e] <= nx && indxj[e] >= 1 && indxj[e] <= ny,
                  "thermo_vertical: index outside block");
@@ -714,6 +778,8 @@ int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, 
   CICE_TRY(ctx)
   CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
   CICE_REQUIRE(nx >= 1 && ny >= 1 && ilo >= 1 && ihi <= nx && jlo >= 1 && jhi <= ny, "bad dimensions");
+  CICE_REQUIRE(aice && frzmlt && eicen && esnon && sst && Tf && strocnxT && strocnyT && Tbot && fbot && rside,
+               "frzmlt_bottom_lateral: NULL array");     // before anything is queued on the stream
   c_->need_device();
   hipStream_t s = c_->stream;
   const size_t np = (size_t)nx * ny;
@@ -734,7 +800,6 @@ int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, 
   a.Tbot = d.p + 6 * np; a.fbot = d.p + 7 * np; a.rside = d.p + 8 * np;
   a.eicen = d.p + 9 * np; a.esnon = d.p + (size_t)(9 + NE) * np;
   frzmlt_launch(a, s);
-  CICE_REQUIRE(Tbot && fbot && rside, "frzmlt_bottom_lateral: NULL output");
   CICE_HIP(hipMemcpyAsync(Tbot, a.Tbot, np * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipMemcpyAsync(fbot, a.fbot, np * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipMemcpyAsync(rside, a.rside, np * 8, hipMemcpyDeviceToHost, s));

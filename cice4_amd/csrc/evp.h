@@ -58,6 +58,7 @@ class Evp {
   bool ready = false, prepared = false, counted = false;
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
+  bool comm_graph = false;   // multi-rank loops: capture the RCCL calls too (opt-in)
   bool fuse_on = true;
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
   mutable int waves2_auto = 0;  // the automatic choice, once made

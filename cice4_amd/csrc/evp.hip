@@ -1115,6 +1115,8 @@ void Evp::set_option(const char* key, int value) {
     derive_on = value != 0;
   } else if (!std::strcmp(key, "use_graph")) {
     use_graph = value != 0;
+  } else if (!std::strcmp(key, "comm_graph")) {    // capture RCCL calls of a multi-rank loop too (default off)
+    comm_graph = value != 0;
   } else if (!std::strcmp(key, "fuse")) {          // two subcycles per launch where the domain allows
     fuse_on = value != 0;
   } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
@@ -1130,6 +1132,8 @@ void Evp::set_option(const char* key, int value) {
 void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   CICE_REQUIRE(dom.nblocks() > 0, "cice_evp_init: no local blocks (call cice_domain_create first)");
   CICE_REQUIRE(c.ndte >= 1, "ndte must be >= 1");
+  // the subcycle kernels address a block plane with 32-bit byte offsets
+  CICE_REQUIRE((size_t)dom.nx_block * dom.ny_block * 8 < (1ull << 32), "cice_evp_init: block plane of 4 GB or more");
   cfg = c;
   n = (size_t)dom.nblocks() * dom.nx_block * dom.ny_block;
   std::vector<int32_t> hb;
@@ -1517,15 +1521,18 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     CICE_HIP(hipEventCreate(&e1));
     CICE_HIP(hipEventRecord(e0, stream));
   }
-  // The whole loop -- kernels, pack/unpack and the RCCL point-to-point calls of a multi-rank
-  // domain -- is captured once and replayed (RCCL send/recv capture verified on this ROCm by
-  // scripts/rccl_graph_probe.cpp).  CICE4_AMD_NO_COMM_GRAPH=1 keeps multi-rank loops eager.
-  static const bool no_comm_graph = std::getenv("CICE4_AMD_NO_COMM_GRAPH") != nullptr;
-  const bool graph_ok = use_graph && nsub > 1 && !(halo.multi_rank() && no_comm_graph);
+  // Single-rank domains: the whole loop is captured once and replayed.  Multi-rank domains launch eagerly
+  // by default: capturing the grouped ncclSend/ncclRecv calls works on this ROCm (scripts/rccl_graph_probe.cpp,
+  // and the 1-rank self-communicator test), but has never run between real peers, where a mis-ordered replay
+  // would hang instead of raising an error.  Opt in with cice_evp_set_option("comm_graph", 1) or
+  // CICE4_AMD_COMM_GRAPH=1 once a multi-GPU parity run has passed.
+  static const bool env_comm_graph = std::getenv("CICE4_AMD_COMM_GRAPH") != nullptr;
+  const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
   bool replayed = false;
   if (graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
-                        ((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2};
+                        (((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 64 +
+                            (halo.generation() & 63)};
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();

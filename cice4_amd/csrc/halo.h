@@ -36,6 +36,9 @@ class Halo {
   const int32_t* d_ring_slot() const { return ring_slot_.p; }
   const int32_t* d_fwd() const { return fwd_.p; }
   bool fwd_ok() const { return fwd_ok_; }
+  // bumped whenever the message buffers are re-allocated (a 65-level bound_state update after the EVP
+  // loop was captured): whoever holds a hipGraph of update() calls has to re-capture it
+  int generation() const { return generation_; }
 
  private:
   template <class T>
@@ -46,9 +49,11 @@ class Halo {
   DevBuf<int32_t> src_, dst_, rsrc_, rdst_, send_addr_, recv_addr_, ring_slot_, fwd_;
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;
-  DevBuf<double> sendbuf_, recvbuf_;  // sized for MAXF fields of 8-byte elements
+  DevBuf<double> sendbuf_, recvbuf_;  // sized for cap_fields_ fields of 8-byte elements
+  int cap_fields_ = 0, total_s_ = 0, total_r_ = 0, generation_ = 0;
+  void reserve(int nfields);          // grows the message buffers (never shrinks)
   ncclComm* comm_ = nullptr;
-  static constexpr int MAXF = 14;  // u, v and the 12 stresses in one message
+  static constexpr int MINF = 14;     // u, v and the 12 stresses in one message: allocated up front
 };
 
 }  // namespace cice

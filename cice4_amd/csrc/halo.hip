@@ -126,9 +126,19 @@ void Halo::init(const Domain& d, hipStream_t s) {
   int ts = flatten(d.send, send_peer_, send_off_, send_cnt_, send_addr_, nsend_);
   int tr = flatten(d.recv, recv_peer_, recv_off_, recv_cnt_, recv_addr_, nrecv_);
   remote_ = nsend_ > 0 || nrecv_ > 0;
-  sendbuf_.alloc((size_t)ts * MAXF);
-  recvbuf_.alloc((size_t)tr * MAXF);
+  total_s_ = ts;
+  total_r_ = tr;
+  reserve(MINF);
   CICE_HIP(hipStreamSynchronize(s));
+}
+
+void Halo::reserve(int nfields) {
+  if (nfields <= cap_fields_) return;
+  if (cap_fields_) CICE_HIP(hipStreamSynchronize(stream_));   // nothing in flight may still use the old buffers
+  sendbuf_.alloc((size_t)total_s_ * nfields);
+  recvbuf_.alloc((size_t)total_r_ * nfields);
+  cap_fields_ = nfields;
+  ++generation_;
 }
 
 Halo::~Halo() {
@@ -147,7 +157,8 @@ void Halo::comm_init(const char uid[128], int rank, int nranks) {
 
 template <class T>
 void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
-  CICE_REQUIRE(nfields >= 1 && nfields <= MAXF, "halo: too many fields in one update");
+  CICE_REQUIRE(nfields >= 1, "halo: no field");
+  if (remote_) reserve(nfields);    // any number of levels in one message per neighbour
   const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
   const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
   // The wrap list goes first: a wide-halo refresh copies whole rows INCLUDING their E/W ghost

@@ -303,6 +303,21 @@ class Context:
         else:
             self._ck(self.lib.cice_halo_update_i4(self.h, _i4(field), nlev))
 
+    def halo_update_resident(self, field):
+        """The same on a field kept in device memory: upload once, update through cice_halo_update_dev_r8/_i4
+        (all levels in one message per neighbour, no staging, no allocation per call), download."""
+        n = self.nblocks * self.ny * self.nx
+        nlev = field.size // n
+        dev = C.c_void_p()
+        self._ck(self.lib.cice_device_alloc(self.h, C.c_size_t(field.nbytes), C.byref(dev)))
+        try:
+            self._ck(self.lib.cice_device_copy(self.h, dev, _p(field), C.c_size_t(field.nbytes), 1))
+            fn = self.lib.cice_halo_update_dev_r8 if field.dtype == np.float64 else self.lib.cice_halo_update_dev_i4
+            self._ck(fn(self.h, dev, nlev))
+            self._ck(self.lib.cice_device_copy(self.h, _p(field), dev, C.c_size_t(field.nbytes), 0))
+        finally:
+            self._ck(self.lib.cice_device_free(self.h, dev))
+
     # ---- thermodynamics ----------------------------------------------------------
     def thermo_init(self, heat_capacity=True, calc_Tsfc=True, conduct="MU71", ustar_min=0.05,
                     tr_iage=True, nt_Tsfc=1, nt_iage=2):

@@ -197,6 +197,15 @@ int cice_evp_stepu(cice_ctx *ctx, int nx_block, int ny_block, int icellu, const 
  * 2DI4, mpi/ice_boundary.F90:1028,1820): nlev slabs of (nx_block,ny_block,nblocks). */
 int cice_halo_update_r8(cice_ctx *ctx, double *field, int nlev);
 int cice_halo_update_i4(cice_ctx *ctx, int32_t *field, int nlev);
+/* The same for a field that is RESIDENT in device memory (ice_HaloUpdate3DR8 / 4DR8 with all levels in one
+ * message per neighbour, mpi/ice_boundary.F90:2216,3587; bound_state's 65 levels, source/ice_state.F90:162-217):
+ * nlev planes of nx_block*ny_block*nblocks elements; asynchronous on the library's stream (cice_device_sync). */
+int cice_halo_update_dev_r8(cice_ctx *ctx, double *dev_field, int nlev);
+int cice_halo_update_dev_i4(cice_ctx *ctx, int32_t *dev_field, int nlev);
+/* Device memory on the context's GPU for such resident fields, and blocking copies ordered on the library's stream. */
+int cice_device_alloc(cice_ctx *ctx, size_t bytes, void **dev);
+int cice_device_free(cice_ctx *ctx, void *dev);
+int cice_device_copy(cice_ctx *ctx, void *dst, const void *src, size_t bytes, int to_device);
 
 /* ---- column thermodynamics (source/ice_therm_vertical.F90) -------------- */
 typedef struct { /* module variables :56-79 + tracer slots (ice_state.F90 nt_Tsfc, nt_iage) */

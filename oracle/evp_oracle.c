@@ -146,7 +146,16 @@ void orc_stress(const orc_evp_params *p, int nx, int ny, int ksub, int icellt,
   double *sp1 = sig[0], *sp2 = sig[1], *sp3 = sig[2], *sp4 = sig[3];
   double *sm1 = sig[4], *sm2 = sig[5], *sm3 = sig[6], *sm4 = sig[7];
   double *s121 = sig[8], *s122 = sig[9], *s123 = sig[10], *s124 = sig[11];
+  /* The two `omp` pragmas of this file are active only in the -fopenmp build (libcice_oracle_omp.so),
+   * which bench.py's all-cores cpu_baseline leg uses; iterations are independent (every cell writes
+   * only its own entries), so the results do not depend on the thread count. */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+  for (long z = 0; z < (long)(8 * np); z++) str[z] = 0.0;
+#else
   memset(str, 0, 8 * np * sizeof(double)); /* :1051 */
+#endif
+#pragma omp parallel for schedule(static)
   for (int ij = 0; ij < icellt; ij++) {
     const int i = indxti[ij], j = indxtj[ij];
     const size_t q = IX(i, j);
@@ -266,6 +275,7 @@ void orc_stepu(int nx, int ny, int icellu, const int32_t *indxui, const int32_t 
                const double *uarear, double *strocnx, double *strocny, double *strintx,
                double *strinty, double *uvel, double *vvel) {
   const size_t np = (size_t)nx * ny;
+#pragma omp parallel for schedule(static)
   for (int ij = 0; ij < icellu; ij++) {
     const int i = indxui[ij], j = indxuj[ij];
     const size_t q = IX(i, j);

@@ -68,10 +68,13 @@ class EvpState(C.Structure):
 
 
 class Oracle:
-    def __init__(self):
-        if not os.path.exists(LIB):
+    def __init__(self, omp=False):
+        """omp=True: the -fopenmp build (the two EVP loops spread over OMP_NUM_THREADS host cores; same
+        results) -- bench.py's all-cores cpu_baseline leg only."""
+        path = LIB.replace("libcice_oracle.so", "libcice_oracle_omp.so") if omp else LIB
+        if not os.path.exists(path):
             build()
-        self.lib = C.CDLL(LIB)
+        self.lib = C.CDLL(path)
         self.lib.orc_thermo_vertical.restype = C.c_int
         self.lib.orc_evp_subcycles_only.restype = C.c_double
         self.p = EvpParams()

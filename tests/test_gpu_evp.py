@@ -417,6 +417,7 @@ def test_message_path_on_one_gpu(orc, monkeypatch):
         sg = {k: v.copy() for k, v in s.items()}
         c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
         c.evp_set_option("use_graph", graph)
+        c.evp_set_option("comm_graph", graph)     # multi-rank loops are eager unless asked otherwise
         c.evp(DT, sg)
         for k in EVP_OUT_FIELDS + ("iceumask",):
             assert np.array_equal(sg[k], so[k]), (graph, k)
@@ -424,6 +425,32 @@ def test_message_path_on_one_gpu(orc, monkeypatch):
     want = a.copy().reshape(2, -1); want[:, dom_plain["hdst"]] = want[:, dom_plain["hsrc"]]
     c.halo_update(a)
     assert np.array_equal(a.reshape(2, -1), want)
+
+
+@pytest.mark.parametrize("selfcomm", [False, True])
+def test_multi_level_halo_resident_on_device(monkeypatch, selfcomm):
+    """bound_state (source/ice_state.F90:162-217) updates aicen, trcrn, vicen, vsnon, eicen, esnon = 65 levels;
+    ice_HaloUpdate3DR8/4DR8 (mpi/ice_boundary.F90:2216,3587) send all levels of a field in one message per
+    neighbour.  cice_halo_update_dev_r8 does the same on a device-resident field: 65 levels, one update, no
+    staging -- on-rank copies, and (CICE4_AMD_SELF_COMM) through pack -> one RCCL message -> unpack."""
+    if selfcomm:
+        monkeypatch.setenv("CICE4_AMD_SELF_COMM", "1")
+    c = lib.Context(); c.sync()
+    dom = c.domain_create(60, 44, 20, 11, ew=1, ns=0)
+    if selfcomm:
+        assert dom["nsend"] == 1
+        c.comm_init(c.comm_unique_id(), 0, 1)
+        monkeypatch.delenv("CICE4_AMD_SELF_COMM")
+    plain = lib.Context().domain_create(60, 44, 20, 11, ew=1, ns=0)
+    rng = np.random.default_rng(5)
+    for nlev, dt in ((65, np.float64), (3, np.float64), (2, np.int32), (65, np.float64)):
+        a = (rng.uniform(0, 1, (nlev, dom["nblocks"], dom["ny"], dom["nx"])) * 1000).astype(dt)
+        want = a.copy().reshape(nlev, -1); want[:, plain["hdst"]] = want[:, plain["hsrc"]]
+        b = a.copy()
+        c.halo_update_resident(a)
+        assert np.array_equal(a.reshape(nlev, -1), want), (nlev, dt)
+        c.halo_update(b)                                  # host form: one update for all levels as well
+        assert np.array_equal(b.reshape(nlev, -1), want), (nlev, dt)
 
 
 def _owned(dom, f):

@@ -97,6 +97,23 @@ def test_tenth_degree_evp(ctx, orc):
         assert np.array_equal(physical(dom12, s12[k]), one[k]), k
 
 
+def test_tenth_degree_rank_slab_against_checker(ctx, orc):
+    """0.1 degree, ndte = 240, against the checker for ALL 240 subcycles: a full-width 3600 x 300 domain -- the slab
+    one of 8 GPUs owns (BASELINE.json configs[4]) -- whole evp(dt) with the default (exp-using) strength, every
+    output field; ~20 s of checker time.  Same kernels, tile shapes and launch pairing as the 3600 x 2400 run."""
+    dom, grid, s = setup(ctx, 3600, 300, 3600, 300, perturb=0.1, land_frac=0.02)
+    orc.set_evp_parameters(DT, 240); orc.set_strength_parameters()
+    so = {k: v.copy() for k, v in s.items()}
+    orc.evp(orc.make_domain(dom, grid), so)
+    ctx.evp_init(grid, ndte=240)
+    assert ctx.evp_get_info("fused") == 1
+    ctx.evp(DT, s)
+    for k in PRIMARY + ("divu", "shear", "rdg_conv", "rdg_shear", "prs_sig", "strength", "strocnxT", "strocnyT",
+                        "strintx", "strinty", "iceumask"):
+        assert relerr(s[k], so[k]) <= TOL_EXP, (k, relerr(s[k], so[k]))
+    assert 0.01 < np.abs(s["uvel"]).max() < 5.0
+
+
 def test_tenth_degree_24_hours(ctx):
     """BASELINE.json configs[4]: 0.1 degree, ndte = 240, 24 h = 24 steps of dt = 3600 s with the state
     resident on the device (velocity, stresses and masks carried from step to step).  Two subcycles per
