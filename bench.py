@@ -37,6 +37,15 @@ THERMO_BYTES_PER_COLUMN = 304.0  # per (cell,category) update (+376 B per cell s
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+_T0 = time.time()
+
+
+def progress(msg):
+    """Stage markers on stderr (the JSON line is the only thing on stdout): a long run must not look hung."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def workload(name):
     if name in WORKLOADS:
         return WORKLOADS[name]
@@ -199,6 +208,15 @@ def thermo_case(dom, seed=20261003, coherent=None):
     return b, cols
 
 
+def host_cores():
+    """Threads of the all-cores baseline: the cores this process may run on, at most 16 (the CPU share of one
+    GPU on the bench hosts; CICE4_AMD_BENCH_CORES overrides)."""
+    if os.environ.get("CICE4_AMD_BENCH_CORES"):
+        return max(1, int(os.environ["CICE4_AMD_BENCH_CORES"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     """Time the CPU checker on a bounded sample of the SAME workload, on this host.
     kind 'reference': the reference's own compiled Fortran (oracle/_ref), single thread;
@@ -268,7 +286,7 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     # --- all host cores available to this process: the C restatement ("port"; bit-identical to the reference,
     # tests/test_oracle_vs_ref.py) with its stress / stepu loops spread over the cores by OpenMP, and
     # thermo_vertical on one slice of the cell list per thread.  A reported baseline, not a target.
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (ncpu or 1)
+    ncores = host_cores()
     if ncores > 1:
         try:
             orc_mp = orc_mod.Oracle(omp=True)
@@ -347,18 +365,25 @@ def run_cpu_baseline(args):
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    env["OMP_NUM_THREADS"] = str(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
-    subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, env=env)
-    with open(path) as f:
-        res = json.load(f)
-    os.unlink(path)
+    env["OMP_NUM_THREADS"] = str(host_cores())
+    try:
+        subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True, env=env,
+                       timeout=max(180.0, 20.0 * args.cpu_seconds))
+        with open(path) as f:
+            res = json.load(f)
+    except (subprocess.SubprocessError, OSError, ValueError) as e:
+        res = {"error": f"{type(e).__name__}: {e}"[:300]}
+    if os.path.exists(path):
+        os.unlink(path)
     return res
 
 
 def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, warmup, ramp_seconds, tune=True):
     """W warm-up + exactly K timed steps of the EVP hot loop on resident state for workload `wl`.
     Returns everything the JSON line needs (rank-local cell counts already reduced over the ranks)."""
+    progress(f"{wl}: building the synthetic case")
     dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs)
+    progress(f"{wl}: case built, device set-up")
     if world > 1 and not getattr(ctx, "_comm_ready", False):
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
@@ -410,6 +435,7 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     for _ in range(warmup):
         ctx.evp_subcycles(1, ndte)
     sync_all()
+    progress(f"{wl}: ramp ({n_ramp[0]} steps) and warm-up done, timing {steps} steps")
     t0 = time.perf_counter()
     dev_ms = 0.0
     for _ in range(steps):
@@ -474,8 +500,10 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
 def measure_thermo(ctx, args, wl, dom, world, dist, torch, steps):
     """K batched passes of the column thermodynamics over every (cell, category) of the rank; state restored
     before each pass (not timed)."""
+    progress(f"{wl}: thermo case")
     ctx.thermo_init()
     tb, tcols = thermo_case(dom, coherent=args.thermo_coherence)
+    progress(f"{wl}: thermo passes")
     ctx.thermo_batch_alloc(dom["nx"], dom["ny"], dom["nblocks"])
     t_ms, nupd = 0.0, 0
     npass = max(2, min(steps, 10))
@@ -556,6 +584,7 @@ def main():
         t1 = (time.perf_counter() - t1) / 2
         pcie = {"what": "cice_evp(dt): H2D of 33 fields + prepare + ndte subcycles + finish + D2H of 38 fields, "
                         "host arrays page-locked once (cice_evp_pin_fields), as the Fortran drop-in does", "ms_per_call": 1e3 * t1, "subcycles_per_s": ndte / t1}
+        ctx.host_unregister_all()     # before the arrays are released (a stale page-locked range faults later)
         del st2
 
     # ---- thermo (secondary figure)
@@ -590,8 +619,10 @@ def main():
         if pcie:
             out["pcie_inclusive"] = pcie
         if world == 1 and not args.no_cpu_baseline:
+            progress("cpu baseline (child process)")
             cb = run_cpu_baseline(args)
-            out["cpu_baseline"] = dict(cb["evp"])
+            out["cpu_baseline"] = dict(cb.get("evp") or {"value": None, "unit": "EVP subcycles/s", "cores": 0,
+                                                         "kind": "reference", "sample": "not measured: " + cb.get("error", "?")})
             if "evp_all_cores" in cb:
                 out["cpu_baseline"]["all_cores"] = cb["evp_all_cores"]
             if "thermo" in cb and thermo:

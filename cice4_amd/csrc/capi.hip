@@ -171,6 +171,18 @@ int cice_host_register(cice_ctx* ctx, void* host, size_t bytes) {
   CICE_CATCH
 }
 
+// Undo every cice_host_register / cice_evp_pin_fields of this context.  Page-locked host ranges MUST be
+// released before the host frees that memory: the runtime keeps treating the range as DMA-able, and a later
+// allocation that lands there is read through a stale mapping (GPU memory access fault).
+int cice_host_unregister_all(cice_ctx* ctx) {
+  CICE_TRY(ctx)
+  if (c_->stream) CICE_HIP(hipStreamSynchronize(c_->stream));
+  for (void* h : c_->pinned)
+    if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
+  c_->pinned.clear();
+  CICE_CATCH
+}
+
 int cice_destroy(cice_ctx* ctx) {
   if (!ctx) return CICE_EINVAL;
   for (void* h : ctx->pinned)

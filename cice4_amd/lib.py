@@ -350,6 +350,10 @@ class Context:
         """Page-lock a numpy array that will be passed to evp()/thermo entries repeatedly."""
         self._ck(self.lib.cice_host_register(self.h, arr.ctypes.data_as(C.c_void_p), C.c_size_t(arr.nbytes)))
 
+    def host_unregister_all(self):
+        """Must precede the release of any array handed to host_register / evp_pin_fields."""
+        self._ck(self.lib.cice_host_unregister_all(self.h))
+
     def thermo_batch_upload(self, a):
         f = self._thermo_fields(a)
         self._ck(self.lib.cice_thermo_batch_upload(self.h, C.byref(f)))

@@ -52,6 +52,9 @@ int cice_device_count(void);
  * Purely an optimisation: arrays that cannot be registered are used pageable.  Registered ranges are
  * released by cice_destroy. */
 int cice_host_register(cice_ctx *ctx, void *host, size_t bytes);
+/* Release every range page-locked through this context (cice_host_register, cice_evp_pin_fields); call it
+ * BEFORE the host frees or re-allocates such an array. */
+int cice_host_unregister_all(cice_ctx *ctx);
 int cice_destroy(cice_ctx *ctx);
 const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
 int cice_device_sync(cice_ctx *ctx);

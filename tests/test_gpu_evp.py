@@ -593,4 +593,5 @@ def test_page_locked_host_arrays_give_the_same_result(orc):
     c.evp(DT, a)
     for k in EVP_OUT_FIELDS:
         assert np.array_equal(a[k], b[k]), k
+    c.host_unregister_all()                             # before the arrays go away
     del c
