@@ -590,6 +590,44 @@ def main():
     # ---- thermo (secondary figure)
     thermo, tcols = (None, None) if args.no_thermo else measure_thermo(ctx, args, args.workload, dom, world, dist, torch, args.steps)
 
+    # ---- PCIe-inclusive thermodynamic half-step: cice_step_therm1 (one upload, frzmlt + thermo x ncat + merge_fluxes
+    # on the device, one download), host arrays page-locked once.  Never `value`.
+    if pcie is not None and thermo is not None:
+        progress("gx1: PCIe-inclusive step_therm1")
+        tb, _ = thermo_case(dom, coherent=args.thermo_coherence)
+        for k in ("fsensn", "fswabsn", "flwoutn", "evapn", "freshn", "fsaltn", "fhocnn"):
+            del tb[k]      # locals of step_therm1 that only feed merge_fluxes (CICE_RunMod.F90:296-312): not downloaded
+        nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
+        fz = dict(aice=np.ascontiguousarray(tb["aicen"].sum(axis=1)), frzmlt=np.full((nb, ny, nx), -5.0),
+                  Tf=np.full((nb, ny, nx), -1.8), sst=np.full((nb, ny, nx), -1.7), strocnxT=np.full((nb, ny, nx), 0.05),
+                  strocnyT=np.full((nb, ny, nx), 0.02), Tbot=np.zeros((nb, ny, nx)), fbot=np.zeros((nb, ny, nx)),
+                  rside=np.zeros((nb, ny, nx)))
+        pc = {k: np.zeros(tb["aicen"].shape) for k in ("strairxn", "strairyn", "Trefn", "Qrefn")}
+        acc = {k: np.zeros((nb, ny, nx)) for k in lib.MERGE_ORDER}
+        keep = [tb, fz, pc, acc]
+        for d in keep:
+            for v in d.values():
+                if isinstance(v, np.ndarray):
+                    ctx.host_register(v)
+        state0 = {k: tb[k].copy() for k in lib.THERMO_STATE + lib.THERMO_SW + lib.THERMO_ONSET}
+        times = []
+        for _ in range(3):
+            for k, v in state0.items():
+                tb[k][...] = v
+            t1 = time.perf_counter()
+            st = ctx.step_therm1(DT, 150.0, tb, fz, pc, acc)
+            times.append(time.perf_counter() - t1)
+        ctx.host_unregister_all()
+        del keep, tb, fz, pc, acc
+        if not st["l_stop"]:
+            pcie["step_therm1"] = {"what": "cice_step_therm1: ONE upload (state, forcing, shortwave, per-category atmo outputs, "
+                                           "20 accumulators ~ 150 planes), frzmlt_bottom_lateral + thermo_vertical x 5 categories + "
+                                           "merge_fluxes on the device, ONE download (~80 planes: state, shortwave, the per-category module arrays, accumulators, Tbot/fbot/rside); page-locked host arrays",
+                                   "ms_per_call": 1e3 * min(times[1:]), "column_updates": st["n_updates"],
+                                   "updates_per_s": st["n_updates"] / min(times[1:])}
+            pcie["therm1_plus_evp_ms"] = pcie["ms_per_call"] + pcie["step_therm1"]["ms_per_call"]
+            pcie["resident_ms"] = 1e3 * m["t_evp"] / args.steps + thermo["ms_per_pass"]
+
     # ---- the 0.1-degree configuration (BASELINE.json configs[4]) inside the same line: a short run, EVP only + thermo
     tenth = None
     if args.workload == "gx1" and not args.no_tenth and args.slabs == 0:

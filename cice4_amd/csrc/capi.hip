@@ -38,6 +38,8 @@ struct cice_ctx {
     DevBuf<int32_t> blk;
     DevBuf<double> aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot,
         lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, out15, mlt_onset, frz_onset;
+    DevBuf<double> mrg_in, mrg_acc, fz_in;   // merge_fluxes inputs / accumulators, frzmlt inputs + rside
+    std::vector<int32_t> hblk;               // ilo, ihi, jlo, jhi per block (host copy of blk)
   } tb;
   // device is required lazily: domain queries work on a CPU-only host
   // Every C-ABI entry binds the calling thread to this context's device first (CICE_TRY): the host
@@ -632,6 +634,8 @@ int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
   }
   t.blk.alloc(hb.size());
   t.blk.upload(hb.data(), c_->stream);
+  t.hblk = hb;
+  t.mrg_in.alloc(5 * nc); t.mrg_acc.alloc(20 * n2); t.fz_in.alloc(7 * n2);
   t.aicen.alloc(nc); t.trcrn.alloc(nc * NTRCR); t.vicen.alloc(nc); t.vsnon.alloc(nc);
   t.eicen.alloc(nc * NILYR); t.esnon.alloc(nc * NSLYR);
   for (DevBuf<double>* d : {&t.flw, &t.potT, &t.Qa, &t.rhoa, &t.fsnow, &t.fbot, &t.Tbot, &t.mlt_onset,
@@ -646,8 +650,7 @@ int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
   CICE_CATCH
 }
 
-int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
-  CICE_TRY(ctx)
+static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fbot_tbot) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
   struct U { DevBuf<double>* d; const double* h; };
@@ -658,6 +661,7 @@ int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
             {&t.fswint, h->fswint}, {&t.fswthrun, h->fswthrun}, {&t.Sswabs, h->Sswabs},
             {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset}, {&t.frz_onset, h->frz_onset}};
   for (U& x : us) {
+    if (!with_fbot_tbot && (x.d == &t.fbot || x.d == &t.Tbot)) continue;   // produced on the device
     CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
     x.d->upload(x.h, c_->stream);
   }
@@ -670,18 +674,22 @@ int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
       CICE_HIP(hipMemcpyAsync(t.out15.p + (size_t)plane[k] * nc, in3[k], nc * 8, hipMemcpyHostToDevice, c_->stream));
     }
   }
+}
+
+int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
+  CICE_TRY(ctx)
+  batch_upload(c_, h, true);
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
 }
 
-int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_updates,
-                           int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
-                           int32_t* bstop, float* elapsed_ms) {
-  CICE_TRY(ctx)
+// launches the dense kernel; the 16-byte status (error key, update count) lands in `status` once the
+// stream has been synchronised
+static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long status[2], float* elapsed_ms,
+                       hipEvent_t* ev) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
   CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
-  CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
   hipStream_t s = c_->stream;
   const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
   CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
@@ -700,29 +708,36 @@ int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_u
   for (int k = 0; k < 15; ++k) *outs[k] = t.out15.p + (size_t)k * nc;
   a.mlt_onset = t.mlt_onset.p; a.frz_onset = t.frz_onset.p;
   a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
   if (elapsed_ms) {
-    CICE_HIP(hipEventCreate(&e0));
-    CICE_HIP(hipEventCreate(&e1));
-    CICE_HIP(hipEventRecord(e0, s));
+    CICE_HIP(hipEventCreate(&ev[0]));
+    CICE_HIP(hipEventCreate(&ev[1]));
+    CICE_HIP(hipEventRecord(ev[0], s));
   }
   thermo_launch_dense(a, s);
-  if (elapsed_ms) CICE_HIP(hipEventRecord(e1, s));
+  if (elapsed_ms) CICE_HIP(hipEventRecord(ev[1], s));
+  CICE_HIP(hipMemcpyAsync(status, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
+}
+
+int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_updates,
+                           int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
+                           int32_t* bstop, float* elapsed_ms) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
   unsigned long long h[2];
-  CICE_HIP(hipMemcpyAsync(h, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
-  CICE_HIP(hipStreamSynchronize(s));
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  batch_step(c_, dt, yday, h, elapsed_ms, ev);
+  CICE_HIP(hipStreamSynchronize(c_->stream));
   if (elapsed_ms) {
-    CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    CICE_HIP(hipEventElapsedTime(elapsed_ms, ev[0], ev[1]));
+    (void)hipEventDestroy(ev[0]);
+    (void)hipEventDestroy(ev[1]);
   }
   if (n_updates) *n_updates = (long long)h[1];
-  decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
+  decode_err(h[0], c_->tb.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
   CICE_CATCH
 }
 
-int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
-  CICE_TRY(ctx)
+static void batch_download(cice_ctx* c_, cice_thermo_fields* h) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
   hipStream_t s = c_->stream;
@@ -740,21 +755,26 @@ int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
   for (int k = 0; k < 15; ++k)
     if (houts[k])
       CICE_HIP(hipMemcpyAsync(houts[k], t.out15.p + (size_t)k * nc, nc * 8, hipMemcpyDeviceToHost, s));
-  CICE_HIP(hipStreamSynchronize(s));
+}
+
+int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
+  CICE_TRY(ctx)
+  batch_download(c_, h);
+  CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
 }
 
-int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
-  CICE_TRY(ctx)
+// aicen_init_dev: device copy of the initial concentrations (cice_step_therm1 keeps one); otherwise
+// f->aicen_init is uploaded
+static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* aicen_init_dev) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && f, "cice_thermo_batch_alloc has not been called");
   hipStream_t s = c_->stream;
   const size_t n2 = (size_t)t.nx * t.ny * t.nb, nc = n2 * NCAT;
-  DevBuf<double> up, acc;
-  up.alloc(5 * nc);
-  acc.alloc(20 * n2);
+  DevBuf<double>&up = t.mrg_in, &acc = t.mrg_acc;
   const double* hin[5] = {f->aicen_init, f->strairxn, f->strairyn, f->Trefn, f->Qrefn};
   for (int k = 0; k < 5; ++k) {
+    if (k == 0 && aicen_init_dev) continue;
     CICE_REQUIRE(hin[k] != nullptr, "cice_thermo_batch_merge: NULL input");
     CICE_HIP(hipMemcpyAsync(up.p + (size_t)k * nc, hin[k], nc * 8, hipMemcpyHostToDevice, s));
   }
@@ -764,7 +784,7 @@ int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
   }
   MergeArgs a{};
   a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.blk = t.blk.p;
-  a.aicen_init = up.p; a.flw = t.flw.p;
+  a.aicen_init = aicen_init_dev ? aicen_init_dev : up.p; a.flw = t.flw.p;
   auto out = [&](int k) { return (const double*)(t.out15.p + (size_t)k * nc); };
   // out15 order: fsurfn fcondtopn fsensn flatn fswabsn flwoutn evapn freshn fsaltn fhocnn meltt melts
   //              meltb congel snoice
@@ -778,7 +798,57 @@ int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
   merge_launch(a, s);
   for (int k = 0; k < 20; ++k)
     CICE_HIP(hipMemcpyAsync(f->acc[k], acc.p + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToHost, s));
+}
+
+int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
+  CICE_TRY(ctx)
+  batch_merge(c_, f, nullptr);
+  CICE_HIP(hipStreamSynchronize(c_->stream));
+  CICE_CATCH
+}
+
+// One call for the thermodynamic half of a time step on all local blocks (the work of step_therm1,
+// drivers/cice4/CICE_RunMod.F90:260-598, minus atmo_boundary_layer, whose per-category outputs are inputs
+// here): ONE upload, frzmlt_bottom_lateral (:363) -> thermo_vertical for every category (:502) ->
+// merge_fluxes (:565) on the device, ONE download, one synchronisation.
+int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* st,
+                     const cice_frzmlt_fields* fz, const cice_merge_fields* mg, long long* n_updates,
+                     int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop, int32_t* bstop) {
+  CICE_TRY(ctx)
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
+  CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
+  CICE_REQUIRE(st && fz && mg && l_stop && istop && jstop, "NULL argument");
+  CICE_REQUIRE(fz->aice && fz->frzmlt && fz->sst && fz->Tf && fz->strocnxT && fz->strocnyT, "NULL frzmlt input");
+  hipStream_t s = c_->stream;
+  const size_t np = (size_t)t.nx * t.ny, n2 = np * t.nb, nc = n2 * NCAT;
+  batch_upload(c_, st, false);
+  const double* fin[6] = {fz->aice, fz->frzmlt, fz->sst, fz->Tf, fz->strocnxT, fz->strocnyT};
+  for (int k = 0; k < 6; ++k)
+    CICE_HIP(hipMemcpyAsync(t.fz_in.p + (size_t)k * n2, fin[k], n2 * 8, hipMemcpyHostToDevice, s));
+  for (int b = 0; b < t.nb; ++b) {   // frzmlt_bottom_lateral per block, on the uploaded enthalpies
+    FrzmltArgs a{};
+    a.nx = t.nx; a.ny = t.ny; a.dt = dt; a.ustar_min = c_->tp.ustar_min;
+    a.ilo = t.hblk[4 * b]; a.ihi = t.hblk[4 * b + 1]; a.jlo = t.hblk[4 * b + 2]; a.jhi = t.hblk[4 * b + 3];
+    const size_t o = (size_t)b * np;
+    a.aice = t.fz_in.p + o; a.frzmlt = t.fz_in.p + n2 + o; a.sst = t.fz_in.p + 2 * n2 + o;
+    a.Tf = t.fz_in.p + 3 * n2 + o; a.strocnxT = t.fz_in.p + 4 * n2 + o; a.strocnyT = t.fz_in.p + 5 * n2 + o;
+    a.Tbot = t.Tbot.p + o; a.fbot = t.fbot.p + o; a.rside = t.fz_in.p + 6 * n2 + o;
+    a.eicen = t.eicen.p + (size_t)b * NCAT * NILYR * np; a.esnon = t.esnon.p + (size_t)b * NCAT * NSLYR * np;
+    frzmlt_launch(a, s);
+  }
+  // aicen_init of merge_fluxes = the concentrations before the column update (CICE_RunMod.F90:342-355)
+  CICE_HIP(hipMemcpyAsync(t.mrg_in.p, t.aicen.p, nc * 8, hipMemcpyDeviceToDevice, s));
+  unsigned long long h[2];
+  batch_step(c_, dt, yday, h, nullptr, nullptr);
+  batch_merge(c_, mg, t.mrg_in.p);
+  batch_download(c_, st);
+  if (fz->Tbot) t.Tbot.download(fz->Tbot, s);
+  if (fz->fbot) t.fbot.download(fz->fbot, s);
+  if (fz->rside) CICE_HIP(hipMemcpyAsync(fz->rside, t.fz_in.p + 6 * n2, n2 * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipStreamSynchronize(s));
+  if (n_updates) *n_updates = (long long)h[1];
+  decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
   CICE_CATCH
 }
 

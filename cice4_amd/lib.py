@@ -68,6 +68,10 @@ class MergeFields(C.Structure):
                [("acc", C.c_void_p * 20)]
 
 
+class FrzmltFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("aice", "frzmlt", "sst", "Tf", "strocnxT", "strocnyT", "Tbot", "fbot", "rside")]
+
+
 class ThermoFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in THERMO_STATE + THERMO_FORCING + THERMO_CAT_IN + THERMO_SW
                 + THERMO_OUT + THERMO_ONSET]
@@ -381,6 +385,28 @@ class Context:
             f.acc[k] = acc[n].ctypes.data
             assert acc[n].dtype == np.float64 and acc[n].flags["C_CONTIGUOUS"]
         self._ck(self.lib.cice_thermo_batch_merge(self.h, C.byref(f)))
+
+    def step_therm1(self, dt, yday, state, fz, percat, acc):
+        """cice_step_therm1: one upload, frzmlt_bottom_lateral + thermo_vertical for every category + merge_fluxes on
+        the device, one download.  state: thermo_batch_upload's dict (fbot/Tbot not needed); fz: aice, frzmlt, sst,
+        Tf, strocnxT, strocnyT (+ optional outputs Tbot, fbot, rside), (nb,ny,nx); percat / acc as thermo_batch_merge
+        (percat['aicen_init'] optional)."""
+        f = self._thermo_fields(state)
+        z = FrzmltFields()
+        for n, _t in FrzmltFields._fields_:
+            setattr(z, n, _f8(fz[n]) if n in fz else None)
+        m = MergeFields()
+        for n in ("aicen_init", "strairxn", "strairyn", "Trefn", "Qrefn"):
+            setattr(m, n, _f8(percat[n]) if n in percat else None)
+        for k, n in enumerate(MERGE_ORDER):
+            m.acc[k] = acc[n].ctypes.data
+            assert acc[n].dtype == np.float64 and acc[n].flags["C_CONTIGUOUS"]
+        nupd = C.c_longlong(0)
+        st = [C.c_int32(0) for _ in range(5)]
+        self._ck(self.lib.cice_step_therm1(self.h, C.c_double(dt), C.c_double(yday), C.byref(f), C.byref(z), C.byref(m),
+                                           C.byref(nupd), *[C.byref(x) for x in st]))
+        return dict(n_updates=nupd.value, l_stop=st[0].value, istop=st[1].value, jstop=st[2].value,
+                    nstop=st[3].value, bstop=st[4].value)
 
     def frzmlt_bottom_lateral(self, ilo, ihi, jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf,
                               strocnxT, strocnyT):

@@ -277,6 +277,22 @@ typedef struct {
 } cice_merge_fields;
 int cice_thermo_batch_merge(cice_ctx *ctx, const cice_merge_fields *f);
 
+/* The thermodynamic half of a time step in ONE call (SURVEY section 8(b) `cice_step_therm1_block`; what
+ * step_therm1, drivers/cice4/CICE_RunMod.F90:260-598, does per block and category): one upload of the state
+ * (cice_thermo_fields, fbot/Tbot ignored), frzmlt_bottom_lateral (:363) on the device from `fz`,
+ * thermo_vertical for every category of every block (:502), merge_fluxes (:565; mg->aicen_init may be NULL: the
+ * concentrations before the update are kept on the device), one download (state, per-category outputs, merged
+ * accumulators, Tbot / fbot / rside where non-NULL).  atmo_boundary_layer (:402) stays with the caller: its
+ * per-category outputs lhcoef, shcoef (st) and strairxn, strairyn, Trefn, Qrefn (mg) are inputs.
+ * All fields (nx,ny[,..],nb) as in cice_thermo_fields; needs cice_thermo_batch_alloc. */
+typedef struct {
+  const double *aice, *frzmlt, *sst, *Tf, *strocnxT, *strocnyT; /* (nx,ny,nb) in */
+  double *Tbot, *fbot, *rside;                                  /* (nx,ny,nb) out, may be NULL */
+} cice_frzmlt_fields;
+int cice_step_therm1(cice_ctx *ctx, double dt, double yday, cice_thermo_fields *state,
+                     const cice_frzmlt_fields *fz, const cice_merge_fields *mg, long long *n_updates,
+                     int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop, int32_t *bstop);
+
 /* frzmlt_bottom_lateral (:605-824), one block, host pointers;
  * eicen (nx,ny,ntilyr), esnon (nx,ny,ntslyr). */
 int cice_frzmlt_bottom_lateral(cice_ctx *ctx, int nx_block, int ny_block, int ilo, int ihi,

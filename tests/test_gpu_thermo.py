@@ -258,6 +258,51 @@ def test_batch_merge_equals_merge_fluxes(ctx, orc):
             assert np.array_equal(got[lk][b], want[ok]), (b, lk)
 
 
+def test_step_therm1_single_call_equals_the_separate_calls(ctx):
+    """cice_step_therm1 (one upload, frzmlt_bottom_lateral -> thermo_vertical x ncat -> merge_fluxes on the device, one
+    download) against the same work through the separate entries (frzmlt per block, batch upload / step / merge /
+    download), which the tests above pin to the checker: every field bit for bit."""
+    ctx.thermo_init()
+    ny, nx, nb = 22, 34, 2
+    batch, percat = _batch_inputs(ny, nx, nb, seed=35)
+    rng = np.random.default_rng(6)
+    aice = np.ascontiguousarray(batch["aicen"].sum(axis=1))
+    fz = dict(aice=aice, frzmlt=np.ascontiguousarray(rng.uniform(-60, 20, (nb, ny, nx))),
+              Tf=np.full((nb, ny, nx), -1.8), strocnxT=np.ascontiguousarray(rng.uniform(-0.2, 0.2, (nb, ny, nx))),
+              strocnyT=np.ascontiguousarray(rng.uniform(-0.2, 0.2, (nb, ny, nx))))
+    fz["sst"] = fz["Tf"] + rng.uniform(0, 0.5, (nb, ny, nx))
+    pc = {k: np.ascontiguousarray(rng.uniform(-1, 1, batch["aicen"].shape)) for k in ("strairxn", "strairyn", "Trefn", "Qrefn")}
+    acc0 = {k: np.ascontiguousarray(rng.uniform(-1, 1, (nb, ny, nx))) for k in lib.MERGE_ORDER}
+    # (a) separate entries
+    a = {k: v.copy() for k, v in batch.items()}
+    rs = np.zeros((nb, ny, nx))
+    for b in range(nb):
+        tb, fb, r = ctx.frzmlt_bottom_lateral(2, nx - 1, 2, ny - 1, DT, fz["aice"][b], fz["frzmlt"][b],
+                                               np.ascontiguousarray(a["eicen"][b]), np.ascontiguousarray(a["esnon"][b]),
+                                               fz["sst"][b], fz["Tf"][b], fz["strocnxT"][b], fz["strocnyT"][b])
+        a["Tbot"][b] = tb; a["fbot"][b] = fb; rs[b] = r
+    ctx.thermo_batch_alloc(nx, ny, nb)
+    ctx.thermo_batch_upload(a)
+    st_a = ctx.thermo_batch_step(DT, yday=150.0)
+    acc_a = {k: v.copy() for k, v in acc0.items()}
+    ctx.thermo_batch_merge(dict(pc, aicen_init=batch["aicen"].copy()), acc_a)
+    ctx.thermo_batch_download(a)
+    # (b) one call
+    b_ = {k: v.copy() for k, v in batch.items()}
+    fzb = dict(fz, Tbot=np.zeros((nb, ny, nx)), fbot=np.zeros((nb, ny, nx)), rside=np.zeros((nb, ny, nx)))
+    acc_b = {k: v.copy() for k, v in acc0.items()}
+    st_b = ctx.step_therm1(DT, 150.0, b_, fzb, pc, acc_b)
+    assert st_b["l_stop"] == st_a["l_stop"] == 0 and st_b["n_updates"] == st_a["n_updates"] > 0
+    assert np.array_equal(fzb["Tbot"], a["Tbot"]) and np.array_equal(fzb["fbot"], a["fbot"]) and np.array_equal(fzb["rside"], rs)
+    assert np.abs(fzb["fbot"]).max() > 0 and np.abs(rs).max() > 0
+    for k in lib.THERMO_STATE + lib.THERMO_SW + lib.THERMO_OUT + lib.THERMO_ONSET:
+        if k == "fswthrun":
+            continue
+        assert np.array_equal(b_[k], a[k]), k
+    for k in lib.MERGE_ORDER:
+        assert np.array_equal(acc_b[k], acc_a[k]), k
+
+
 def test_frzmlt_bottom_lateral(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
     ny, nx = 30, 44
