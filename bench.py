@@ -149,7 +149,7 @@ def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
         if overlap < 0:
             overlap = auto_overlap(nxg, rows)
         dom = ctx.domain_create_slabs(nxg, nyg, slabs, ew=1, ns=0, rank=0, nranks=1, overlap=overlap)
-        if dom["nsend"]:
+        if dom["nsend"]:        # CICE4_AMD_SELF_COMM: messages to the own rank through a 1-rank communicator
             ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     elif world == 1:
         dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
@@ -384,10 +384,13 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     progress(f"{wl}: building the synthetic case")
     dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs)
     progress(f"{wl}: case built, device set-up")
-    if world > 1 and not getattr(ctx, "_comm_ready", False):
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+    if world > 1:
+        # the communicator is created once per context and handed to every decomposition built afterwards
+        # (the uid is only used by the first call)
+        uid = [ctx.comm_unique_id() if rank == 0 and not getattr(ctx, "_comm_ready", False) else None]
+        if not getattr(ctx, "_comm_ready", False):
+            dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0] if uid[0] is not None else bytes(128), rank, world)
         ctx._comm_ready = True
     ctx.evp_init(grid, ndte=ndte)
     if tune and args.waves:
@@ -549,6 +552,11 @@ def main():
     # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With
     # torch first, libcice4_amd.so runs on torch's bundled runtime and RCCL -- the combination
     # scripts/gpu_slabs_selfcomm.sh exercises.
+    # stdout carries exactly ONE line (the JSON record, rank 0): everything else that native libraries print
+    # there -- RCCL's version banner at communicator creation, Fortran runtime messages -- goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world, local, dist = init_dist(args.gpus)
     try:
         import torch
@@ -630,7 +638,7 @@ def main():
 
     # ---- the 0.1-degree configuration (BASELINE.json configs[4]) inside the same line: a short run, EVP only + thermo
     tenth = None
-    if args.workload == "gx1" and not args.no_tenth and args.slabs == 0:
+    if args.workload == "gx1" and not args.no_tenth:
         del state
         m["state"] = m["grid"] = None
         t = measure_evp(ctx, args, "tenth", rank, world, dist, torch, have_torch_gpu, args.tenth_steps, 1, 0.3, tune=False)
@@ -667,7 +675,8 @@ def main():
                 out["thermo"]["cpu_baseline"] = cb["thermo"]
                 if "thermo_all_cores" in cb:
                     out["thermo"]["cpu_baseline"]["all_cores"] = cb["thermo_all_cores"]
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -23,6 +23,10 @@ struct cice_ctx {
   bool have_domain = false;
   std::unique_ptr<Halo> halo;
   std::unique_ptr<Evp> evp;
+  // RCCL communicator of this rank (cice_comm_init): created once, handed to every Halo built afterwards --
+  // the block decomposition may change (cice_domain_create*), the set of ranks does not
+  ncclComm_t comm = nullptr;
+  int comm_rank = -1, comm_nranks = 0;
   std::vector<void*> pinned;   // cice_host_register
   // staging of the host-pointer entries (thermo_vertical is called ncat x nblocks times per step with
   // the same block size: allocated once, grown only when a larger block comes along)
@@ -66,6 +70,7 @@ struct cice_ctx {
       CICE_REQUIRE(have_domain, "cice_domain_create has not been called");
       halo.reset(new Halo());
       halo->init(dom, stream);
+      if (comm) halo->set_comm((ncclComm*)comm, comm_rank, comm_nranks);
     }
   }
 };
@@ -191,6 +196,7 @@ int cice_destroy(cice_ctx* ctx) {
     if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
   ctx->evp.reset();
   ctx->halo.reset();
+  if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CICE_OK;
@@ -332,8 +338,24 @@ int cice_comm_unique_id(char uid[128]) {
 int cice_comm_init(cice_ctx* ctx, const char uid[128], int rank, int nranks) {
   CICE_TRY(ctx)
   if (skip_comm()) return CICE_OK;
+  CICE_REQUIRE(uid != nullptr && nranks >= 1 && rank >= 0 && rank < nranks, "cice_comm_init: bad arguments");
   c_->need_halo();
-  c_->halo->comm_init(uid, rank, nranks);
+  if (!c_->comm) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    std::memcpy(&id, uid, sizeof(id));
+    const ncclResult_t r = ncclCommInitRank(&c_->comm, nranks, id, rank);
+    if (r != ncclSuccess) {
+      c_->comm = nullptr;
+      throw Error{CICE_ECOMM, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)};
+    }
+    c_->comm_rank = rank;
+    c_->comm_nranks = nranks;
+  } else {
+    CICE_REQUIRE(rank == c_->comm_rank && nranks == c_->comm_nranks,
+                 "cice_comm_init: this context already has a communicator with another rank / size");
+  }
+  c_->halo->set_comm((ncclComm*)c_->comm, c_->comm_rank, c_->comm_nranks);
   CICE_CATCH
 }
 

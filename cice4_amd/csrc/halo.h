@@ -18,7 +18,9 @@ class Halo {
   Halo() = default;
   ~Halo();
   void init(const Domain& d, hipStream_t s);
-  void comm_init(const char uid[128], int rank, int nranks);
+  // The RCCL communicator belongs to the CONTEXT (it outlives a change of the block decomposition); a Halo
+  // borrows it.
+  void set_comm(ncclComm* c, int rank, int nranks);
   bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
   bool has_refresh() const { return remote_ || nrefresh_ > 0; }
   // nfields fields of element type T, field k starting at base + k*stride (elements).

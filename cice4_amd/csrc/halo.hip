@@ -141,18 +141,11 @@ void Halo::reserve(int nfields) {
   ++generation_;
 }
 
-Halo::~Halo() {
-  if (comm_) (void)ncclCommDestroy((ncclComm_t)comm_);
-}
+Halo::~Halo() = default;
 
-void Halo::comm_init(const char uid[128], int rank, int nranks) {
+void Halo::set_comm(ncclComm* c, int rank, int nranks) {
   CICE_REQUIRE(rank == rank_ && nranks == nranks_, "cice_comm_init: rank/nranks differ from cice_domain_create");
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-  ncclUniqueId id;
-  std::memcpy(&id, uid, sizeof(id));
-  ncclComm_t c;
-  CICE_NCCL(ncclCommInitRank(&c, nranks, id, rank));
-  comm_ = (ncclComm*)c;
+  comm_ = c;
 }
 
 template <class T>
