@@ -84,3 +84,44 @@ def test_reference_step_loop_with_dropin_modules(name, tol):
     assert "EVP dynamics on the GPU" in log
     worst = _compare(rec, gold, stride, tol)
     print("whole-driver drop-in", name, "worst field-relative difference", worst)
+
+
+@pytest.mark.gpu
+def test_restart_round_trip_with_dropin_modules():
+    """Checkpoint / resume through the reference's own dumpfile / restartfile (source/ice_restart.F90:74-256, :265)
+    with the GPU modules in the loop: (A) 50 steps without interruption, dumps after 25 and 49 steps; (B) a new
+    process restarted from A's first dump (runtype = 'continue': velocities, 12 stresses, iceumask, state read back
+    into the module arrays the drop-in evp uploads).  B's dump must equal A's second dump bit for bit, and both
+    must equal the PURE reference run on this host (cice_ref_gx3, 50 steps)."""
+    import glob
+    exe = {k: os.path.join(ROOT, "oracle", "_ref", "cice_%s_gx3" % k) for k in ("ref", "dropin")}
+    for e in exe.values():
+        if not os.path.exists(e):
+            pytest.skip("%s not built" % e)
+    dirs = {k: tempfile.mkdtemp(prefix="cice_rs_%s_" % k) for k in ("A", "B", "R")}
+    try:
+        dumps = {}
+        for tag, kind in (("A", "dropin"), ("R", "ref")):
+            driver.write_rundir(dirs[tag], npt=50)
+            driver.run(exe[kind], dirs[tag])
+            dumps[tag] = sorted(f for f in glob.glob(dirs[tag] + "/restart/iced.1997*"))
+            assert [os.path.basename(f) for f in dumps[tag]] == ["iced.1997-01-02-00000", "iced.1997-01-03-00000"]
+        driver.write_rundir(dirs["B"], npt=30, overrides={"setup_nml": dict(runtype="continue", restart=True)})
+        for f in glob.glob(dirs["A"] + "/restart/iced*1997-01-02*"):      # the dump and its ice-age companion
+            shutil.copy(f, dirs["B"] + "/restart/")
+        with open(dirs["B"] + "/restart/ice.restart_file", "w") as f:
+            f.write("./restart/iced.1997-01-02-00000\n")
+        log = driver.run(exe["dropin"], dirs["B"])
+        assert "Using restart dump" in log and "EVP dynamics on the GPU" in log
+        a2 = driver.read_restart(dumps["A"][1], 100, 116)
+        b2 = driver.read_restart(dirs["B"] + "/restart/iced.1997-01-03-00000", 100, 116)
+        r2 = driver.read_restart(dumps["R"][1], 100, 116)
+        assert a2[0] == b2[0] == r2[0] and a2[0]["istep1"] == 48
+        for k in a2[1]:
+            assert np.array_equal(a2[1][k], b2[1][k]), ("restarted vs uninterrupted", k)
+            if TOL_EXP == 0.0:
+                assert np.array_equal(a2[1][k], r2[1][k]), ("drop-in vs pure reference, 49 steps", k)
+        assert np.abs(a2[1]["uvel"]).max() > 0.05
+    finally:
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
