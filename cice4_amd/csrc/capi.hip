@@ -6,6 +6,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <type_traits>
 
 #include "common.h"
 #include "domain.h"
@@ -117,7 +118,17 @@ __global__ __launch_bounds__(256) void k_diag_copy16(const double2* __restrict__
 // staged through a persistent device buffer (grown only when a larger field comes along) and ALL its levels
 // travel in one update = one message per neighbour (bound_state's 65 levels included, ice_state.F90:162-217).
 template <class T>
-static void halo_host(cice_ctx* c, T* field, int nlev) {
+static void halo_apply(cice_ctx* c, T* d, int nlev, size_t n, int loc, int kind, double fill) {
+  if (std::is_same<T, double>::value)
+    c->halo->update_r8(reinterpret_cast<double*>(d), nlev, n, true, loc, kind, fill);
+  else if (std::is_same<T, float>::value)
+    c->halo->update_r4(reinterpret_cast<float*>(d), nlev, n, loc, kind, (float)fill);
+  else
+    c->halo->update_i4(reinterpret_cast<int32_t*>(d), nlev, n, loc, kind, (int32_t)fill);
+}
+
+template <class T>
+static void halo_host(cice_ctx* c, T* field, int nlev, int loc = LOC_CENTER, int kind = KIND_SCALAR, double fill = 0.0) {
   c->need_halo();
   CICE_REQUIRE(field && nlev >= 1, "bad argument");
   const size_t n = (size_t)c->dom.nblocks() * c->dom.nx_block * c->dom.ny_block;
@@ -125,8 +136,7 @@ static void halo_host(cice_ctx* c, T* field, int nlev) {
   if (c->halo_stage.n < words) c->halo_stage.alloc(words);
   T* d = reinterpret_cast<T*>(c->halo_stage.p);
   CICE_HIP(hipMemcpyAsync(d, field, n * nlev * sizeof(T), hipMemcpyHostToDevice, c->stream));
-  if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(d), nlev, n);
-  else c->halo->update_i4(reinterpret_cast<int32_t*>(d), nlev, n);
+  halo_apply<T>(c, d, nlev, n, loc, kind, fill);
   CICE_HIP(hipMemcpyAsync(field, d, n * nlev * sizeof(T), hipMemcpyDeviceToHost, c->stream));
   CICE_HIP(hipStreamSynchronize(c->stream));
 }
@@ -135,15 +145,14 @@ static void halo_host(cice_ctx* c, T* field, int nlev) {
 // elements, level stride = one such plane set); nothing crosses PCIe, no allocation, asynchronous on the
 // library's stream.
 template <class T>
-static void halo_dev(cice_ctx* c, T* dev_field, int nlev) {
+static void halo_dev(cice_ctx* c, T* dev_field, int nlev, int loc = LOC_CENTER, int kind = KIND_SCALAR, double fill = 0.0) {
   c->need_halo();
   CICE_REQUIRE(dev_field && nlev >= 1, "bad argument");
   hipPointerAttribute_t at{};
   CICE_REQUIRE(hipPointerGetAttributes(&at, dev_field) == hipSuccess && at.type == hipMemoryTypeDevice,
                "cice_halo_update_dev: not a device pointer");
   const size_t n = (size_t)c->dom.nblocks() * c->dom.nx_block * c->dom.ny_block;
-  if (sizeof(T) == 8) c->halo->update_r8(reinterpret_cast<double*>(dev_field), nlev, n);
-  else c->halo->update_i4(reinterpret_cast<int32_t*>(dev_field), nlev, n);
+  halo_apply<T>(c, dev_field, nlev, n, loc, kind, fill);
 }
 
 extern "C" {
@@ -244,7 +253,8 @@ int cice_device_sync(cice_ctx* ctx) {
 int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew, int ns, int rank,
                        int npx, int npy) {
   CICE_TRY(ctx)
-  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 2, "boundary type must be 0 (open), 1 (cyclic) or 2 (closed)");
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 3,
+               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole)");
   c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;  // test aid, see domain.h
   const char* msg = c_->dom.create(nxg, nyg, bsx, bsy, ew, ns, rank, npx, npy);
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create: ") + msg};
@@ -252,6 +262,41 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   c_->evp.reset();
   c_->halo.reset();
   CICE_CATCH
+}
+
+int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew, int ns, int rank,
+                           int nranks, const int* owner, const int* local_id) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 3,
+               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole)");
+  c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;
+  const char* msg = c_->dom.create_map(nxg, nyg, bsx, bsy, ew, ns, rank, nranks, owner, local_id);
+  if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_map: ") + msg};
+  c_->have_domain = true;
+  c_->evp.reset();
+  c_->halo.reset();
+  CICE_CATCH
+}
+
+// host copies of the index lists of the current domain (tests, external tools): *n entries; out may be NULL
+int cice_domain_list(const cice_ctx* ctx, const char* name, int loc, int* n, int32_t* out) {
+  if (!ctx || !ctx->have_domain || !name || !n) return CICE_EINVAL;
+  const Domain& d = ctx->dom;
+  const std::vector<int32_t>* v = nullptr;
+  const std::string k(name);
+  const int l = loc - 1;
+  const bool lok = l >= 0 && l < 4;
+  if (k == "hfill") v = &d.hfill;
+  else if (k == "fold_lsrc") v = &d.fold_lsrc;
+  else if (k == "fold_bidx") v = &d.fold_bidx;
+  else if (k == "fold_dst" && lok) v = &d.fold_out[l].dst;
+  else if (k == "fold_src" && lok) v = &d.fold_out[l].src;
+  else if (k == "fold_lo" && lok) v = &d.fold_lo[l];
+  else if (k == "fold_hi" && lok) v = &d.fold_hi[l];
+  if (!v) return CICE_EINVAL;
+  *n = (int)v->size();
+  if (out && !v->empty()) std::memcpy(out, v->data(), v->size() * 4);
+  return CICE_OK;
 }
 
 int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int ew, int ns, int rank,
@@ -475,6 +520,20 @@ int cice_halo_update_r8(cice_ctx* ctx, double* field, int nlev) {
 }
 int cice_halo_update_i4(cice_ctx* ctx, int32_t* field, int nlev) {
   CICE_TRY(ctx) halo_host<int32_t>(c_, field, nlev); CICE_CATCH
+}
+// the same with the field location / kind (FieldLoc, FieldKind codes of ice_constants.F90:185-205: they decide
+// offsets and sign at a tripole fold) and the fill value for ghost cells facing eliminated land blocks
+int cice_halo_update_ex_r8(cice_ctx* ctx, double* field, int nlev, int loc, int kind, double fill) {
+  CICE_TRY(ctx) halo_host<double>(c_, field, nlev, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_ex_r4(cice_ctx* ctx, float* field, int nlev, int loc, int kind, float fill) {
+  CICE_TRY(ctx) halo_host<float>(c_, field, nlev, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_ex_i4(cice_ctx* ctx, int32_t* field, int nlev, int loc, int kind, int32_t fill) {
+  CICE_TRY(ctx) halo_host<int32_t>(c_, field, nlev, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_dev_ex_r8(cice_ctx* ctx, double* dev_field, int nlev, int loc, int kind, double fill) {
+  CICE_TRY(ctx) halo_dev<double>(c_, dev_field, nlev, loc, kind, fill); CICE_CATCH
 }
 int cice_halo_update_dev_r8(cice_ctx* ctx, double* dev_field, int nlev) {
   CICE_TRY(ctx) halo_dev<double>(c_, dev_field, nlev); CICE_CATCH

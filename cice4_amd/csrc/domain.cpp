@@ -22,17 +22,68 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
   if (block_size_x < 1 || block_size_y < 1) return "block size < 1";
   if (npx_ < 1 || npy_ < 1) return "process grid < 1";
   nxg = nx_global; nyg = ny_global; bsx = block_size_x; bsy = block_size_y;
-  nx_block = bsx + 2; ny_block = bsy + 2;
   nbx = (nxg - 1) / bsx + 1;  // ice_blocks.F90:158-160
   nby = (nyg - 1) / bsy + 1;
   npx = npx_; npy = npy_; nranks = npx * npy; rank = rank_;
   ew = ew_bnd; ns = ns_bnd;
   if (rank < 0 || rank >= nranks) return "rank out of range";
   if (npx > nbx || npy > nby) return "more ranks than blocks along an axis";
-  all.clear(); local.clear(); hsrc.clear(); hdst.clear(); send.clear(); recv.clear();
-  rsrc.clear(); rdst.clear(); overlap = 0;
+  // contiguous rectangles of blocks per rank, dealt the way create_distrb_cart does
+  // (ice_distribution.F90:719-732): ceil(nblocks / nprocs) block columns (rows) per process
+  // column (row), the last ones taking what is left -- possibly nothing
+  std::vector<int> owner((size_t)nbx * nby), lid((size_t)nbx * nby), nlocal(nranks, 0);
+  const int per_x = (nbx - 1) / npx + 1, per_y = (nby - 1) / npy + 1;
+  for (int jb = 0; jb < nby; ++jb)
+    for (int ib = 0; ib < nbx; ++ib) {
+      const int o = (jb / per_y) * npx + ib / per_x;
+      owner[jb * nbx + ib] = o;
+      lid[jb * nbx + ib] = nlocal[o]++;
+    }
+  return build(owner, lid);
+}
 
-  std::vector<int> nlocal(nranks, 0);
+const char* Domain::create_map(int nx_global, int ny_global, int block_size_x, int block_size_y,
+                               int ew_bnd, int ns_bnd, int rank_, int nranks_, const int* owner_in,
+                               const int* lid_in) {
+  if (nx_global < 1 || ny_global < 1) return "domain size < 1";
+  if (block_size_x < 1 || block_size_y < 1) return "block size < 1";
+  if (nranks_ < 1 || rank_ < 0 || rank_ >= nranks_) return "rank out of range";
+  if (!owner_in) return "NULL block map";
+  nxg = nx_global; nyg = ny_global; bsx = block_size_x; bsy = block_size_y;
+  nbx = (nxg - 1) / bsx + 1;
+  nby = (nyg - 1) / bsy + 1;
+  npx = nranks_; npy = 1; nranks = nranks_; rank = rank_;
+  ew = ew_bnd; ns = ns_bnd;
+  const size_t nb = (size_t)nbx * nby;
+  std::vector<int> owner(owner_in, owner_in + nb), lid(nb, -1), nlocal(nranks, 0);
+  for (size_t g = 0; g < nb; ++g) {
+    if (owner[g] < -1 || owner[g] >= nranks) return "block map: owner out of range";
+    if (owner[g] < 0) continue;
+    lid[g] = lid_in ? lid_in[g] : nlocal[owner[g]];
+    nlocal[owner[g]]++;
+  }
+  for (size_t g = 0; g < nb; ++g)   // local ids of a rank must be a permutation of 0 .. n-1
+    if (owner[g] >= 0 && (lid[g] < 0 || lid[g] >= nlocal[owner[g]])) return "block map: local id out of range";
+  return build(owner, lid);
+}
+
+const char* Domain::build(const std::vector<int>& owner, const std::vector<int>& lid) {
+  nx_block = bsx + 2; ny_block = bsy + 2;
+  if (ew < 0 || ew > BND_CLOSED) return "east-west boundary must be open, cyclic or closed";
+  if (ns < 0 || ns > BND_TRIPOLE) return "unknown north-south boundary";
+  if (ns == BND_TRIPOLE) {
+    if (ew != BND_CYCLIC) return "a tripole north boundary needs a cyclic east-west boundary";
+    if (nxg % 2) return "a tripole north boundary needs an even nx_global";
+    if (nyg - (nby - 1) * bsy < 2 && nby > 1) return "tripole: the top block row needs two physical rows";
+    if (nyg < 2) return "tripole: fewer than two rows";
+  }
+  all.clear(); local.clear(); hsrc.clear(); hdst.clear(); hfill.clear(); send.clear(); recv.clear();
+  rsrc.clear(); rdst.clear(); overlap = 0;
+  fold = false; fold_lsrc.clear(); fold_bidx.clear(); fold_send.clear(); fold_recv.clear();
+  for (int l = 0; l < 4; ++l) {
+    fold_out[l].dst.clear(); fold_out[l].src.clear(); fold_lo[l].clear(); fold_hi[l].clear();
+  }
+
   for (int jb = 0; jb < nby; ++jb)
     for (int ib = 0; ib < nbx; ++ib) {
       Block b;
@@ -41,37 +92,46 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
       b.ilo = 2; b.jlo = 2;
       b.ihi = 1 + std::min(bsx, nxg - b.i0);  // padded last block: ice_blocks.F90:171-178
       b.jhi = 1 + std::min(bsy, nyg - b.j0);
-      // contiguous rectangles of blocks per rank, dealt the way create_distrb_cart does
-      // (ice_distribution.F90:719-732): ceil(nblocks / nprocs) block columns (rows) per process
-      // column (row), the last ones taking what is left -- possibly nothing
-      const int per_x = (nbx - 1) / npx + 1, per_y = (nby - 1) / npy + 1;
-      const int px = ib / per_x, py = jb / per_y;
-      b.owner = py * npx + px;
-      b.local_id = nlocal[b.owner]++;
+      b.owner = owner[b.gid];
+      b.local_id = lid[b.gid];
       b.own_jlo = b.jlo; b.own_jhi = b.jhi;
       all.push_back(b);
     }
-  for (const Block& b : all)
-    if (b.owner == rank) local.push_back(b.gid);
+  {  // this rank's blocks in local-id order
+    std::vector<std::pair<int, int>> mine;
+    for (const Block& b : all)
+      if (b.owner == rank) mine.push_back({b.local_id, b.gid});
+    std::sort(mine.begin(), mine.end());
+    for (size_t k = 0; k < mine.size(); ++k) {
+      if (mine[k].first != (int)k) return "block map: local ids of this rank are not 0 .. n-1";
+      local.push_back(mine[k].second);
+    }
+  }
 
   const long long np = (long long)nx_block * ny_block;
   if (np * (long long)std::max<size_t>(local.size(), 1) > 0x7fffffffLL) return "local array too large for int32 addressing";
   auto addr = [&](const Block& b, int i, int j) {  // 1-based (i,j)
     return (int32_t)((long long)b.local_id * np + (long long)(j - 1) * nx_block + (i - 1));
   };
+  const int ns_wrap = (ns == BND_TRIPOLE) ? BND_OPEN : ns;   // south edge of a tripole grid is open (:246)
 
   std::map<int, HaloMsg> smap, rmap;
   // Visit every ghost cell of every block in one global order; both ends of a message
   // therefore agree on element order.
   for (const Block& d : all) {
+    if (d.owner < 0) continue;
     for (int j = d.jlo - 1; j <= d.jhi + 1; ++j)
       for (int i = d.ilo - 1; i <= d.ihi + 1; ++i) {
         const bool ghost = (i < d.ilo || i > d.ihi || j < d.jlo || j > d.jhi);
         if (!ghost) continue;
         int ig = wrap(d.i0 + (i - d.ilo), nxg, ew);
-        int jg = wrap(d.j0 + (j - d.jlo), nyg, ns);
-        if (ig < 0 || jg < 0) continue;  // beyond an open/closed edge: never written
+        int jg = wrap(d.j0 + (j - d.jlo), nyg, ns_wrap);
+        if (ig < 0 || jg < 0) continue;  // beyond an open/closed edge (or the fold, below): never written here
         const Block& s = all[(jg / bsy) * nbx + (ig / bsx)];
+        if (s.owner < 0) {               // eliminated land block: fill value
+          if (d.owner == rank) hfill.push_back(addr(d, i, j));
+          continue;
+        }
         int is = s.ilo + (ig - s.i0), js = s.jlo + (jg - s.j0);
         if (d.owner == rank && s.owner == rank && !(self_comm && s.gid != d.gid)) {
           hsrc.push_back(addr(s, is, js));
@@ -92,6 +152,66 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
   }
   for (auto& kv : smap) send.push_back(std::move(kv.second));
   for (auto& kv : rmap) recv.push_back(std::move(kv.second));
+
+  if (ns == BND_TRIPOLE) {
+    // ranks that own a block of the top block row each assemble the whole buffer
+    std::vector<char> top_rank(nranks, 0);
+    for (const Block& b : all)
+      if (b.jb == nby - 1 && b.owner >= 0) top_rank[b.owner] = 1;
+    fold = top_rank[rank] != 0;
+    std::map<int, HaloMsg> fs, fr;
+    for (const Block& s : all) {   // 1. top two physical rows of every top-row block -> buffer
+      if (s.jb != nby - 1 || s.owner < 0) continue;
+      for (int r = 0; r < 2; ++r)
+        for (int i = s.ilo; i <= s.ihi; ++i) {
+          const int32_t b = (int32_t)(r * nxg + s.i0 + (i - s.ilo));
+          const int j = s.jhi - 1 + r;
+          if (s.owner == rank) {
+            fold_lsrc.push_back(addr(s, i, j));
+            fold_bidx.push_back(b);
+            for (int p = 0; p < nranks; ++p)
+              if (p != rank && top_rank[p]) {
+                HaloMsg& m = fs[p]; m.peer = p; m.addr.push_back(addr(s, i, j));
+              }
+          } else if (fold) {
+            HaloMsg& m = fr[s.owner]; m.peer = s.owner; m.addr.push_back(b);
+          }
+        }
+    }
+    for (auto& kv : fs) fold_send.push_back(std::move(kv.second));
+    for (auto& kv : fr) fold_recv.push_back(std::move(kv.second));
+    if (fold) {
+      // 2. symmetry of the degenerate top row (serial/ice_boundary.F90:784-823); 1-based i as there
+      for (int i = 1; i <= nxg / 2 - 1; ++i) {
+        fold_lo[LOC_NECORNER - 1].push_back(nxg + i - 1);
+        fold_hi[LOC_NECORNER - 1].push_back(nxg + (nxg - i) - 1);
+      }
+      for (int i = 1; i <= nxg / 2; ++i) {
+        fold_lo[LOC_NFACE - 1].push_back(nxg + i - 1);
+        fold_hi[LOC_NFACE - 1].push_back(nxg + (nxg + 1 - i) - 1);
+      }
+      // 3. copy out (:3726-3750 list, :831-866 offsets): rows jhi (jj = 1) and jhi+1 (jj = 2) of every
+      // top-row block of this rank, columns 1 .. ihi+1
+      const int ioff[4] = {0, 1, 0, 1}, joff[4] = {0, 1, 1, 0};  // center, NE corner, N face, E face
+      for (int gid : local) {
+        const Block& d = all[gid];
+        if (d.jb != nby - 1) continue;
+        for (int jj = 1; jj <= 2; ++jj)
+          for (int i = 1; i <= d.ihi + 1; ++i) {
+            const int ig1 = ((d.i0 + (i - d.ilo)) % nxg + nxg) % nxg + 1;  // i_glob(i), cyclic
+            for (int l = 0; l < 4; ++l) {
+              int iSrc = nxg - ig1 + 1 - ioff[l];
+              const int jSrc = 4 - jj - joff[l];
+              if (iSrc == 0) iSrc = nxg;
+              if (iSrc > nxg) iSrc -= nxg;
+              if (jSrc > 2 || jSrc < 1) continue;
+              fold_out[l].dst.push_back(addr(d, i, d.jhi + jj - 1));
+              fold_out[l].src.push_back((int32_t)((jSrc - 1) * nxg + iSrc - 1));
+            }
+          }
+      }
+    }
+  }
   return "";
 }
 

@@ -1288,20 +1288,20 @@ void Evp::prepare(double dt) {
   a.mu_rdg = cfg.mu_rdg; a.counters = counters.p;
   const dim3 g = grid1(n), blk256(256);
   hipLaunchKernelGGL(k_prep1, g, blk256, 0, stream, a);                       // :214-244
-  halo.update_i4(icetmask.p, 1, n);                                           // :250-253
+  halo.update_i4(icetmask.p, 1, n, LOC_CENTER, KIND_SCALAR);                  // :250-253
   hipLaunchKernelGGL(k_to_ugrid2, g, blk256, 0, stream, a, (const double*)tmass.p,
                      (const double*)aice.p, umass.p, aiu.p);                  // :259-260
   // t2ugrid_vector(strairx), (strairy) :276-277 = copy, halo update, to_ugrid
   CICE_HIP(hipMemcpyAsync(work1.p, strairx.p, n * 8, hipMemcpyDeviceToDevice, stream));
   CICE_HIP(hipMemcpyAsync(work1.p + n, strairy.p, n * 8, hipMemcpyDeviceToDevice, stream));
-  halo.update_r8(work1.p, 2, n);
+  halo.update_r8(work1.p, 2, n, true, LOC_CENTER, KIND_VECTOR);               // ice_grid.F90:1565
   hipLaunchKernelGGL(k_to_ugrid2, g, blk256, 0, stream, a, (const double*)work1.p,
                      (const double*)(work1.p + n), strairx.p, strairy.p);
   hipLaunchKernelGGL(k_prep2, g, blk256, 0, stream, a);                       // :280-316
   hipLaunchKernelGGL(k_strength, g, blk256, 0, stream, a);                    // :322-332
-  halo.update_r8(strength.p, 1, n);                                           // :337
+  halo.update_r8(strength.p, 1, n, true, LOC_CENTER, KIND_SCALAR);            // :337
   if (dom.overlap > 0) halo.update_r8(st[cur].p, 14, n);   // overlap rows of u, v AND sigma from their owners
-  else halo.update_r8(uv[cur].p, 2, n);                                       // :340-343
+  else halo.update_r8(uv[cur].p, 2, n, true, LOC_NECORNER, KIND_VECTOR);      // :340-343
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
   CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
@@ -1410,8 +1410,8 @@ void Evp::after_subcycle(int ksub) {
   if (dom.overlap > 0) {
     if (ksub % dom.overlap == 0 || ksub == sc.ndte) halo.update_r8(st[cur].p, 14, n, /*wrap=*/!fwd);
     else if (!fwd) halo.update_r8(uv[cur].p, 2, n, true);
-  } else if (halo.has_refresh() || !fwd) {
-    halo.update_r8(uv[cur].p, 2, n, /*wrap=*/!fwd);
+  } else if (halo.has_refresh() || !fwd || halo.has_fold()) {
+    halo.update_r8(uv[cur].p, 2, n, /*wrap=*/!fwd, LOC_NECORNER, KIND_VECTOR);   // :397-402
   }
 }
 
@@ -1442,7 +1442,8 @@ bool Evp::can_fuse() const {
   if (!fuse_on || !halo.fwd_ok()) return false;
   if (dom.nbx != 1) return false;
   if (dom.overlap > 0) return dom.overlap % 2 == 0;
-  return dom.nby == 1 && dom.ns != BND_CYCLIC && !halo.has_refresh();
+  // a tripole fold rewrites the top row and its ghost row after every subcycle
+  return dom.nby == 1 && dom.ns != BND_CYCLIC && dom.ns != BND_TRIPOLE && !halo.has_refresh();
 }
 
 int Evp::fused_waves() const {
@@ -1588,7 +1589,7 @@ void Evp::finish() {
   // u2tgrid_vector :427-428 = copy, halo update (NE corner), to_tgrid
   CICE_HIP(hipMemcpyAsync(work1.p, strocnxT.p, n * 8, hipMemcpyDeviceToDevice, stream));
   CICE_HIP(hipMemcpyAsync(work1.p + n, strocnyT.p, n * 8, hipMemcpyDeviceToDevice, stream));
-  halo.update_r8(work1.p, 2, n);
+  halo.update_r8(work1.p, 2, n, true, LOC_NECORNER, KIND_VECTOR);             // ice_grid.F90:1669
   hipLaunchKernelGGL(k_to_tgrid2, g, blk256, 0, stream, a, (const double*)work1.p,
                      (const double*)(work1.p + n), strocnxT.p, strocnyT.p);
   CICE_HIP(hipGetLastError());

@@ -22,13 +22,20 @@ class Halo {
   // borrows it.
   void set_comm(ncclComm* c, int rank, int nranks);
   bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
-  bool has_refresh() const { return remote_ || nrefresh_ > 0; }
+  bool has_refresh() const { return remote_ || nrefresh_ > 0 || nfill_ > 0; }
   // nfields fields of element type T, field k starting at base + k*stride (elements).
   // Always performs the refresh part (on-rank block-to-block rows of a wide-halo domain and all
   // off-rank messages); wrap = false skips the every-subcycle on-rank list (hsrc/hdst) because
   // the caller -- the subcycle kernel -- has written those ghosts itself.
-  void update_r8(double* base, int nfields, size_t stride, bool wrap = true);
-  void update_i4(int32_t* base, int nfields, size_t stride);
+  // loc / kind (FieldLoc, FieldKind) and fill only matter on a tripole north boundary / next to eliminated
+  // land blocks (domain.h); the defaults are right for every other domain.
+  void update_r8(double* base, int nfields, size_t stride, bool wrap = true, int loc = LOC_CENTER,
+                 int kind = KIND_SCALAR, double fill = 0.0);
+  void update_i4(int32_t* base, int nfields, size_t stride, int loc = LOC_CENTER, int kind = KIND_SCALAR,
+                 int32_t fill = 0);
+  void update_r4(float* base, int nfields, size_t stride, int loc = LOC_CENTER, int kind = KIND_SCALAR,
+                 float fill = 0.0f);
+  bool has_fold() const { return fold_; }
   // Device pointers to the on-rank copy list, for kernels that fold it in.
   const int32_t* d_src() const { return src_.p; }
   const int32_t* d_dst() const { return dst_.p; }
@@ -44,13 +51,27 @@ class Halo {
 
  private:
   template <class T>
-  void update(T* base, int nfields, size_t stride, bool wrap);
+  void update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill);
+  template <class T>
+  void exchange(const T* src_base, size_t src_stride, T* dst_base, size_t dst_stride, int nfields,
+                const DevBuf<int32_t>& saddr, const std::vector<int>& speer, const std::vector<int>& soff,
+                const std::vector<int>& scnt, int ns, const DevBuf<int32_t>& raddr,
+                const std::vector<int>& rpeer, const std::vector<int>& roff, const std::vector<int>& rcnt, int nr);
   hipStream_t stream_ = nullptr;
   int ncopy_ = 0, nrefresh_ = 0, rank_ = 0, nranks_ = 1;
   bool fwd_ok_ = true, remote_ = false;
   DevBuf<int32_t> src_, dst_, rsrc_, rdst_, send_addr_, recv_addr_, ring_slot_, fwd_;
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;
+  // land-block fill list and tripole fold (domain.h)
+  int nfill_ = 0, nxg_ = 0, nfold_src_ = 0, nfold_out_[4] = {0, 0, 0, 0}, nfold_pair_[4] = {0, 0, 0, 0};
+  bool fold_ = false;
+  DevBuf<int32_t> fill_, fold_lsrc_, fold_bidx_, fold_send_addr_, fold_recv_addr_, fold_dst_[4], fold_src_[4],
+      fold_lo_[4], fold_hi_[4];
+  std::vector<int> fsend_peer_, fsend_off_, fsend_cnt_, frecv_peer_, frecv_off_, frecv_cnt_;
+  int nfsend_ = 0, nfrecv_ = 0, ftotal_s_ = 0, ftotal_r_ = 0;
+  DevBuf<double> foldbuf_;            // 2 * nx_global elements per field, grown like the message buffers
+  int fold_cap_ = 0;
   DevBuf<double> sendbuf_, recvbuf_;  // sized for cap_fields_ fields of 8-byte elements
   int cap_fields_ = 0, total_s_ = 0, total_r_ = 0, generation_ = 0;
   void reserve(int nfields);          // grows the message buffers (never shrinks)

@@ -2,7 +2,9 @@
 
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 namespace cice {
 
@@ -55,6 +57,65 @@ __global__ __launch_bounds__(256) void k_unpack(T* __restrict__ base, int nfield
   int off = meta[2 * m], cnt = meta[2 * m + 1];
   for (int k = 0; k < nfields; ++k)
     base[(size_t)k * stride + addr[e]] = buf[(size_t)nfields * off + (size_t)k * cnt + (e - off)];
+}
+
+// ghost cells that face an eliminated land block (mpi/ice_boundary.F90:5108-5111)
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_fill(T* __restrict__ base, int nfields, size_t stride,
+                                                   const int32_t* __restrict__ addr, int n, T fill) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * nfields) return;
+  int k = t / n, e = t - k * n;
+  base[(size_t)k * stride + addr[e]] = fill;
+}
+
+// ---- tripole fold (serial/ice_boundary.F90:705-869); buffer: nfields x (2 x nx_global) ----
+template <class T>
+__global__ __launch_bounds__(256) void k_fold_fill(T* __restrict__ buf, size_t n, T fill) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) buf[t] = fill;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_fold_gather(const T* __restrict__ base, int nfields, size_t stride,
+                                                     const int32_t* __restrict__ lsrc,
+                                                     const int32_t* __restrict__ bidx, int n,
+                                                     T* __restrict__ buf, int bstride) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * nfields) return;
+  int k = t / n, e = t - k * n;
+  buf[(size_t)k * bstride + bidx[e]] = base[(size_t)k * stride + lsrc[e]];
+}
+
+__device__ __forceinline__ double fold_avg(double x1, double x2, int sgn) { return 0.5 * (x1 + sgn * x2); }
+__device__ __forceinline__ float fold_avg(float x1, float x2, int sgn) { return 0.5f * (x1 + sgn * x2); }
+__device__ __forceinline__ int32_t fold_avg(int32_t x1, int32_t x2, int sgn) {
+  return (int32_t)round(0.5 * (double)(x1 + sgn * x2));   // nint(): halves away from zero
+}
+
+// "top row is degenerate, so must enforce symmetry": pairs are disjoint
+template <class T>
+__global__ __launch_bounds__(256) void k_fold_sym(T* __restrict__ buf, int nfields, int bstride,
+                                                  const int32_t* __restrict__ lo,
+                                                  const int32_t* __restrict__ hi, int n, int sgn) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * nfields) return;
+  int k = t / n, e = t - k * n;
+  T* b = buf + (size_t)k * bstride;
+  const T xavg = fold_avg(b[lo[e]], b[hi[e]], sgn);
+  b[lo[e]] = xavg;
+  b[hi[e]] = (T)sgn * xavg;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_fold_out(T* __restrict__ base, int nfields, size_t stride,
+                                                  const int32_t* __restrict__ dst,
+                                                  const int32_t* __restrict__ src, int n,
+                                                  const T* __restrict__ buf, int bstride, int sgn) {
+  int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * nfields) return;
+  int k = t / n, e = t - k * n;
+  base[(size_t)k * stride + dst[e]] = (T)sgn * buf[(size_t)k * bstride + src[e]];
 }
 
 }  // namespace
@@ -125,9 +186,27 @@ void Halo::init(const Domain& d, hipStream_t s) {
   };
   int ts = flatten(d.send, send_peer_, send_off_, send_cnt_, send_addr_, nsend_);
   int tr = flatten(d.recv, recv_peer_, recv_off_, recv_cnt_, recv_addr_, nrecv_);
-  remote_ = nsend_ > 0 || nrecv_ > 0;
-  total_s_ = ts;
-  total_r_ = tr;
+  ftotal_s_ = flatten(d.fold_send, fsend_peer_, fsend_off_, fsend_cnt_, fold_send_addr_, nfsend_);
+  ftotal_r_ = flatten(d.fold_recv, frecv_peer_, frecv_off_, frecv_cnt_, fold_recv_addr_, nfrecv_);
+  remote_ = nsend_ > 0 || nrecv_ > 0 || nfsend_ > 0 || nfrecv_ > 0;
+  total_s_ = std::max(ts, ftotal_s_);
+  total_r_ = std::max(tr, ftotal_r_);
+  auto put = [&](DevBuf<int32_t>& dev, const std::vector<int32_t>& h) {
+    dev.alloc(h.size());
+    if (!h.empty()) dev.upload(h.data(), s);
+    return (int)h.size();
+  };
+  nfill_ = put(fill_, d.hfill);
+  fold_ = d.fold;
+  nxg_ = d.nxg;
+  nfold_src_ = put(fold_lsrc_, d.fold_lsrc);
+  put(fold_bidx_, d.fold_bidx);
+  for (int l = 0; l < 4; ++l) {
+    nfold_out_[l] = put(fold_dst_[l], d.fold_out[l].dst);
+    put(fold_src_[l], d.fold_out[l].src);
+    nfold_pair_[l] = put(fold_lo_[l], d.fold_lo[l]);
+    put(fold_hi_[l], d.fold_hi[l]);
+  }
   reserve(MINF);
   CICE_HIP(hipStreamSynchronize(s));
 }
@@ -148,12 +227,44 @@ void Halo::set_comm(ncclComm* c, int rank, int nranks) {
   comm_ = c;
 }
 
+// pack -> grouped RCCL send/recv -> unpack for one set of message lists
 template <class T>
-void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
+void Halo::exchange(const T* src_base, size_t src_stride, T* dst_base, size_t dst_stride, int nfields,
+                    const DevBuf<int32_t>& saddr, const std::vector<int>& speer, const std::vector<int>& soff,
+                    const std::vector<int>& scnt, int ns, const DevBuf<int32_t>& raddr,
+                    const std::vector<int>& rpeer, const std::vector<int>& roff, const std::vector<int>& rcnt,
+                    int nr) {
+  const int total_s = ns ? soff.back() + scnt.back() : 0;
+  const int total_r = nr ? roff.back() + rcnt.back() : 0;
+  if (!total_s && !total_r) return;
+  CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
+  T* sb = reinterpret_cast<T*>(sendbuf_.p);
+  T* rb = reinterpret_cast<T*>(recvbuf_.p);
+  if (total_s) {
+    const int* meta = reinterpret_cast<const int*>(saddr.p + total_s);
+    hipLaunchKernelGGL(k_pack<T>, dim3((total_s + 255) / 256), dim3(256), 0, stream_, src_base, nfields,
+                       src_stride, saddr.p, total_s, sb, meta, ns);
+  }
+  const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : (std::is_same<T, float>::value ? ncclFloat : ncclInt32);
+  CICE_NCCL(ncclGroupStart());
+  for (int m = 0; m < nr; ++m)
+    CICE_NCCL(ncclRecv(rb + (size_t)nfields * roff[m], (size_t)nfields * rcnt[m], dt, rpeer[m],
+                       (ncclComm_t)comm_, stream_));
+  for (int m = 0; m < ns; ++m)
+    CICE_NCCL(ncclSend(sb + (size_t)nfields * soff[m], (size_t)nfields * scnt[m], dt, speer[m],
+                       (ncclComm_t)comm_, stream_));
+  CICE_NCCL(ncclGroupEnd());
+  if (total_r) {
+    const int* meta = reinterpret_cast<const int*>(raddr.p + total_r);
+    hipLaunchKernelGGL(k_unpack<T>, dim3((total_r + 255) / 256), dim3(256), 0, stream_, dst_base, nfields,
+                       dst_stride, raddr.p, total_r, reinterpret_cast<const T*>(recvbuf_.p), meta, nr);
+  }
+}
+
+template <class T>
+void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill) {
   CICE_REQUIRE(nfields >= 1, "halo: no field");
   if (remote_) reserve(nfields);    // any number of levels in one message per neighbour
-  const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
-  const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
   // The wrap list goes first: a wide-halo refresh copies whole rows INCLUDING their E/W ghost
   // columns, so the owner's ghost columns must be current before they are packed or copied.
   if (ncopy_ && wrap) {
@@ -161,7 +272,16 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
     hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, src_.p, dst_.p, ncopy_);
   }
-  if (remote_) {
+  if (nfill_) {
+    int t = nfill_ * nfields;
+    hipLaunchKernelGGL(k_halo_fill<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields, stride,
+                       fill_.p, nfill_, fill);
+  }
+  if (nsend_ || nrecv_) {
+    // sources are physical cells, destinations ghost cells: the on-rank refresh below may run between
+    // pack and unpack
+    const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
+    const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
     CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
     T* sb = reinterpret_cast<T*>(sendbuf_.p);
     T* rb = reinterpret_cast<T*>(recvbuf_.p);
@@ -170,7 +290,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
       hipLaunchKernelGGL(k_pack<T>, dim3((total_s + 255) / 256), dim3(256), 0, stream_, base, nfields,
                          stride, send_addr_.p, total_s, sb, meta, nsend_);
     }
-    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclInt32;
+    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : (std::is_same<T, float>::value ? ncclFloat : ncclInt32);
     CICE_NCCL(ncclGroupStart());
     for (int m = 0; m < nrecv_; ++m)
       CICE_NCCL(ncclRecv(rb + (size_t)nfields * recv_off_[m], (size_t)nfields * recv_cnt_[m], dt,
@@ -185,16 +305,63 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap) {
     hipLaunchKernelGGL(k_halo_copy<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, rsrc_.p, rdst_.p, nrefresh_);
   }
-  if (remote_ && total_r) {
+  if (nrecv_) {
+    const int total_r = recv_off_.back() + recv_cnt_.back();
     const int* meta = reinterpret_cast<const int*>(recv_addr_.p + total_r);
     hipLaunchKernelGGL(k_unpack<T>, dim3((total_r + 255) / 256), dim3(256), 0, stream_, base, nfields,
                        stride, recv_addr_.p, total_r, reinterpret_cast<const T*>(recvbuf_.p), meta,
                        nrecv_);
   }
+  if (fold_ || nfsend_) {   // tripole north boundary, after all regular copies (serial/ice_boundary.F90:705)
+    CICE_REQUIRE(loc >= LOC_CENTER && loc <= LOC_EFACE, "halo: field location unknown on a tripole grid");
+    CICE_REQUIRE(kind >= KIND_SCALAR && kind <= KIND_ANGLE, "halo: field kind unknown on a tripole grid");
+    const int sgn = kind == KIND_SCALAR ? 1 : -1;
+    const int bstride = 2 * nxg_;
+    T* buf = nullptr;
+    if (fold_) {
+      if (fold_cap_ < nfields) {
+        if (fold_cap_) CICE_HIP(hipStreamSynchronize(stream_));
+        foldbuf_.alloc((size_t)bstride * nfields);
+        fold_cap_ = nfields;
+        ++generation_;
+      }
+      buf = reinterpret_cast<T*>(foldbuf_.p);
+      const size_t nbuf = (size_t)bstride * nfields;
+      hipLaunchKernelGGL(k_fold_fill<T>, dim3((unsigned)((nbuf + 255) / 256)), dim3(256), 0, stream_, buf, nbuf, fill);
+      if (nfold_src_) {
+        int t = nfold_src_ * nfields;
+        hipLaunchKernelGGL(k_fold_gather<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, (const T*)base, nfields,
+                           stride, fold_lsrc_.p, fold_bidx_.p, nfold_src_, buf, bstride);
+      }
+    }
+    // top rows of the other ranks' top-row blocks: straight into the buffer
+    exchange<T>(base, stride, buf, (size_t)bstride, nfields, fold_send_addr_, fsend_peer_, fsend_off_, fsend_cnt_,
+                nfsend_, fold_recv_addr_, frecv_peer_, frecv_off_, frecv_cnt_, nfrecv_);
+    if (fold_) {
+      const int l = loc - 1;
+      if (nfold_pair_[l]) {
+        int t = nfold_pair_[l] * nfields;
+        hipLaunchKernelGGL(k_fold_sym<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, buf, nfields, bstride,
+                           fold_lo_[l].p, fold_hi_[l].p, nfold_pair_[l], sgn);
+      }
+      if (nfold_out_[l]) {
+        int t = nfold_out_[l] * nfields;
+        hipLaunchKernelGGL(k_fold_out<T>, dim3((t + 255) / 256), dim3(256), 0, stream_, base, nfields, stride,
+                           fold_dst_[l].p, fold_src_[l].p, nfold_out_[l], (const T*)buf, bstride, sgn);
+      }
+    }
+  }
   CICE_HIP(hipGetLastError());
 }
 
-void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap) { update<double>(base, nfields, stride, wrap); }
-void Halo::update_i4(int32_t* base, int nfields, size_t stride) { update<int32_t>(base, nfields, stride, true); }
+void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap, int loc, int kind, double fill) {
+  update<double>(base, nfields, stride, wrap, loc, kind, fill);
+}
+void Halo::update_i4(int32_t* base, int nfields, size_t stride, int loc, int kind, int32_t fill) {
+  update<int32_t>(base, nfields, stride, true, loc, kind, fill);
+}
+void Halo::update_r4(float* base, int nfields, size_t stride, int loc, int kind, float fill) {
+  update<float>(base, nfields, stride, true, loc, kind, fill);
+}
 
 }  // namespace cice

@@ -69,6 +69,15 @@ module cice4_amd_c
          integer(c_int), value :: nx_global, ny_global, block_size_x, block_size_y, ew_boundary, &
                                   ns_boundary, rank, npx, npy
       end function
+      integer(c_int) function cice_domain_create_map(ctx, nx_global, ny_global, block_size_x, &
+            block_size_y, ew_boundary, ns_boundary, rank, nranks, owner, local_id) &
+            bind(C, name='cice_domain_create_map')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_global, ny_global, block_size_x, block_size_y, ew_boundary, &
+                                  ns_boundary, rank, nranks
+         integer(c_int), intent(in) :: owner(*), local_id(*)
+      end function
       integer(c_int) function cice_domain_info(ctx, info) bind(C, name='cice_domain_info')
          import
          type(c_ptr), value :: ctx
@@ -91,6 +100,29 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          integer(c_int) :: field(*)
          integer(c_int), value :: nlev
+      end function
+      integer(c_int) function cice_halo_update_ex_r8(ctx, field, nlev, loc, kind, fill) &
+            bind(C, name='cice_halo_update_ex_r8')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double) :: field(*)
+         integer(c_int), value :: nlev, loc, kind
+         real(c_double), value :: fill
+      end function
+      integer(c_int) function cice_halo_update_ex_r4(ctx, field, nlev, loc, kind, fill) &
+            bind(C, name='cice_halo_update_ex_r4')
+         import
+         type(c_ptr), value :: ctx
+         real(c_float) :: field(*)
+         integer(c_int), value :: nlev, loc, kind
+         real(c_float), value :: fill
+      end function
+      integer(c_int) function cice_halo_update_ex_i4(ctx, field, nlev, loc, kind, fill) &
+            bind(C, name='cice_halo_update_ex_i4')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int) :: field(*)
+         integer(c_int), value :: nlev, loc, kind, fill
       end function
       integer(c_int) function cice_comm_unique_id(uid) bind(C, name='cice_comm_unique_id')
          import

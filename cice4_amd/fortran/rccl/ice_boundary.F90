@@ -10,11 +10,13 @@
 ! MPI builds (-DCICE4_AMD_MPI, with the reference's mpi/ice_communicate.F90): ice_HaloCreate also sets up
 ! the RCCL communicator (id broadcast over MPI_COMM_ICE); off-rank ghost cells then travel by RCCL.
 !
-! Scope: ghost width 1, cyclic / open / closed edges, cartesian block distribution without
-! land-block elimination (SURVEY.md section 8f).  Tripole grids stop with a message.
+! Scope: ghost width 1; cyclic / open / closed edges and the 'tripole' (U-fold) north boundary
+! (serial/ice_boundary.F90:705-869: fieldLoc / fieldKind decide offsets and sign at the fold); ANY
+! block distribution create_distribution produced, land-block elimination included -- the block->task
+! map is handed to the device as it is, ghost cells facing an eliminated block take fillValue
+! (mpi/ice_boundary.F90:5108-5111).  'tripoleT' stops with a message.
 ! Ghost cells beyond an open or closed edge are left untouched, which is what the reference
-! does for them (mpi/ice_boundary.F90: messages to a non-existent neighbour are never
-! created), so the fillValue / fieldLoc / fieldKind arguments have no effect here.
+! does for them (mpi/ice_boundary.F90: messages to a non-existent neighbour are never created).
 !
 ! This generic entry point moves the host field to the device and back on every call: it
 ! is the functional drop-in for the model's set-up and state updates (ice_grid.F90,
@@ -28,9 +30,9 @@ module ice_boundary
    use ice_communicate, only: my_task
    use ice_fileunits, only: nu_diag
    use ice_domain_size, only: nx_global, ny_global, block_size_x, block_size_y
-   use ice_blocks, only: nx_block, ny_block, nghost, nblocks_x, nblocks_y, block, get_block
+   use ice_blocks, only: nx_block, ny_block, nghost, nblocks_x, nblocks_y, nblocks_tot, block, get_block
    use ice_distribution, only: distrb, ice_distributionGet, ice_distributionGetBlockLoc, &
-                               ice_distributionGetBlockID, nprocsX, nprocsY
+                               ice_distributionGetBlockID
    use ice_exit, only: abort_ice
    use cice4_amd_c
 
@@ -41,7 +43,7 @@ module ice_boundary
    type, public :: ice_halo
       integer (int_kind) :: communicator   ! kept for source compatibility (unused)
       integer (int_kind) :: numBlocks      ! local blocks the device domain was built for
-      integer (int_kind) :: ewBnd, nsBnd   ! 0 open, 1 cyclic, 2 closed
+      integer (int_kind) :: ewBnd, nsBnd   ! 0 open, 1 cyclic, 2 closed, 3 tripole (north-south only)
    end type
 
    public :: ice_HaloCreate, ice_HaloUpdate, ice_HaloExtrapolate
@@ -67,38 +69,32 @@ contains
       integer (int_kind), intent(in) :: nxGlobal
       type (ice_halo) :: halo
 
-      integer (int_kind) :: nprocs, numBlocks, npx, npy, ib, proc, lid, last, n, gid
+      integer (int_kind) :: nprocs, numBlocks, proc, lid, n, gid
       integer (c_int) :: info(9), binfo(10)
+      integer (c_int), allocatable :: owner(:), local_id(:)
 
       if (nghost /= 1) call abort_ice('ice_HaloCreate: the GPU path needs nghost = 1')
       if (nxGlobal /= nx_global) call abort_ice('ice_HaloCreate: nxGlobal /= nx_global')
       halo%ewBnd = boundary_code(ewBoundaryType)
       halo%nsBnd = boundary_code(nsBoundaryType)
+      if (halo%ewBnd == 3) call abort_ice('ice_HaloCreate: tripole is a north-south boundary type')
 
       call ice_distributionGet(dist, nprocs=nprocs, communicator=halo%communicator, &
                                numLocalBlocks=numBlocks)
-      ! process grid of the cartesian distribution (set by create_distrb_cart, ice_distribution.F90:701)
-      npx = nprocsX; npy = nprocsY
-      if (npx < 1 .or. npy < 1 .or. npx*npy /= nprocs) then
-         ! not set (another distribution type): distinct owners along the first block row
-         npx = 0; last = -1
-         do ib = 1, nblocks_x
-            call ice_distributionGetBlockLoc(dist, ib, proc, lid)
-            if (proc /= last) npx = npx + 1
-            last = proc
-         enddo
-         if (mod(nprocs, npx) /= 0) call abort_ice('ice_HaloCreate: distribution is not cartesian')
-         npy = nprocs/npx
-      endif
-      do ib = 1, nblocks_x
-         call ice_distributionGetBlockLoc(dist, ib, proc, lid)
-         if (proc == 0) call abort_ice('ice_HaloCreate: land-block elimination is not supported')
+      ! the block -> task map exactly as create_distribution made it (cartesian, rake, space curve;
+      ! proc = 0: eliminated land block), global block n = (jblock-1)*nblocks_x + iblock
+      allocate(owner(nblocks_tot), local_id(nblocks_tot))
+      do n = 1, nblocks_tot
+         call ice_distributionGetBlockLoc(dist, n, proc, lid)
+         owner(n) = proc - 1
+         local_id(n) = lid - 1
       enddo
 
       ! one task = one GPU: task t takes device mod(t, visible devices)
       call cice_gpu_ensure(mod(my_task, max(1, cice_device_count())))
-      call cice_gpu_check(cice_domain_create(cice_gpu_ctx, nx_global, ny_global, block_size_x, &
-           block_size_y, halo%ewBnd, halo%nsBnd, my_task, npx, npy), 'cice_domain_create')
+      call cice_gpu_check(cice_domain_create_map(cice_gpu_ctx, nx_global, ny_global, block_size_x, &
+           block_size_y, halo%ewBnd, halo%nsBnd, my_task, nprocs, owner, local_id), 'cice_domain_create_map')
+      deallocate(owner, local_id)
       call cice_gpu_check(cice_domain_info(cice_gpu_ctx, info), 'cice_domain_info')
       if (info(1) /= nx_block .or. info(2) /= ny_block .or. info(3) /= numBlocks) then
          write(nu_diag,*) 'ice_HaloCreate: device layout', info(1:3), ' host layout', &
@@ -111,7 +107,7 @@ contains
          if (binfo(7) + 1 /= gid) then
             write(nu_diag,*) 'ice_HaloCreate: local block', n, ' is global block', gid, &
                              ' on the host but', binfo(7) + 1, ' on the device'
-            call abort_ice('ice_HaloCreate: block distribution is not the cartesian one')
+            call abort_ice('ice_HaloCreate: device block order differs from the host order')
          endif
       enddo
       halo%numBlocks = numBlocks
@@ -128,6 +124,7 @@ contains
       case ('open');   boundary_code = 0
       case ('cyclic'); boundary_code = 1
       case ('closed'); boundary_code = 2
+      case ('tripole'); boundary_code = 3
       case default
          call abort_ice('ice_HaloCreate: boundary type not supported on the GPU path: '//trim(name))
       end select
@@ -135,24 +132,46 @@ contains
 
 !=======================================================================
 ! Workers: nlev horizontal slabs in the device layout (nx_block,ny_block,nblocks,nlev).
-   subroutine update_levels_r8(buf, nblk, nlev, halo, who)
-      integer (int_kind), intent(in) :: nblk, nlev
+   subroutine update_levels_r8(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
       real (dbl_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
       type (ice_halo), intent(in) :: halo
       character (*), intent(in) :: who
+      real (dbl_kind), intent(in), optional :: fillValue
+      real (c_double) :: fill
       if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
       if (nlev < 1) return
-      call cice_gpu_check(cice_halo_update_r8(cice_gpu_ctx, buf, nlev), who)
+      fill = 0.0_c_double
+      if (present(fillValue)) fill = fillValue
+      call cice_gpu_check(cice_halo_update_ex_r8(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
    end subroutine update_levels_r8
 
-   subroutine update_levels_i4(buf, nblk, nlev, halo, who)
-      integer (int_kind), intent(in) :: nblk, nlev
+   subroutine update_levels_r4(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
+      real (real_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+      type (ice_halo), intent(in) :: halo
+      character (*), intent(in) :: who
+      real (real_kind), intent(in), optional :: fillValue
+      real (c_float) :: fill
+      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
+      if (nlev < 1) return
+      fill = 0.0_c_float
+      if (present(fillValue)) fill = fillValue
+      call cice_gpu_check(cice_halo_update_ex_r4(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
+   end subroutine update_levels_r4
+
+   subroutine update_levels_i4(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
       integer (int_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
       type (ice_halo), intent(in) :: halo
       character (*), intent(in) :: who
+      integer (int_kind), intent(in), optional :: fillValue
+      integer (c_int) :: fill
       if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
       if (nlev < 1) return
-      call cice_gpu_check(cice_halo_update_i4(cice_gpu_ctx, buf, nlev), who)
+      fill = 0
+      if (present(fillValue)) fill = fillValue
+      call cice_gpu_check(cice_halo_update_ex_i4(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
    end subroutine update_levels_i4
 
    ! arrays are dimensioned max_blocks in their last dimension; this task's blocks are the first numBlocks
@@ -184,7 +203,7 @@ contains
       nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR8')
       allocate(buf(nx_block,ny_block,nb,1))
       buf(:,:,:,1) = array(:,:,1:nb)
-      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR8')
+      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR8', fieldLoc, fieldKind, fillValue)
       array(:,:,1:nb) = buf(:,:,:,1)
    end subroutine ice_HaloUpdate2DR8
 
@@ -193,14 +212,14 @@ contains
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      real (real_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR4')
       nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR4')
       allocate(buf(nx_block,ny_block,nb,1))
-      buf(:,:,:,1) = real(array(:,:,1:nb), dbl_kind)          ! exact; the update only copies
-      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR4')
-      array(:,:,1:nb) = real(buf(:,:,:,1), real_kind)
+      buf(:,:,:,1) = array(:,:,1:nb)
+      call update_levels_r4(buf, nb, 1, halo, 'ice_HaloUpdate2DR4', fieldLoc, fieldKind, fillValue)
+      array(:,:,1:nb) = buf(:,:,:,1)
    end subroutine ice_HaloUpdate2DR4
 
    subroutine ice_HaloUpdate2DI4(array, halo, fieldLoc, fieldKind, fillValue)
@@ -214,7 +233,7 @@ contains
       nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DI4')
       allocate(buf(nx_block,ny_block,nb,1))
       buf(:,:,:,1) = array(:,:,1:nb)
-      call update_levels_i4(buf, nb, 1, halo, 'ice_HaloUpdate2DI4')
+      call update_levels_i4(buf, nb, 1, halo, 'ice_HaloUpdate2DI4', fieldLoc, fieldKind, fillValue)
       array(:,:,1:nb) = buf(:,:,:,1)
    end subroutine ice_HaloUpdate2DI4
 
@@ -235,7 +254,7 @@ contains
          buf(:,:,n,k) = array(:,:,k,n)
       enddo
       enddo
-      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR8')
+      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR8', fieldLoc, fieldKind, fillValue)
       do k = 1, nz
       do n = 1, nb
          array(:,:,k,n) = buf(:,:,n,k)
@@ -248,20 +267,20 @@ contains
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      real (real_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, n, nz, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR4')
       nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DR4')
       allocate(buf(nx_block,ny_block,nb,nz))
       do k = 1, nz
       do n = 1, nb
-         buf(:,:,n,k) = real(array(:,:,k,n), dbl_kind)
+         buf(:,:,n,k) = array(:,:,k,n)
       enddo
       enddo
-      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR4')
+      call update_levels_r4(buf, nb, nz, halo, 'ice_HaloUpdate3DR4', fieldLoc, fieldKind, fillValue)
       do k = 1, nz
       do n = 1, nb
-         array(:,:,k,n) = real(buf(:,:,n,k), real_kind)
+         array(:,:,k,n) = buf(:,:,n,k)
       enddo
       enddo
    end subroutine ice_HaloUpdate3DR4
@@ -281,7 +300,7 @@ contains
          buf(:,:,n,k) = array(:,:,k,n)
       enddo
       enddo
-      call update_levels_i4(buf, nb, nz, halo, 'ice_HaloUpdate3DI4')
+      call update_levels_i4(buf, nb, nz, halo, 'ice_HaloUpdate3DI4', fieldLoc, fieldKind, fillValue)
       do k = 1, nz
       do n = 1, nb
          array(:,:,k,n) = buf(:,:,n,k)
@@ -308,7 +327,7 @@ contains
       enddo
       enddo
       enddo
-      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR8')
+      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR8', fieldLoc, fieldKind, fillValue)
       do l = 1, nt
       do k = 1, nz
       do n = 1, nb
@@ -323,7 +342,7 @@ contains
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
+      real (real_kind), allocatable :: buf(:,:,:,:)
       integer (int_kind) :: k, l, n, nz, nt, nb
       call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR4')
       nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DR4')
@@ -331,15 +350,15 @@ contains
       do l = 1, nt
       do k = 1, nz
       do n = 1, nb
-         buf(:,:,n,(l-1)*nz+k) = real(array(:,:,k,l,n), dbl_kind)
+         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
       enddo
       enddo
       enddo
-      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR4')
+      call update_levels_r4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR4', fieldLoc, fieldKind, fillValue)
       do l = 1, nt
       do k = 1, nz
       do n = 1, nb
-         array(:,:,k,l,n) = real(buf(:,:,n,(l-1)*nz+k), real_kind)
+         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
       enddo
       enddo
       enddo
@@ -362,7 +381,7 @@ contains
       enddo
       enddo
       enddo
-      call update_levels_i4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DI4')
+      call update_levels_i4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DI4', fieldLoc, fieldKind, fillValue)
       do l = 1, nt
       do k = 1, nz
       do n = 1, nb

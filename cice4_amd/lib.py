@@ -158,6 +158,28 @@ class Context:
                           nxg=nxg, nyg=nyg)
         return self.domain()
 
+    def domain_create_map(self, nxg, nyg, bsx, bsy, owner, ew=1, ns=0, rank=0, nranks=1, local_id=None):
+        """Any block->task map; owner[g] = rank or -1 (eliminated land block)."""
+        owner = np.ascontiguousarray(owner, np.int32)
+        lid = None if local_id is None else np.ascontiguousarray(local_id, np.int32)
+        self._ck(self.lib.cice_domain_create_map(self.h, nxg, nyg, bsx, bsy, ew, ns, rank, nranks, _i4(owner),
+                                                 None if lid is None else _i4(lid)))
+        info = (C.c_int * 9)()
+        self._ck(self.lib.cice_domain_info(self.h, info))
+        self.nx, self.ny, self.nblocks = info[0], info[1], info[2]
+        self.dinfo = dict(nx=info[0], ny=info[1], nblocks=info[2], nblocks_tot=info[3], ncopy=info[4],
+                          nsend=info[5], nrecv=info[6], nsend_elems=info[7], nrecv_elems=info[8],
+                          nxg=nxg, nyg=nyg)
+        return self.domain()
+
+    def domain_list(self, name, loc=1):
+        n = C.c_int(0)
+        self._ck(self.lib.cice_domain_list(self.h, name.encode(), loc, C.byref(n), None))
+        out = np.zeros(n.value, np.int32)
+        if n.value:
+            self._ck(self.lib.cice_domain_list(self.h, name.encode(), loc, C.byref(n), _i4(out)))
+        return out
+
     def domain_create_slabs(self, nxg, nyg, nblocks_y, ew=1, ns=0, rank=0, nranks=1, overlap=0):
         """j-slabs of full width, optionally extended by `overlap` rows (wide halo)."""
         self._ck(self.lib.cice_domain_create_slabs(self.h, nxg, nyg, nblocks_y, ew, ns, rank, nranks, overlap))
@@ -189,7 +211,35 @@ class Context:
         if nr.value:
             self._ck(self.lib.cice_domain_halo_refresh(self.h, C.byref(nr), _i4(rs), _i4(rd)))
         d["rsrc"], d["rdst"] = rs, rd
+        d["hfill"] = self.domain_list("hfill")
         return d
+
+    def apply_halo_lists(self, a, loc=1, kind=1, fill=0):
+        """The halo update the device performs, in numpy on a host array (nlev?, nblocks, ny, nx) -- for CPU tests of
+        the lists: on-rank copies, fill of ghost cells facing eliminated blocks, tripole fold (single-rank domains)."""
+        d = self.domain()
+        n = self.nblocks * self.ny * self.nx
+        v = a.reshape(-1, n)
+        v[:, d["hdst"]] = v[:, d["hsrc"]]
+        if len(d["hfill"]):
+            v[:, d["hfill"]] = fill
+        lsrc, bidx = self.domain_list("fold_lsrc"), self.domain_list("fold_bidx")
+        if len(lsrc):
+            sgn = 1 if kind == 1 else -1
+            buf = np.full((v.shape[0], 2 * self.dinfo["nxg"]), fill, a.dtype)
+            buf[:, bidx] = v[:, lsrc]
+            lo, hi = self.domain_list("fold_lo", loc), self.domain_list("fold_hi", loc)
+            if len(lo):
+                if a.dtype == np.int32:   # nint(0.5_dbl_kind*(x1 + isign*x2)), halves away from zero
+                    t = 0.5 * (buf[:, lo] + sgn * buf[:, hi]).astype(np.float64)
+                    x = (np.sign(t) * np.floor(np.abs(t) + 0.5)).astype(np.int32)
+                else:
+                    x = (a.dtype.type(0.5) * (buf[:, lo] + a.dtype.type(sgn) * buf[:, hi])).astype(a.dtype)
+                buf[:, lo] = x
+                buf[:, hi] = a.dtype.type(sgn) * x
+            dst, src = self.domain_list("fold_dst", loc), self.domain_list("fold_src", loc)
+            v[:, dst] = a.dtype.type(sgn) * buf[:, src]
+        return a
 
     def halo_msgs(self, direction):
         out = []
@@ -298,14 +348,20 @@ class Context:
             _f8(waterx), _f8(watery), _f8(forcex), _f8(forcey), _f8(umassdtei), _f8(fm), _f8(uarear),
             _f8(strocnx), _f8(strocny), _f8(strintx), _f8(strinty), _f8(uvel), _f8(vvel)))
 
-    def halo_update(self, field):
-        """field: (nlev?, nblocks, ny, nx) float64 or int32, updated in place."""
+    def halo_update(self, field, loc=1, kind=1, fill=0):
+        """field: (nlev?, nblocks, ny, nx) float64 / float32 / int32, updated in place.  loc / kind: field location
+        and type codes of ice_HaloUpdate (tripole fold); fill: value for ghost cells facing eliminated blocks."""
         n = self.nblocks * self.ny * self.nx
         nlev = field.size // n
+        assert field.flags["C_CONTIGUOUS"]
+        p = field.ctypes.data_as(C.c_void_p)
         if field.dtype == np.float64:
-            self._ck(self.lib.cice_halo_update_r8(self.h, _f8(field), nlev))
+            self._ck(self.lib.cice_halo_update_ex_r8(self.h, p, nlev, loc, kind, C.c_double(fill)))
+        elif field.dtype == np.float32:
+            self._ck(self.lib.cice_halo_update_ex_r4(self.h, p, nlev, loc, kind, C.c_float(fill)))
         else:
-            self._ck(self.lib.cice_halo_update_i4(self.h, _i4(field), nlev))
+            assert field.dtype == np.int32
+            self._ck(self.lib.cice_halo_update_ex_i4(self.h, p, nlev, loc, kind, C.c_int32(int(fill))))
 
     def halo_update_resident(self, field):
         """The same on a field kept in device memory: upload once, update through cice_halo_update_dev_r8/_i4

@@ -65,12 +65,24 @@ int cice_diag_stream_copy(cice_ctx *ctx, long long n_doubles, float *elapsed_ms)
 
 /* ---- domain: replaces init_domain_blocks + init_domain_distribution +
  * ice_HaloCreate (source/ice_domain.F90:96,258; mpi/ice_boundary.F90:153).
- * Host logic only -- usable without a GPU. boundary: 0 open, 1 cyclic, 2 closed.
+ * Host logic only -- usable without a GPU. boundary: 0 open, 1 cyclic, 2 closed; ns_boundary also 3 =
+ * 'tripole' (U-fold, source/ice_blocks.F90:457-467; needs a cyclic e-w boundary and an even nx_global).
  * Blocks are dealt to an (npx x npy) process grid in contiguous rectangles
  * (cartesian distribution, source/ice_distribution.F90:78). */
 int cice_domain_create(cice_ctx *ctx, int nx_global, int ny_global, int block_size_x,
                        int block_size_y, int ew_boundary, int ns_boundary, int rank, int npx,
                        int npy);
+/* The same for ANY block->task map (what create_distribution produced: cartesian, rake, space curve --
+ * source/ice_distribution.F90:78-190 -- with land-block elimination): owner[g] = task of global block g
+ * (g = jblock * nblocks_x + iblock, 0-based) or -1 for an eliminated block, local_id[g] = its 0-based position
+ * among that task's blocks (NULL: ascending g).  Ghost cells facing an eliminated block take the fill value. */
+int cice_domain_create_map(cice_ctx *ctx, int nx_global, int ny_global, int block_size_x,
+                           int block_size_y, int ew_boundary, int ns_boundary, int rank, int nranks,
+                           const int *owner, const int *local_id);
+/* Host copy of one index list of the domain: "hfill" (ghost cells facing eliminated blocks), and the tripole
+ * lists "fold_lsrc"/"fold_bidx" (local top rows -> global buffer), "fold_lo"/"fold_hi" (symmetry pairs),
+ * "fold_dst"/"fold_src" (copy out) for field location loc (1..4).  *n = length; out may be NULL. */
+int cice_domain_list(const cice_ctx *ctx, const char *name, int loc, int *n, int32_t *out);
 /* Wide-halo variant for j-slab decompositions (strong scaling over GPUs): nblocks_y slabs of
  * full width dealt to nranks ranks in contiguous runs; every slab is extended by `overlap`
  * rows into its neighbours.  The overlap rows are recomputed redundantly by the subcycle kernel
@@ -205,6 +217,14 @@ int cice_halo_update_i4(cice_ctx *ctx, int32_t *field, int nlev);
  * nlev planes of nx_block*ny_block*nblocks elements; asynchronous on the library's stream (cice_device_sync). */
 int cice_halo_update_dev_r8(cice_ctx *ctx, double *dev_field, int nlev);
 int cice_halo_update_dev_i4(cice_ctx *ctx, int32_t *dev_field, int nlev);
+/* With the field location and kind of ice_HaloUpdate (ice_constants.F90:185-205: 1 center, 2 NE corner, 3 N face,
+ * 4 E face; 1 scalar, 2 vector, 3 angle) -- they set offsets and sign at a tripole fold
+ * (serial/ice_boundary.F90:705-869) -- and its fillValue for ghost cells that face an eliminated land block
+ * (mpi/ice_boundary.F90:5108-5111).  R4 fields are handled in single precision as the reference does. */
+int cice_halo_update_ex_r8(cice_ctx *ctx, double *field, int nlev, int loc, int kind, double fill);
+int cice_halo_update_ex_r4(cice_ctx *ctx, float *field, int nlev, int loc, int kind, float fill);
+int cice_halo_update_ex_i4(cice_ctx *ctx, int32_t *field, int nlev, int loc, int kind, int32_t fill);
+int cice_halo_update_dev_ex_r8(cice_ctx *ctx, double *dev_field, int nlev, int loc, int kind, double fill);
 /* Device memory on the context's GPU for such resident fields, and blocking copies ordered on the library's stream. */
 int cice_device_alloc(cice_ctx *ctx, size_t bytes, void **dev);
 int cice_device_free(cice_ctx *ctx, void *dev);

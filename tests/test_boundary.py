@@ -12,7 +12,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # edge, ice_domain.F90:313-347); for ghost copies the reference treats 'closed' exactly like 'open'
 # (no neighbour: ice_blocks.F90:455-458,482-485,504-507,522-525), which is what 'open' covers here.
 CASES = [("gx3b4", "cyclic", "open"), ("pad", "cyclic", "open"), ("pad", "open", "open"),
-         ("pad", "open", "cyclic"), ("pad", "cyclic", "cyclic"), ("padx", "cyclic", "open")]   # padx: max_blocks > blocks
+         ("pad", "open", "cyclic"), ("pad", "cyclic", "cyclic"), ("padx", "cyclic", "open"),   # padx: max_blocks > blocks
+         # tripole (U-fold) north boundary, serial/ice_boundary.F90:705-869: every field location x kind x type
+         ("small", "cyclic", "tripole"), ("pad", "cyclic", "tripole"),
+         # land-block elimination on the reference's own gx3 grid and land mask: 10 x 12 blocks, the 4 all-land ones dropped by
+         # create_distribution; ghost cells facing them take the fill value (mpi/ice_boundary.F90:5108-5111)
+         ("gx3e", "cyclic", "open", "gx3")]
 
 
 def run_case(mode, cfg, ew, ns, *extra):
@@ -26,16 +31,16 @@ def run_case(mode, cfg, ew, ns, *extra):
     assert p.returncode == 0 and "BOUNDARY-OK" in p.stdout, p.stdout[-2000:] + p.stderr[-4000:]
 
 
-@pytest.mark.parametrize("cfg,ew,ns", CASES)
-def test_halo_lists_equal_reference_update(cfg, ew, ns):
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(c))
+def test_halo_lists_equal_reference_update(case):
     """Host topology (cice4_amd/csrc/domain.cpp) == serial/ice_boundary.F90 for padded blocks and
     every boundary type the path supports."""
-    run_case("lists", cfg, ew, ns)
+    run_case("lists", *case)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,ew,ns", CASES)
-def test_boundary_module_dropin(cfg, ew, ns):
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "-".join(c))
+def test_boundary_module_dropin(case):
     """The reference's callers (ice_domain, ice_grid, ice_state) linked with our ice_boundary
     module, ghost cells filled on the MI355X: same grid, same updates, bit for bit."""
-    run_case("gpu", cfg, ew, ns)
+    run_case("gpu", *case)
