@@ -355,7 +355,11 @@ int cice_domain_halo_local(const cice_ctx* ctx, int32_t* src, int32_t* dst) {
 
 int cice_domain_halo_msg(const cice_ctx* ctx, int dir, int msg, int* peer, int* count, int32_t* addr) {
   if (!ctx || !ctx->have_domain) return CICE_EINVAL;
-  const std::vector<HaloMsg>& v = dir ? ctx->dom.recv : ctx->dom.send;
+  // dir 0 / 1: ghost-cell messages (send / receive); 2 / 3: tripole top rows into the global buffer
+  // (send: local addresses, receive: buffer indices)
+  if (dir < 0 || dir > 3) return CICE_EINVAL;
+  const std::vector<HaloMsg>& v = dir == 0 ? ctx->dom.send : dir == 1 ? ctx->dom.recv
+                                  : dir == 2 ? ctx->dom.fold_send : ctx->dom.fold_recv;
   if (msg < 0 || msg >= (int)v.size()) return CICE_EINVAL;
   if (peer) *peer = v[msg].peer;
   if (count) *count = (int)v[msg].addr.size();

@@ -242,11 +242,15 @@ class Context:
         return a
 
     def halo_msgs(self, direction):
+        """direction 0 / 1: ghost-cell messages sent / received; 2 / 3: tripole top rows sent / received (receive
+        addresses are indices into the global fold buffer)."""
         out = []
-        n = self.dinfo["nrecv" if direction else "nsend"]
-        for m in range(n):
+        m = -1
+        while True:
+            m += 1
             peer = C.c_int(); cnt = C.c_int()
-            self._ck(self.lib.cice_domain_halo_msg(self.h, direction, m, C.byref(peer), C.byref(cnt), None))
+            if self.lib.cice_domain_halo_msg(self.h, direction, m, C.byref(peer), C.byref(cnt), None) != 0:
+                break
             addr = np.zeros(cnt.value, np.int32)
             self._ck(self.lib.cice_domain_halo_msg(self.h, direction, m, None, None, _i4(addr)))
             out.append((peer.value, addr))

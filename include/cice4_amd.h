@@ -104,7 +104,8 @@ int cice_domain_halo_refresh(const cice_ctx *ctx, int *n, int32_t *src, int32_t 
 /* on-rank halo copy list (0-based linear addresses into the (nx_block,ny_block,nblocks)
  * array): a[dst[n]] = a[src[n]]; = srcLocalAddr/dstLocalAddr of serial/ice_boundary.F90:49-62 */
 int cice_domain_halo_local(const cice_ctx *ctx, int32_t *src, int32_t *dst);
-/* msg-th send (dir=0) / recv (dir=1) message: peer rank, element count, addresses */
+/* msg-th send (dir=0) / recv (dir=1) message: peer rank, element count, addresses; dir = 2 / 3: the tripole
+ * top-row messages (send: local addresses, receive: indices into the global fold buffer).  CICE_EINVAL past the last. */
 int cice_domain_halo_msg(const cice_ctx *ctx, int dir, int msg, int *peer, int *count,
                          int32_t *addr);
 

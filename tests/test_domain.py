@@ -121,3 +121,73 @@ def test_slab_overlap_lists(nb, nr, ov):
             for jj in (d["jlo"][b] - 2, d["jhi"][b]):       # ghost rows inside the domain
                 if (wants[r][b, jj] >= 0).any():
                     assert np.array_equal(got[b, jj], wants[r][b, jj]), (r, b, jj)
+
+
+def _halo_multi_rank(ctxs, fields, loc, kind, fill, nxg):
+    """Emulates Halo::update for several ranks on host arrays (one flat float64 array per rank): wrap list, fill
+    list, ghost messages, then the tripole fold with its own messages into each top-row rank's buffer."""
+    nr = len(ctxs)
+    doms = [c.domain() for c in ctxs]
+    sends = [dict(c.halo_msgs(0)) for c in ctxs]; recvs = [dict(c.halo_msgs(1)) for c in ctxs]
+    staged = [{p: fields[p][sends[p][r]].copy() for p in recvs[r]} for r in range(nr)]
+    for r in range(nr):
+        f = fields[r]
+        f[doms[r]["hdst"]] = f[doms[r]["hsrc"]]
+        f[doms[r]["hfill"]] = fill
+        for p, addr in recvs[r].items():
+            f[addr] = staged[r][p]
+    fs = [dict(c.halo_msgs(2)) for c in ctxs]; fr = [dict(c.halo_msgs(3)) for c in ctxs]
+    fstaged = [{p: fields[p][fs[p][r]].copy() for p in fr[r]} for r in range(nr)]
+    sgn = 1.0 if kind == 1 else -1.0
+    for r, c in enumerate(ctxs):
+        lsrc, bidx = c.domain_list("fold_lsrc"), c.domain_list("fold_bidx")
+        dst, src = c.domain_list("fold_dst", loc), c.domain_list("fold_src", loc)
+        if not len(dst):
+            assert not fr[r]
+            continue
+        buf = np.full(2 * nxg, fill, np.float64)
+        buf[bidx] = fields[r][lsrc]
+        for p, b in fr[r].items():
+            buf[b] = fstaged[r][p]
+        lo, hi = c.domain_list("fold_lo", loc), c.domain_list("fold_hi", loc)
+        x = 0.5 * (buf[lo] + sgn * buf[hi])
+        buf[lo] = x; buf[hi] = sgn * x
+        fields[r][dst] = sgn * buf[src]
+
+
+@pytest.mark.parametrize("ns", [0, 3])
+@pytest.mark.parametrize("nr,seed", [(2, 1), (3, 2), (4, 3)])
+def test_any_block_map_tripole_and_eliminated_blocks_on_several_ranks(nr, seed, ns):
+    """cice_domain_create_map: a RANDOM block->task map (what rake / space-curve distributions produce) with
+    eliminated blocks, on nr ranks, open or tripole north boundary: ghost messages, fill cells and fold messages
+    give every rank the ghost values the single-rank domain with the same eliminated blocks has."""
+    nxg, nyg, bsx, bsy = 24, 20, 6, 5
+    nbx, nby = 4, 4
+    rng = np.random.default_rng(seed)
+    owner = rng.integers(0, nr, nbx * nby).astype(np.int32)
+    owner[rng.choice(nbx * nby - nbx, 3, replace=False)] = -1          # eliminated (never in the top block row)
+    owner[nbx * nby - 1] = 0; owner[nbx * nby - 2] = nr - 1             # top row spread over ranks
+    one = lib.Context()
+    own1 = np.where(owner >= 0, 0, -1).astype(np.int32)
+    d1 = one.domain_create_map(nxg, nyg, bsx, bsy, own1, ew=1, ns=ns)
+    ctxs = [lib.Context() for _ in range(nr)]
+    doms = [c.domain_create_map(nxg, nyg, bsx, bsy, owner, ew=1, ns=ns, rank=r, nranks=nr) for r, c in enumerate(ctxs)]
+    assert sum(d["nblocks"] for d in doms) == d1["nblocks"] == int((owner >= 0).sum())
+    np_ = d1["ny"] * d1["nx"]
+    for loc in ((1, 2, 3, 4) if ns == 3 else (1,)):
+        for kind in ((1, 2) if ns == 3 else (1,)):
+            g = rng.uniform(-1, 1, (d1["nblocks"], d1["ny"], d1["nx"]))
+            want = g.copy()
+            one.apply_halo_lists(want, loc, kind, fill=7.0)
+            fields = []
+            for d in doms:
+                f = np.zeros((d["nblocks"], d["ny"], d["nx"]))
+                for lb, gid in enumerate(d["gid"]):
+                    f[lb] = g[list(d1["gid"]).index(gid)]
+                fields.append(f.reshape(-1))
+            _halo_multi_rank(ctxs, fields, loc, kind, 7.0, nxg)
+            for d, f in zip(doms, fields):
+                f = f.reshape(d["nblocks"], d["ny"], d["nx"])
+                for lb, gid in enumerate(d["gid"]):
+                    assert np.array_equal(f[lb], want[list(d1["gid"]).index(gid)]), (nr, ns, loc, kind, gid)
+            assert not np.array_equal(want, g)
