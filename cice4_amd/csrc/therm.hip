@@ -828,7 +828,7 @@ __global__ __launch_bounds__(256) void k_frzmlt(const FrzmltArgs a) {
     ustar = fmax(ustar, a.ustar_min);
     fbot = cpchr * deltaT * ustar;
     fbot = fmax(fbot, a.frzmlt[q]);
-    const double wlat = m1 * pow(deltaT, m2);
+    const double wlat = m1 * pow_libm(deltaT, m2);
     rside = wlat * a.dt * pi / (alpha * floediam);
     rside = fmax(c0, fmin(rside, c1));
     for (int n = 0; n < NCAT; ++n) {
