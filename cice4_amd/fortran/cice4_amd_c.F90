@@ -40,7 +40,46 @@ module cice4_amd_c
       integer(c_int) :: tr_iage, nt_Tsfc, nt_iage
    end type
 
+   ! the thermodynamic half-step in one call (cice_step_therm1): c_ptr to module arrays of shape
+   ! (nx_block,ny_block[,k],[ncat,]max_blocks) used with nblocks = max_blocks; c_null_ptr = not wanted
+   type, bind(C) :: cice_thermo_fields
+      type(c_ptr) :: aicen, trcrn, vicen, vsnon, eicen, esnon
+      type(c_ptr) :: flw, potT, Qa, rhoa, fsnow, fbot, Tbot
+      type(c_ptr) :: lhcoef, shcoef
+      type(c_ptr) :: fswsfc, fswint, fswthrun, Sswabs, Iswabs
+      type(c_ptr) :: fsurfn, fcondtopn, fsensn, flatn, fswabsn, flwoutn, evapn, freshn, fsaltn, fhocnn, &
+                     meltt, melts, meltb, congel, snoice
+      type(c_ptr) :: mlt_onset, frz_onset
+   end type
+
+   type, bind(C) :: cice_frzmlt_fields
+      type(c_ptr) :: aice, frzmlt, sst, Tf, strocnxT, strocnyT
+      type(c_ptr) :: Tbot = c_null_ptr, fbot = c_null_ptr, rside = c_null_ptr
+   end type
+
+   type, bind(C) :: cice_merge_fields
+      type(c_ptr) :: aicen_init = c_null_ptr, strairxn, strairyn, Trefn, Qrefn
+      type(c_ptr) :: acc(20)
+   end type
+
    interface
+      integer(c_int) function cice_step_therm1(ctx, dt, yday, st, fz, mg, n_updates, l_stop, istop, jstop, &
+            nstop, bstop) bind(C, name='cice_step_therm1')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: dt, yday
+         type(cice_thermo_fields), intent(in) :: st
+         type(cice_frzmlt_fields), intent(in) :: fz
+         type(cice_merge_fields), intent(in) :: mg
+         integer(c_long_long), intent(out) :: n_updates
+         integer(c_int), intent(out) :: l_stop, istop, jstop, nstop, bstop
+      end function
+      integer(c_int) function cice_thermo_batch_alloc(ctx, nx_block, ny_block, nblocks) &
+            bind(C, name='cice_thermo_batch_alloc')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_block, ny_block, nblocks
+      end function
       integer(c_int) function cice_create(ctx, device) bind(C, name='cice_create')
          import
          type(c_ptr), intent(out) :: ctx
