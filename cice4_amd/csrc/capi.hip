@@ -13,6 +13,7 @@
 #include "evp.h"
 #include "halo.h"
 #include "therm.h"
+#include "transport.h"
 
 using namespace cice;
 
@@ -24,6 +25,7 @@ struct cice_ctx {
   bool have_domain = false;
   std::unique_ptr<Halo> halo;
   std::unique_ptr<Evp> evp;
+  std::unique_ptr<Transport> transport;
   // RCCL communicator of this rank (cice_comm_init): created once, handed to every Halo built afterwards --
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
@@ -204,6 +206,7 @@ int cice_destroy(cice_ctx* ctx) {
   for (void* h : ctx->pinned)
     if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
   ctx->evp.reset();
+  ctx->transport.reset();
   ctx->halo.reset();
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -260,6 +263,7 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create: ") + msg};
   c_->have_domain = true;
   c_->evp.reset();
+  c_->transport.reset();
   c_->halo.reset();
   CICE_CATCH
 }
@@ -274,6 +278,7 @@ int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, in
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_map: ") + msg};
   c_->have_domain = true;
   c_->evp.reset();
+  c_->transport.reset();
   c_->halo.reset();
   CICE_CATCH
 }
@@ -308,6 +313,7 @@ int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_slabs: ") + msg};
   c_->have_domain = true;
   c_->evp.reset();
+  c_->transport.reset();
   c_->halo.reset();
   CICE_CATCH
 }
@@ -971,6 +977,35 @@ int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, 
   CICE_HIP(hipMemcpyAsync(fbot, a.fbot, np * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipMemcpyAsync(rside, a.rside, np * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipStreamSynchronize(s));
+  CICE_CATCH
+}
+
+// ---- horizontal transport ---------------------------------------------------------------------
+int cice_transport_init(cice_ctx* ctx, const cice_transport_config* cfg, const cice_transport_grid* grid) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(cfg && grid, "NULL argument");
+  c_->need_halo();
+  c_->transport.reset(new Transport(c_->dom, *c_->halo, c_->stream));
+  c_->transport->init(*cfg, *grid);
+  CICE_CATCH
+}
+
+int cice_transport_remap(cice_ctx* ctx, double dt, const cice_transport_fields* f, int32_t* l_stop,
+                         int32_t* istop, int32_t* jstop) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(c_->transport != nullptr, "cice_transport_init has not been called");
+  CICE_REQUIRE(f, "NULL argument");
+  c_->transport->remap(dt, *f, l_stop, istop, jstop);
+  CICE_CATCH
+}
+
+// test aid (not part of the drop-in surface): see Transport::debug_stop / debug_fetch
+int cice_transport_debug(cice_ctx* ctx, int stop_stage, int which, double* out, long long* count) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(c_->transport != nullptr, "cice_transport_init has not been called");
+  c_->transport->debug_stop(stop_stage);
+  const size_t n = which >= 0 ? c_->transport->debug_fetch(which, out) : 0;
+  if (count) *count = (long long)n;
   CICE_CATCH
 }
 

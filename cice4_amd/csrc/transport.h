@@ -1,0 +1,57 @@
+// Horizontal transport by incremental remapping on the device (source/ice_transport_driver.F90:179-663
+// transport_remap, source/ice_transport_remap.F90:328-881 horizontal_remap) -- SURVEY.md section 8(f3).
+#pragma once
+#include "common.h"
+#include "domain.h"
+#include "halo.h"
+
+namespace cice {
+
+constexpr int TR_MAXTRACE = 2 + NTRCR + NILYR + NSLYR;  // hice, hsno, trcr, qice, qsno (max_ntrace, :40)
+
+struct TransportKernelArgs {
+  int nx, ny, nb, ntrace, ntrcr;
+  int type[TR_MAXTRACE], dep[TR_MAXTRACE], hasdep[TR_MAXTRACE];  // tracer_type, depend (0-based, -1 none), has_dependents
+  double dt;
+  const int32_t* blk;  // ilo, ihi, jlo, jhi per block (1-based)
+  const double *HTN, *HTE, *dxt, *dyt, *dxu, *dyu, *tarear, *hm;
+  // state, reference layout
+  double *aice0, *aicen, *trcrn, *vicen, *vsnon, *eicen, *esnon;
+  const double *uvel, *vvel;
+  // work: mm (nx,ny,0:ncat,nb); tm (nx,ny,ntrace,ncat,nb); masks alike
+  double *mm, *tm, *mmask, *tmask;
+  double *mc, *mx, *my;     // (nx,ny,0:ncat,nb) each; mc directly followed by tc (one scalar halo update)
+  double *tc, *tx, *ty;     // (nx,ny,ntrace,ncat,nb)
+  double *dpx, *dpy;        // (nx,ny,nb)
+  double *mflx, *mtflx;     // [dir 0 east / 1 north]: (nx,ny,0:ncat,nb), (nx,ny,ntrace,ncat,nb)
+  unsigned long long* errkey;
+};
+
+class Transport {
+ public:
+  Transport(const Domain& d, Halo& h, hipStream_t s) : dom(d), halo(h), stream(s) {}
+  void init(const cice_transport_config& c, const cice_transport_grid& g);
+  // one transport_remap(dt) on host arrays (upload, remap, bound_state on the device, download)
+  void remap(double dt, const cice_transport_fields& f, int32_t* l_stop, int32_t* istop, int32_t* jstop);
+  // test aid: stop the next remap() after kernel stage `s` (1 tracers, 2 fields + departure points + their halos,
+  // 3 fluxes, 4 update; 0 = run through) and copy a work array to the host (0 mm, 1 tm, 2 mc|tc, 3 mx|tx|my|ty,
+  // 4 dpx|dpy, 5 mflx, 6 mtflx, 7 mmask, 8 tmask); returns the number of doubles
+  void debug_stop(int s) { stop_stage = s; }
+  size_t debug_fetch(int which, double* out);
+  int stop_stage = 0;
+
+ private:
+  const Domain& dom;
+  Halo& halo;
+  hipStream_t stream;
+  size_t n = 0;  // nblocks * nx_block * ny_block
+  int ntrace = 0, ntrcr = 0;
+  TransportKernelArgs a{};
+  DevBuf<int32_t> blk;
+  DevBuf<double> HTN, HTE, dxt, dyt, dxu, dyu, tarear, hm;
+  DevBuf<double> aice0, aicen, trcrn, vicen, vsnon, eicen, esnon, uv;
+  DevBuf<double> mm, tm, mmask, tmask, ctr, grad, dp, mflx, mtflx;
+  DevBuf<unsigned long long> key;
+};
+
+}  // namespace cice

@@ -68,6 +68,18 @@ class MergeFields(C.Structure):
                [("acc", C.c_void_p * 20)]
 
 
+class TransportConfig(C.Structure):
+    _fields_ = [("ntrcr", C.c_int), ("trcr_depend", C.c_int * 5)]
+
+
+class TransportGrid(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("HTN", "HTE", "dxt", "dyt", "dxu", "dyu", "tarear", "hm")]
+
+
+class TransportFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("aice0", "aicen", "trcrn", "vicen", "vsnon", "eicen", "esnon", "uvel", "vvel")]
+
+
 class FrzmltFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("aice", "frzmlt", "sst", "Tf", "strocnxT", "strocnyT", "Tbot", "fbot", "rside")]
 
@@ -445,6 +457,38 @@ class Context:
             f.acc[k] = acc[n].ctypes.data
             assert acc[n].dtype == np.float64 and acc[n].flags["C_CONTIGUOUS"]
         self._ck(self.lib.cice_thermo_batch_merge(self.h, C.byref(f)))
+
+    # ---- horizontal transport --------------------------------------------------
+    def transport_init(self, grid, ntrcr=2, trcr_depend=(0, 1)):
+        """grid: HTN, HTE, dxt, dyt, dxu, dyu, tarear, hm as (nblocks, ny, nx) arrays; tracer set as in ice_init.F90:848."""
+        cfg = TransportConfig()
+        cfg.ntrcr = ntrcr
+        for k, d in enumerate(trcr_depend):
+            cfg.trcr_depend[k] = d
+        g = TransportGrid()
+        self._tgrid = {n: np.ascontiguousarray(grid[n], np.float64) for n, _t in TransportGrid._fields_}
+        for n in self._tgrid:
+            setattr(g, n, _f8(self._tgrid[n]))
+        self._ck(self.lib.cice_transport_init(self.h, C.byref(cfg), C.byref(g)))
+
+    def transport_remap(self, dt, s):
+        """s: aice0, uvel, vvel (nb,ny,nx); aicen, vicen, vsnon (nb,ncat,ny,nx); trcrn (nb,ncat,5,ny,nx); eicen
+        (nb,ncat*nilyr,ny,nx); esnon (nb,ncat*nslyr,ny,nx); state updated in place.  Returns (l_stop, istop, jstop)."""
+        f = TransportFields()
+        for n, _t in TransportFields._fields_:
+            setattr(f, n, _f8(s[n]))
+        st = [C.c_int32(0) for _ in range(3)]
+        self._ck(self.lib.cice_transport_remap(self.h, C.c_double(dt), C.byref(f), *[C.byref(x) for x in st]))
+        return tuple(x.value for x in st)
+
+    def transport_debug(self, stop_stage=0, which=-1):
+        cnt = C.c_longlong(0)
+        self._ck(self.lib.cice_transport_debug(self.h, stop_stage, which, None, C.byref(cnt)))
+        if which < 0:
+            return None
+        out = np.zeros(cnt.value)
+        self._ck(self.lib.cice_transport_debug(self.h, stop_stage, which, _f8(out), C.byref(cnt)))
+        return out
 
     def step_therm1(self, dt, yday, state, fz, percat, acc):
         """cice_step_therm1: one upload, frzmlt_bottom_lateral + thermo_vertical for every category + merge_fluxes on

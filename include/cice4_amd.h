@@ -323,6 +323,36 @@ int cice_frzmlt_bottom_lateral(cice_ctx *ctx, int nx_block, int ny_block, int il
                                const double *strocnyT, double *Tbot, double *fbot,
                                double *rside);
 
+/* ---- horizontal transport by incremental remapping ----------------------------------
+ * cice_transport_init ≙ init_transport (source/ice_transport_driver.F90:81; advection = 'remap'): tracer
+ * dependencies from ntrcr / trcr_depend (ice_init.F90:848-852: 0 area tracer, 1 ice-volume, 2 snow-volume tracer),
+ * one upload of the grid arrays of ice_grid (HTN, HTE, dxt, dyt, dxu, dyu, tarear, hm; (nx_block,ny_block,nblocks)).
+ * cice_transport_remap ≙ `call transport_remap(dt)` (ice_step_mod.F90:600; driver :179-663 with
+ * l_conservation_check = l_monotonicity_check = F): state_to_tracers, horizontal_remap (make_masks,
+ * construct_fields, departure_points, locate_triangles, triangle_coordinates, transport_integrals, update_fields),
+ * tracers_to_state and bound_state, all on the device; host arrays in the reference's layout: aice0, uvel, vvel
+ * (nx,ny,nb), aicen/vicen/vsnon (nx,ny,ncat,nb), trcrn (nx,ny,max_ntrcr,ncat,nb), eicen (nx,ny,ntilyr,nb),
+ * esnon (nx,ny,ntslyr,nb).  l_stop: 0 ok, 1 departure point outside the neighbouring cells, 2 negative area
+ * (the caller's abort_ice), with a cell (istop, jstop).  Compile-time choices of the reference kept:
+ * l_fixed_area = F, integral_order = 3, l_dp_midpt = T.  advection = 'upwind' is not provided. */
+typedef struct {
+  int ntrcr;
+  int trcr_depend[CICE_MAX_NTRCR];
+} cice_transport_config;
+typedef struct {
+  const double *HTN, *HTE, *dxt, *dyt, *dxu, *dyu, *tarear, *hm;
+} cice_transport_grid;
+typedef struct {
+  double *aice0, *aicen, *trcrn, *vicen, *vsnon, *eicen, *esnon;
+  const double *uvel, *vvel;
+} cice_transport_fields;
+int cice_transport_init(cice_ctx *ctx, const cice_transport_config *cfg, const cice_transport_grid *grid);
+int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *f, int32_t *l_stop,
+                         int32_t *istop, int32_t *jstop);
+/* Test aid: make the next cice_transport_remap stop after kernel stage stop_stage (0: run through) and / or copy
+ * work array `which` (-1: none) to `out`; *count = its length in doubles. */
+int cice_transport_debug(cice_ctx *ctx, int stop_stage, int which, double *out, long long *count);
+
 #ifdef __cplusplus
 }
 #endif

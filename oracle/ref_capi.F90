@@ -603,10 +603,115 @@ contains
                endif
             enddo
          enddo
+      case ('vsnon')
+         n = ncat*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ncat
+               m = (iblk-1)*ncat + k
+               if (dir == 0) then
+                  buf(:,:,m) = vsnon(:,:,k,iblk)
+               else
+                  vsnon(:,:,k,iblk) = buf(:,:,m)
+               endif
+            enddo
+         enddo
+      case ('trcrn')      ! (nx,ny,max_ntrcr,ncat,max_blocks) as max_ntrcr*ncat*max_blocks planes
+         n = max_ntrcr*ncat*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ncat
+               do m = 1, max_ntrcr
+                  if (dir == 0) then
+                     buf(:,:,((iblk-1)*ncat + k-1)*max_ntrcr + m) = trcrn(:,:,m,k,iblk)
+                  else
+                     trcrn(:,:,m,k,iblk) = buf(:,:,((iblk-1)*ncat + k-1)*max_ntrcr + m)
+                  endif
+               enddo
+            enddo
+         enddo
+      case ('eicen')
+         n = ntilyr*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ntilyr
+               if (dir == 0) then
+                  buf(:,:,(iblk-1)*ntilyr + k) = eicen(:,:,k,iblk)
+               else
+                  eicen(:,:,k,iblk) = buf(:,:,(iblk-1)*ntilyr + k)
+               endif
+            enddo
+         enddo
+      case ('esnon')
+         n = ntslyr*max_blocks
+         do iblk = 1, max_blocks
+            do k = 1, ntslyr
+               if (dir == 0) then
+                  buf(:,:,(iblk-1)*ntslyr + k) = esnon(:,:,k,iblk)
+               else
+                  esnon(:,:,k,iblk) = buf(:,:,(iblk-1)*ntslyr + k)
+               endif
+            enddo
+         enddo
       case default
          n = -1
       end select
       ref_field = n
    end function ref_field
+
+   !--------------------------------------------------------------------
+   ! horizontal transport: init_transport (ice_transport_driver.F90:81) with advection = 'remap' and the
+   ! tracer set of the gx3 namelist (Tsfc, iage), then transport_remap(dt) (:179) on the module state
+   !--------------------------------------------------------------------
+   subroutine ref_init_transport() bind(C, name='ref_init_transport')
+      use ice_transport_driver, only: init_transport, advection
+      use ice_state, only: ntrcr, nt_Tsfc, nt_iage, trcr_depend
+      logical, save :: done = .false.
+      if (done) return
+      advection = 'remap'
+      ntrcr = 2
+      nt_Tsfc = 1
+      nt_iage = 2
+      trcr_depend(:) = 0
+      trcr_depend(nt_iage) = 1     ! ice_init.F90:848-849
+      call init_transport
+      done = .true.
+   end subroutine ref_init_transport
+
+   ! pieces of transport_remap for stage-by-stage comparisons: state_to_tracers for every local block, and
+   ! horizontal_remap on caller-supplied mean fields (module uvel, vvel); edgearea_* come back (l_fixed_area = F)
+   subroutine ref_state_to_tracers(aim, trm) bind(C, name='ref_state_to_tracers')
+      use ice_transport_driver, only: state_to_tracers, ntrace
+      use ice_blocks, only: nx_block, ny_block
+      use ice_domain, only: nblocks
+      use ice_state
+      real(c_double), intent(out) :: aim(nx_block,ny_block,0:ncat,max_blocks)
+      real(c_double), intent(out) :: trm(nx_block,ny_block,ntrace,ncat,max_blocks)
+      integer :: iblk
+      aim = 0; trm = 0
+      do iblk = 1, nblocks
+         call state_to_tracers(nx_block, ny_block, ntrcr, ntrace, aice0(:,:,iblk), aicen(:,:,:,iblk), &
+                               trcrn(:,:,1:ntrcr,:,iblk), vicen(:,:,:,iblk), vsnon(:,:,:,iblk), &
+                               eicen(:,:,:,iblk), esnon(:,:,:,iblk), aim(:,:,:,iblk), trm(:,:,:,:,iblk))
+      enddo
+   end subroutine ref_state_to_tracers
+
+   subroutine ref_horizontal_remap(dt, aim, trm, ee, en) bind(C, name='ref_horizontal_remap')
+      use ice_transport_driver, only: ntrace, tracer_type, depend, has_dependents, integral_order, l_dp_midpt, &
+                                      l_fixed_area
+      use ice_transport_remap, only: horizontal_remap
+      use ice_blocks, only: nx_block, ny_block
+      use ice_state, only: uvel, vvel
+      real(c_double), value :: dt
+      real(c_double), intent(inout) :: aim(nx_block,ny_block,0:ncat,max_blocks)
+      real(c_double), intent(inout) :: trm(nx_block,ny_block,ntrace,ncat,max_blocks)
+      real(c_double), intent(out) :: ee(nx_block,ny_block,max_blocks), en(nx_block,ny_block,max_blocks)
+      ee = 0; en = 0
+      call horizontal_remap(dt, ntrace, uvel, vvel, aim, trm, l_fixed_area, ee, en, tracer_type, depend, &
+                            has_dependents, integral_order, l_dp_midpt)
+   end subroutine ref_horizontal_remap
+
+   subroutine ref_transport_remap(dt) bind(C, name='ref_transport_remap')
+      use ice_transport_driver, only: transport_remap
+      real(c_double), value :: dt
+      call transport_remap(dt)
+   end subroutine ref_transport_remap
 
 end module ref_capi

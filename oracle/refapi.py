@@ -252,6 +252,24 @@ class Ref:
     def halo_i4(self, a, loc=1, kind=1):
         self.lib.ref_halo_i4(_p(a), C.c_int(loc), C.c_int(kind))
 
+    def init_transport(self):
+        self.lib.ref_init_transport()
+
+    def state_to_tracers(self, ntrace=9):
+        aim = np.zeros((self.max_blocks, NCAT + 1, self.ny_block, self.nx_block))
+        trm = np.zeros((self.max_blocks, NCAT, ntrace, self.ny_block, self.nx_block))
+        self.lib.ref_state_to_tracers(_p(aim), _p(trm))
+        return aim, trm
+
+    def horizontal_remap(self, dt, aim, trm):
+        ee = np.zeros((self.max_blocks, self.ny_block, self.nx_block)); en = np.zeros_like(ee)
+        self.lib.ref_horizontal_remap(C.c_double(dt), _p(aim), _p(trm), _p(ee), _p(en))
+        return ee, en
+
+    def transport_remap(self, dt):
+        """transport_remap(dt) (ice_transport_driver.F90:179) on the module state."""
+        self.lib.ref_transport_remap(C.c_double(dt))
+
     def halo_nd(self, a, loc=1, kind=1):
         """Generic ice_HaloUpdate on a C-ordered array (nblk[,nt][,nz],ny,nx) of float64,
         float32 or int32 -- the 2-d/3-d/4-d x R8/R4/I4 specifics."""
