@@ -40,6 +40,20 @@ module cice4_amd_c
       integer(c_int) :: tr_iage, nt_Tsfc, nt_iage
    end type
 
+   ! horizontal transport (cice_transport_init / cice_transport_remap)
+   type, bind(C) :: cice_transport_config
+      integer(c_int) :: ntrcr
+      integer(c_int) :: trcr_depend(5)
+   end type
+
+   type, bind(C) :: cice_transport_grid
+      type(c_ptr) :: HTN, HTE, dxt, dyt, dxu, dyu, tarear, hm
+   end type
+
+   type, bind(C) :: cice_transport_fields
+      type(c_ptr) :: aice0, aicen, trcrn, vicen, vsnon, eicen, esnon, uvel, vvel
+   end type
+
    ! the thermodynamic half-step in one call (cice_step_therm1): c_ptr to module arrays of shape
    ! (nx_block,ny_block[,k],[ncat,]max_blocks) used with nblocks = max_blocks; c_null_ptr = not wanted
    type, bind(C) :: cice_thermo_fields
@@ -73,6 +87,20 @@ module cice4_amd_c
          type(cice_merge_fields), intent(in) :: mg
          integer(c_long_long), intent(out) :: n_updates
          integer(c_int), intent(out) :: l_stop, istop, jstop, nstop, bstop
+      end function
+      integer(c_int) function cice_transport_init(ctx, cfg, grid) bind(C, name='cice_transport_init')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_transport_config), intent(in) :: cfg
+         type(cice_transport_grid), intent(in) :: grid
+      end function
+      integer(c_int) function cice_transport_remap(ctx, dt, f, l_stop, istop, jstop) &
+            bind(C, name='cice_transport_remap')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: dt
+         type(cice_transport_fields), intent(in) :: f
+         integer(c_int), intent(out) :: l_stop, istop, jstop
       end function
       integer(c_int) function cice_thermo_batch_alloc(ctx, nx_block, ny_block, nblocks) &
             bind(C, name='cice_thermo_batch_alloc')

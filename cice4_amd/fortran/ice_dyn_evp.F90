@@ -137,10 +137,12 @@
       ! with rccl/ice_boundary.F90 in the build the device topology (and, under MPI, the RCCL
       ! communicator) already exists for the model's block distribution; with the reference's own
       ! boundary module (serial build) it is created here
-      if (.not. cice_gpu_domain_ready) &
+      if (.not. cice_gpu_domain_ready) then
          call cice_gpu_check(cice_domain_create(cice_gpu_ctx, nx_global, ny_global, block_size_x, &
               block_size_y, bnd_code(ew_boundary_type), bnd_code(ns_boundary_type), 0_c_int, &
               1_c_int, 1_c_int), 'cice_domain_create')
+         cice_gpu_domain_ready = .true.     ! the transport module reuses it
+      endif
       call cice_gpu_check(cice_domain_info(cice_gpu_ctx, info), 'cice_domain_info')
       if (info(1) /= nx_block .or. info(2) /= ny_block .or. info(3) /= nblocks .or. &
           nblocks > max_blocks) then

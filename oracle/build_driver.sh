@@ -7,15 +7,12 @@
 #
 #   oracle/_ref/cice_ref_<cfg>      every module the reference's own (serial/ backend)
 #   oracle/_ref/cice_dropin_<cfg>   the same, except that source/ice_dyn_evp.F90,
-#                                   source/ice_therm_vertical.F90 and serial/ice_boundary.F90 are
-#                                   replaced by cice4_amd/fortran/{ice_dyn_evp,ice_therm_vertical,
-#                                   rccl/ice_boundary}.F90 (+ cice4_amd_c.F90) and the program is
+#                                   source/ice_therm_vertical.F90, source/ice_transport_driver.F90 and
+#                                   serial/ice_boundary.F90 are replaced by cice4_amd/fortran/{ice_dyn_evp,
+#                                   ice_therm_vertical,ice_transport_driver,rccl/ice_boundary}.F90
+#                                   (+ cice4_amd_c.F90) and the program is
 #                                   linked with libcice4_amd.so -- what a user of the reference who
-#                                   swaps the three modules builds.
-#
-# With DRIVER=amd the drop-in build also takes cice4_amd/fortran/drivers/cice4_amd/CICE_RunMod.F90 (our
-# driver variant, the same seam as drivers/{cice4,esmf,access-om,access-cm}: one batched device call
-# per step_therm1 instead of ncat x nblocks thermo_vertical calls) -> oracle/_ref/cice_dropinb_<cfg>.
+#                                   swaps the four modules builds.
 #
 # No reference source is copied into the repository and none is stubbed.  The image has no netCDF;
 # all netCDF use in the model is behind `#ifdef ncdf` (left undefined) except three
@@ -32,7 +29,6 @@ HERE=$(cd "$(dirname "$0")" && pwd)
 CFG=$1; NXG=$2; NYG=$3; BX=$4; BY=$5; MXB=$6
 FC=${FC:-/opt/rocm/bin/amdflang}
 DROPIN=${DROPIN:-0}
-DRIVER=${DRIVER:-cice4}
 OUT=$HERE/_ref
 if [ ! -d "$REF/source" ]; then
   echo "build_driver: $REF not present (GPU box?) -- using prebuilt files in $OUT" >&2
@@ -40,7 +36,6 @@ if [ ! -d "$REF/source" ]; then
 fi
 KIND=ref
 [ "$DROPIN" = "1" ] && KIND=dropin
-[ "$DROPIN" = "1" ] && [ "$DRIVER" = "amd" ] && KIND=dropinb
 OBJ=$OUT/drv_${CFG}_$KIND
 TARGET=$OUT/cice_${KIND}_$CFG
 OURS=$HERE/../cice4_amd/fortran
@@ -54,12 +49,10 @@ FFLAGS="-O2 -w -cpp -fdefault-real-8 -fconvert=big-endian -ffp-contract=off \
 # the source list: the reference's files, with ours substituted for the drop-in build
 LIST=$(ls $REF/drivers/cice4/*.F90 $REF/source/*.F90 $REF/serial/*.F90 $REF/csm_share/*.F90 | grep -v dump_field.F90)
 if [ "$DROPIN" = "1" ]; then
-  LIST=$(echo "$LIST" | grep -v -e source/ice_dyn_evp.F90 -e source/ice_therm_vertical.F90 -e serial/ice_boundary.F90)
-  LIST="$LIST $OURS/cice4_amd_c.F90 $OURS/ice_dyn_evp.F90 $OURS/ice_therm_vertical.F90 $OURS/rccl/ice_boundary.F90"
-  if [ "$DRIVER" = "amd" ]; then
-    LIST=$(echo "$LIST" | tr ' ' '\n' | grep -v drivers/cice4/CICE_RunMod.F90)
-    LIST="$LIST $OURS/drivers/cice4_amd/CICE_RunMod.F90"
-  fi
+  LIST=$(echo "$LIST" | grep -v -e source/ice_dyn_evp.F90 -e source/ice_therm_vertical.F90 -e serial/ice_boundary.F90 \
+         -e source/ice_transport_driver.F90)
+  LIST="$LIST $OURS/cice4_amd_c.F90 $OURS/ice_dyn_evp.F90 $OURS/ice_therm_vertical.F90 $OURS/rccl/ice_boundary.F90 \
+        $OURS/ice_transport_driver.F90"
 fi
 # module/use topological order
 ORDER=$(python3 - $LIST <<'EOF'

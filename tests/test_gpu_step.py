@@ -1,7 +1,8 @@
 """Whole-driver drop-in run: the reference's own `program icemodel`
 (drivers/cice4/CICE.F90:64-94 -> ice_step, CICE_RunMod.F90:164-242 -> step_therm1 :260-598 and
-step_dynamics, source/ice_step_mod.F90:538-745) compiled UNCHANGED, linked with the three drop-in modules
-(cice4_amd/fortran/{ice_dyn_evp,ice_therm_vertical,rccl/ice_boundary}.F90) and libcice4_amd.so, runs its
+step_dynamics, source/ice_step_mod.F90:538-745 -> evp, transport_remap) compiled UNCHANGED, linked with the four drop-in
+modules (cice4_amd/fortran/{ice_dyn_evp,ice_therm_vertical,ice_transport_driver,rccl/ice_boundary}.F90) and
+libcice4_amd.so, runs its
 time loop on the GPU box; its restart dump (source/ice_restart.F90:74-256) is compared with the dump of
 the pure serial reference (tests/golden/step_*.npz, minted by tests/golden/make_golden_step.py).
 
@@ -81,7 +82,7 @@ def test_pure_reference_reproduces_its_golden_dump(name):
                                       ("gx1_default3", TOL_EXP)])
 def test_reference_step_loop_with_dropin_modules(name, tol):
     rec, gold, stride, log = _run_case("dropin", name)
-    assert "EVP dynamics on the GPU" in log
+    assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
     worst = _compare(rec, gold, stride, tol)
     print("whole-driver drop-in", name, "worst field-relative difference", worst)
 
