@@ -126,3 +126,38 @@ def test_restart_round_trip_with_dropin_modules():
     finally:
         for d in dirs.values():
             shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
+def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
+    """The whole model on the real gx3 grid cut into 10 x 12 blocks of 10 x 10 cells (max_blocks = 120), the four
+    all-land blocks eliminated by the reference's own create_distribution: multi-block EVP (per-subcycle halo updates
+    between blocks), transport, thermodynamics and every ice_HaloUpdate of the model through the drop-in modules, 6
+    steps, against the pure reference built for the same block layout and run on this host: restart dumps bit for bit."""
+    import glob
+    exe = {k: os.path.join(ROOT, "oracle", "_ref", "cice_%s_gx3e" % k) for k in ("ref", "dropin")}
+    for e in exe.values():
+        if not os.path.exists(e):
+            pytest.skip("%s not built" % e)
+    dirs = {k: tempfile.mkdtemp(prefix="cice_e_%s_" % k) for k in exe}
+    try:
+        rec = {}
+        for kind in exe:
+            driver.write_rundir(dirs[kind], npt=6, istep0=19)
+            log = driver.run(exe[kind], dirs[kind])
+            if kind == "dropin":
+                assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+            rec[kind] = driver.read_restart(driver.restart_path(dirs[kind]), 100, 116)
+        assert rec["ref"][0] == rec["dropin"][0]
+        for k in rec["ref"][1]:
+            a, b = rec["dropin"][1][k], rec["ref"][1][k]
+            if TOL_EXP == 0.0:
+                assert np.array_equal(a, b), (k, np.abs(a - b).max())
+            else:
+                assert np.abs(a - b).max() <= TOL_EXP * max(np.abs(b).max(), 1e-300), k
+        u = rec["ref"][1]["uvel"]
+        assert (np.abs(u) > 1e29).any()                    # eliminated blocks are written with the reference's spval
+        assert np.abs(u[np.abs(u) < 1e29]).max() > 0.05
+    finally:
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
