@@ -143,6 +143,36 @@ static void halo_host(cice_ctx* c, T* field, int nlev, int loc = LOC_CENTER, int
   CICE_HIP(hipStreamSynchronize(c->stream));
 }
 
+// The same for a field in the reference's own array layout (nx_block, ny_block, nz, nblocks) -- block outermost,
+// what ice_HaloUpdate3D/4D receive: strided copies to and from the level-major device layout replace the
+// repacking on the host.
+template <class T>
+static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, double fill) {
+  c->need_halo();
+  CICE_REQUIRE(field && nz >= 1, "bad argument");
+  const int nb = c->dom.nblocks();
+  const size_t np = (size_t)c->dom.nx_block * c->dom.ny_block, n = np * nb;
+  const size_t words = (n * nz * sizeof(T) + 7) / 8;
+  if (c->halo_stage.n < words) c->halo_stage.alloc(words);
+  T* d = reinterpret_cast<T*>(c->halo_stage.p);
+  if (nz == 1 || nb == 1) {
+    CICE_HIP(hipMemcpyAsync(d, field, n * nz * sizeof(T), hipMemcpyHostToDevice, c->stream));
+  } else {
+    for (int b = 0; b < nb; ++b)
+      CICE_HIP(hipMemcpy2DAsync(d + (size_t)b * np, n * sizeof(T), field + (size_t)b * nz * np, np * sizeof(T),
+                                np * sizeof(T), nz, hipMemcpyHostToDevice, c->stream));
+  }
+  halo_apply<T>(c, d, nz, n, loc, kind, fill);
+  if (nz == 1 || nb == 1) {
+    CICE_HIP(hipMemcpyAsync(field, d, n * nz * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+  } else {
+    for (int b = 0; b < nb; ++b)
+      CICE_HIP(hipMemcpy2DAsync(field + (size_t)b * nz * np, np * sizeof(T), d + (size_t)b * np, n * sizeof(T),
+                                np * sizeof(T), nz, hipMemcpyDeviceToHost, c->stream));
+  }
+  CICE_HIP(hipStreamSynchronize(c->stream));
+}
+
 // Device-resident form: the field already lives in device memory (nlev levels of nblocks*ny_block*nx_block
 // elements, level stride = one such plane set); nothing crosses PCIe, no allocation, asynchronous on the
 // library's stream.
@@ -541,6 +571,16 @@ int cice_halo_update_ex_r4(cice_ctx* ctx, float* field, int nlev, int loc, int k
 }
 int cice_halo_update_ex_i4(cice_ctx* ctx, int32_t* field, int nlev, int loc, int kind, int32_t fill) {
   CICE_TRY(ctx) halo_host<int32_t>(c_, field, nlev, loc, kind, fill); CICE_CATCH
+}
+// host field in the reference's (nx_block, ny_block, nz, nblocks) layout (nz = product of the level dimensions)
+int cice_halo_update_blocked_r8(cice_ctx* ctx, double* field, int nz, int loc, int kind, double fill) {
+  CICE_TRY(ctx) halo_host_blocked<double>(c_, field, nz, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_blocked_r4(cice_ctx* ctx, float* field, int nz, int loc, int kind, float fill) {
+  CICE_TRY(ctx) halo_host_blocked<float>(c_, field, nz, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_blocked_i4(cice_ctx* ctx, int32_t* field, int nz, int loc, int kind, int32_t fill) {
+  CICE_TRY(ctx) halo_host_blocked<int32_t>(c_, field, nz, loc, kind, fill); CICE_CATCH
 }
 int cice_halo_update_dev_ex_r8(cice_ctx* ctx, double* dev_field, int nlev, int loc, int kind, double fill) {
   CICE_TRY(ctx) halo_dev<double>(c_, dev_field, nlev, loc, kind, fill); CICE_CATCH

@@ -191,6 +191,29 @@ module cice4_amd_c
          integer(c_int) :: field(*)
          integer(c_int), value :: nlev, loc, kind, fill
       end function
+      integer(c_int) function cice_halo_update_blocked_r8(ctx, field, nz, loc, kind, fill) &
+            bind(C, name='cice_halo_update_blocked_r8')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double) :: field(*)
+         integer(c_int), value :: nz, loc, kind
+         real(c_double), value :: fill
+      end function
+      integer(c_int) function cice_halo_update_blocked_r4(ctx, field, nz, loc, kind, fill) &
+            bind(C, name='cice_halo_update_blocked_r4')
+         import
+         type(c_ptr), value :: ctx
+         real(c_float) :: field(*)
+         integer(c_int), value :: nz, loc, kind
+         real(c_float), value :: fill
+      end function
+      integer(c_int) function cice_halo_update_blocked_i4(ctx, field, nz, loc, kind, fill) &
+            bind(C, name='cice_halo_update_blocked_i4')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int) :: field(*)
+         integer(c_int), value :: nz, loc, kind, fill
+      end function
       integer(c_int) function cice_comm_unique_id(uid) bind(C, name='cice_comm_unique_id')
          import
          character(kind=c_char), intent(out) :: uid(128)

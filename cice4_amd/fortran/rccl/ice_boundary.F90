@@ -131,264 +131,134 @@ contains
    end function boundary_code
 
 !=======================================================================
-! Workers: nlev horizontal slabs in the device layout (nx_block,ny_block,nblocks,nlev).
-   subroutine update_levels_r8(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
-      real (dbl_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+! Workers: the field goes to the device in the layout the caller has it in, (nx_block,ny_block,nz,max_blocks) with
+! the task's blocks first; nz = 1 for 2-d fields, nz*nt for 4-d ones (cice_halo_update_blocked_*).
+   subroutine update_r8(array, n1, n2, nz, nlast, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: n1, n2, nz, nlast, fieldLoc, fieldKind
+      real (dbl_kind), intent(inout) :: array(*)
       type (ice_halo), intent(in) :: halo
       character (*), intent(in) :: who
       real (dbl_kind), intent(in), optional :: fillValue
       real (c_double) :: fill
-      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
-      if (nlev < 1) return
+      if (n1 /= nx_block .or. n2 /= ny_block) call abort_ice(who//': horizontal extent is not (nx_block,ny_block)')
+      if (nlast < halo%numBlocks) call abort_ice(who//': fewer blocks in the array than on this task')
+      if (nz < 1 .or. halo%numBlocks < 1) return
       fill = 0.0_c_double
       if (present(fillValue)) fill = fillValue
-      call cice_gpu_check(cice_halo_update_ex_r8(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
-   end subroutine update_levels_r8
+      call cice_gpu_check(cice_halo_update_blocked_r8(cice_gpu_ctx, array, nz, fieldLoc, fieldKind, fill), who)
+   end subroutine update_r8
 
-   subroutine update_levels_r4(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
-      real (real_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+   subroutine update_r4(array, n1, n2, nz, nlast, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: n1, n2, nz, nlast, fieldLoc, fieldKind
+      real (real_kind), intent(inout) :: array(*)
       type (ice_halo), intent(in) :: halo
       character (*), intent(in) :: who
       real (real_kind), intent(in), optional :: fillValue
       real (c_float) :: fill
-      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
-      if (nlev < 1) return
+      if (n1 /= nx_block .or. n2 /= ny_block) call abort_ice(who//': horizontal extent is not (nx_block,ny_block)')
+      if (nlast < halo%numBlocks) call abort_ice(who//': fewer blocks in the array than on this task')
+      if (nz < 1 .or. halo%numBlocks < 1) return
       fill = 0.0_c_float
       if (present(fillValue)) fill = fillValue
-      call cice_gpu_check(cice_halo_update_ex_r4(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
-   end subroutine update_levels_r4
+      call cice_gpu_check(cice_halo_update_blocked_r4(cice_gpu_ctx, array, nz, fieldLoc, fieldKind, fill), who)
+   end subroutine update_r4
 
-   subroutine update_levels_i4(buf, nblk, nlev, halo, who, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), intent(in) :: nblk, nlev, fieldLoc, fieldKind
-      integer (int_kind), intent(inout) :: buf(nx_block,ny_block,nblk,nlev)
+   subroutine update_i4(array, n1, n2, nz, nlast, halo, who, fieldLoc, fieldKind, fillValue)
+      integer (int_kind), intent(in) :: n1, n2, nz, nlast, fieldLoc, fieldKind
+      integer (int_kind), intent(inout) :: array(*)
       type (ice_halo), intent(in) :: halo
       character (*), intent(in) :: who
       integer (int_kind), intent(in), optional :: fillValue
       integer (c_int) :: fill
-      if (nblk /= halo%numBlocks) call abort_ice(who//': block dimension differs from the halo')
-      if (nlev < 1) return
+      if (n1 /= nx_block .or. n2 /= ny_block) call abort_ice(who//': horizontal extent is not (nx_block,ny_block)')
+      if (nlast < halo%numBlocks) call abort_ice(who//': fewer blocks in the array than on this task')
+      if (nz < 1 .or. halo%numBlocks < 1) return
       fill = 0
       if (present(fillValue)) fill = fillValue
-      call cice_gpu_check(cice_halo_update_ex_i4(cice_gpu_ctx, buf, nlev, fieldLoc, fieldKind, fill), who)
-   end subroutine update_levels_i4
-
-   ! arrays are dimensioned max_blocks in their last dimension; this task's blocks are the first numBlocks
-   integer (int_kind) function local_blocks(halo, nlast, who)
-      type (ice_halo), intent(in) :: halo
-      integer (int_kind), intent(in) :: nlast
-      character (*), intent(in) :: who
-      if (nlast < halo%numBlocks) call abort_ice(who//': fewer blocks in the array than on this task')
-      local_blocks = halo%numBlocks
-   end function local_blocks
-
-   subroutine check_shape(n1, n2, who)
-      integer (int_kind), intent(in) :: n1, n2
-      character (*), intent(in) :: who
-      if (n1 /= nx_block .or. n2 /= ny_block) &
-         call abort_ice(who//': horizontal extent is not (nx_block,ny_block)')
-   end subroutine check_shape
+      call cice_gpu_check(cice_halo_update_blocked_i4(cice_gpu_ctx, array, nz, fieldLoc, fieldKind, fill), who)
+   end subroutine update_i4
 
 !=======================================================================
-! 2-d fields: (nx_block,ny_block,nblocks)
+! The nine specifics of the generic ice_HaloUpdate: 2-d (nx,ny,blocks), 3-d (nx,ny,nz,blocks), 4-d (nx,ny,nz,nt,blocks)
    subroutine ice_HaloUpdate2DR8(array, halo, fieldLoc, fieldKind, fillValue)
-      real (dbl_kind), dimension(:,:,:), intent(inout) :: array
+      real (dbl_kind), dimension(:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (dbl_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR8')
-      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR8')
-      allocate(buf(nx_block,ny_block,nb,1))
-      buf(:,:,:,1) = array(:,:,1:nb)
-      call update_levels_r8(buf, nb, 1, halo, 'ice_HaloUpdate2DR8', fieldLoc, fieldKind, fillValue)
-      array(:,:,1:nb) = buf(:,:,:,1)
+      call update_r8(array, size(array,1), size(array,2), 1, size(array,3), halo, 'ice_HaloUpdate2DR8', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate2DR8
 
    subroutine ice_HaloUpdate2DR4(array, halo, fieldLoc, fieldKind, fillValue)
-      real (real_kind), dimension(:,:,:), intent(inout) :: array
+      real (real_kind), dimension(:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (real_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DR4')
-      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DR4')
-      allocate(buf(nx_block,ny_block,nb,1))
-      buf(:,:,:,1) = array(:,:,1:nb)
-      call update_levels_r4(buf, nb, 1, halo, 'ice_HaloUpdate2DR4', fieldLoc, fieldKind, fillValue)
-      array(:,:,1:nb) = buf(:,:,:,1)
+      call update_r4(array, size(array,1), size(array,2), 1, size(array,3), halo, 'ice_HaloUpdate2DR4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate2DR4
 
    subroutine ice_HaloUpdate2DI4(array, halo, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), dimension(:,:,:), intent(inout) :: array
+      integer (int_kind), dimension(:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       integer (int_kind), intent(in), optional :: fillValue
-      integer (int_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate2DI4')
-      nb = local_blocks(halo, size(array,3), 'ice_HaloUpdate2DI4')
-      allocate(buf(nx_block,ny_block,nb,1))
-      buf(:,:,:,1) = array(:,:,1:nb)
-      call update_levels_i4(buf, nb, 1, halo, 'ice_HaloUpdate2DI4', fieldLoc, fieldKind, fillValue)
-      array(:,:,1:nb) = buf(:,:,:,1)
+      call update_i4(array, size(array,1), size(array,2), 1, size(array,3), halo, 'ice_HaloUpdate2DI4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate2DI4
 
-!=======================================================================
-! 3-d fields: (nx_block,ny_block,nz,nblocks) -- all levels in ONE device update
    subroutine ice_HaloUpdate3DR8(array, halo, fieldLoc, fieldKind, fillValue)
-      real (dbl_kind), dimension(:,:,:,:), intent(inout) :: array
+      real (dbl_kind), dimension(:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (dbl_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, n, nz, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR8')
-      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DR8')
-      allocate(buf(nx_block,ny_block,nb,nz))
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,k) = array(:,:,k,n)
-      enddo
-      enddo
-      call update_levels_r8(buf, nb, nz, halo, 'ice_HaloUpdate3DR8', fieldLoc, fieldKind, fillValue)
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,n) = buf(:,:,n,k)
-      enddo
-      enddo
+      call update_r8(array, size(array,1), size(array,2), size(array,3), size(array,4), halo, 'ice_HaloUpdate3DR8', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate3DR8
 
    subroutine ice_HaloUpdate3DR4(array, halo, fieldLoc, fieldKind, fillValue)
-      real (real_kind), dimension(:,:,:,:), intent(inout) :: array
+      real (real_kind), dimension(:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (real_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, n, nz, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DR4')
-      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DR4')
-      allocate(buf(nx_block,ny_block,nb,nz))
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,k) = array(:,:,k,n)
-      enddo
-      enddo
-      call update_levels_r4(buf, nb, nz, halo, 'ice_HaloUpdate3DR4', fieldLoc, fieldKind, fillValue)
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,n) = buf(:,:,n,k)
-      enddo
-      enddo
+      call update_r4(array, size(array,1), size(array,2), size(array,3), size(array,4), halo, 'ice_HaloUpdate3DR4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate3DR4
 
    subroutine ice_HaloUpdate3DI4(array, halo, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), dimension(:,:,:,:), intent(inout) :: array
+      integer (int_kind), dimension(:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       integer (int_kind), intent(in), optional :: fillValue
-      integer (int_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, n, nz, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate3DI4')
-      nz = size(array,3); nb = local_blocks(halo, size(array,4), 'ice_HaloUpdate3DI4')
-      allocate(buf(nx_block,ny_block,nb,nz))
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,k) = array(:,:,k,n)
-      enddo
-      enddo
-      call update_levels_i4(buf, nb, nz, halo, 'ice_HaloUpdate3DI4', fieldLoc, fieldKind, fillValue)
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,n) = buf(:,:,n,k)
-      enddo
-      enddo
+      call update_i4(array, size(array,1), size(array,2), size(array,3), size(array,4), halo, 'ice_HaloUpdate3DI4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate3DI4
 
-!=======================================================================
-! 4-d fields: (nx_block,ny_block,nz,nt,nblocks) -- nz*nt levels in ONE device update
    subroutine ice_HaloUpdate4DR8(array, halo, fieldLoc, fieldKind, fillValue)
-      real (dbl_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      real (dbl_kind), dimension(:,:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (dbl_kind), intent(in), optional :: fillValue
-      real (dbl_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, l, n, nz, nt, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR8')
-      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DR8')
-      allocate(buf(nx_block,ny_block,nb,nz*nt))
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
-      enddo
-      enddo
-      enddo
-      call update_levels_r8(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR8', fieldLoc, fieldKind, fillValue)
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
-      enddo
-      enddo
-      enddo
+      call update_r8(array, size(array,1), size(array,2), size(array,3)*size(array,4), size(array,5), halo, 'ice_HaloUpdate4DR8', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate4DR8
 
    subroutine ice_HaloUpdate4DR4(array, halo, fieldLoc, fieldKind, fillValue)
-      real (real_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      real (real_kind), dimension(:,:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (real_kind), intent(in), optional :: fillValue
-      real (real_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, l, n, nz, nt, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DR4')
-      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DR4')
-      allocate(buf(nx_block,ny_block,nb,nz*nt))
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
-      enddo
-      enddo
-      enddo
-      call update_levels_r4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DR4', fieldLoc, fieldKind, fillValue)
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
-      enddo
-      enddo
-      enddo
+      call update_r4(array, size(array,1), size(array,2), size(array,3)*size(array,4), size(array,5), halo, 'ice_HaloUpdate4DR4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate4DR4
 
    subroutine ice_HaloUpdate4DI4(array, halo, fieldLoc, fieldKind, fillValue)
-      integer (int_kind), dimension(:,:,:,:,:), intent(inout) :: array
+      integer (int_kind), dimension(:,:,:,:,:), intent(inout), contiguous :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       integer (int_kind), intent(in), optional :: fillValue
-      integer (int_kind), allocatable :: buf(:,:,:,:)
-      integer (int_kind) :: k, l, n, nz, nt, nb
-      call check_shape(size(array,1), size(array,2), 'ice_HaloUpdate4DI4')
-      nz = size(array,3); nt = size(array,4); nb = local_blocks(halo, size(array,5), 'ice_HaloUpdate4DI4')
-      allocate(buf(nx_block,ny_block,nb,nz*nt))
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         buf(:,:,n,(l-1)*nz+k) = array(:,:,k,l,n)
-      enddo
-      enddo
-      enddo
-      call update_levels_i4(buf, nb, nz*nt, halo, 'ice_HaloUpdate4DI4', fieldLoc, fieldKind, fillValue)
-      do l = 1, nt
-      do k = 1, nz
-      do n = 1, nb
-         array(:,:,k,l,n) = buf(:,:,n,(l-1)*nz+k)
-      enddo
-      enddo
-      enddo
+      call update_i4(array, size(array,1), size(array,2), size(array,3)*size(array,4), size(array,5), halo, 'ice_HaloUpdate4DI4', &
+                     fieldLoc, fieldKind, fillValue)
    end subroutine ice_HaloUpdate4DI4
 
 !=======================================================================

@@ -225,6 +225,12 @@ int cice_halo_update_dev_i4(cice_ctx *ctx, int32_t *dev_field, int nlev);
 int cice_halo_update_ex_r8(cice_ctx *ctx, double *field, int nlev, int loc, int kind, double fill);
 int cice_halo_update_ex_r4(cice_ctx *ctx, float *field, int nlev, int loc, int kind, float fill);
 int cice_halo_update_ex_i4(cice_ctx *ctx, int32_t *field, int nlev, int loc, int kind, int32_t fill);
+/* ... and for a host field in the array layout ice_HaloUpdate3D/4D receive, (nx_block, ny_block, nz, nblocks) with the
+ * block index last (nz = product of the level dimensions; the task's blocks are the first ones): no repacking on the
+ * host, strided copies to the device's level-major layout instead. */
+int cice_halo_update_blocked_r8(cice_ctx *ctx, double *field, int nz, int loc, int kind, double fill);
+int cice_halo_update_blocked_r4(cice_ctx *ctx, float *field, int nz, int loc, int kind, float fill);
+int cice_halo_update_blocked_i4(cice_ctx *ctx, int32_t *field, int nz, int loc, int kind, int32_t fill);
 int cice_halo_update_dev_ex_r8(cice_ctx *ctx, double *dev_field, int nlev, int loc, int kind, double fill);
 /* Device memory on the context's GPU for such resident fields, and blocking copies ordered on the library's stream. */
 int cice_device_alloc(cice_ctx *ctx, size_t bytes, void **dev);
