@@ -5,8 +5,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <algorithm>
 #include <string>
 #include <type_traits>
+#include <vector>
 
 #include "common.h"
 #include "domain.h"
@@ -30,7 +32,50 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
-  std::vector<void*> pinned;   // cice_host_register
+  // Page-locked host ranges of this context: [start, end) in bytes, disjoint.  One manager for the explicit
+  // registrations (cice_host_register, cice_evp_pin_fields): a new range that touches registered ones is registered
+  // as their union (a whole array after some of its slices), because a copy whose host range is partly registered
+  // is refused by the runtime.  CICE4_AMD_PIN=0 in the environment leaves everything pageable (diagnostic).
+  // Exact byte ranges, not page-rounded, for the same reason (a neighbouring variable sharing the last page).
+  std::vector<std::pair<uintptr_t, uintptr_t>> pin_ranges;
+  std::vector<std::pair<uintptr_t, uintptr_t>> pin_refused;  // ranges hipHostRegister turned down (not retried)
+  void pin_range(const void* p, size_t bytes) {
+    if (!p || !bytes) return;
+    static const bool off = [] { const char* e = std::getenv("CICE4_AMD_PIN"); return e && e[0] == '0'; }();
+    if (off) return;
+    uintptr_t lo = (uintptr_t)p, hi = (uintptr_t)p + bytes;
+    for (const auto& r : pin_ranges)
+      if (lo >= r.first && hi <= r.second) return;            // already inside a registered range
+    for (const auto& r : pin_refused)
+      if (lo >= r.first && hi <= r.second) return;
+    bool drained = false;
+    for (size_t k = 0; k < pin_ranges.size();) {
+      if (pin_ranges[k].first <= hi && lo <= pin_ranges[k].second) {
+        lo = std::min(lo, pin_ranges[k].first);
+        hi = std::max(hi, pin_ranges[k].second);
+        if (!drained) {                                       // no copy may be in flight on a range being released
+          (void)hipDeviceSynchronize();
+          drained = true;
+        }
+        if (hipHostUnregister((void*)pin_ranges[k].first) != hipSuccess) (void)hipGetLastError();
+        pin_ranges.erase(pin_ranges.begin() + k);
+      } else {
+        ++k;
+      }
+    }
+    if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
+      pin_ranges.push_back({lo, hi});
+    } else {   // registered by somebody else, or not registrable: stays pageable
+      (void)hipGetLastError();
+      pin_refused.push_back({lo, hi});
+    }
+  }
+  void unpin_all() {
+    for (const auto& r : pin_ranges)
+      if (hipHostUnregister((void*)r.first) != hipSuccess) (void)hipGetLastError();
+    pin_ranges.clear();
+    pin_refused.clear();
+  }
   // staging of the host-pointer entries (thermo_vertical is called ncat x nblocks times per step with
   // the same block size: allocated once, grown only when a larger block comes along)
   DevBuf<double> tv_stage, fz_stage, halo_stage;
@@ -214,8 +259,7 @@ int cice_host_register(cice_ctx* ctx, void* host, size_t bytes) {
   CICE_TRY(ctx)
   CICE_REQUIRE(host && bytes, "NULL array");
   c_->need_device();
-  if (hipHostRegister(host, bytes, hipHostRegisterDefault) == hipSuccess) c_->pinned.push_back(host);
-  else (void)hipGetLastError();   // already registered, or not registrable: stays pageable
+  c_->pin_range(host, bytes);
   CICE_CATCH
 }
 
@@ -225,16 +269,13 @@ int cice_host_register(cice_ctx* ctx, void* host, size_t bytes) {
 int cice_host_unregister_all(cice_ctx* ctx) {
   CICE_TRY(ctx)
   if (c_->stream) CICE_HIP(hipStreamSynchronize(c_->stream));
-  for (void* h : c_->pinned)
-    if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
-  c_->pinned.clear();
+  c_->unpin_all();
   CICE_CATCH
 }
 
 int cice_destroy(cice_ctx* ctx) {
   if (!ctx) return CICE_EINVAL;
-  for (void* h : ctx->pinned)
-    if (hipHostUnregister(h) != hipSuccess) (void)hipGetLastError();
+  ctx->unpin_all();
   ctx->evp.reset();
   ctx->transport.reset();
   ctx->halo.reset();
@@ -477,13 +518,7 @@ int cice_evp_pin_fields(cice_ctx* ctx, const cice_evp_fields* f) {
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
   const size_t n = (size_t)c_->dom.nblocks() * c_->dom.nx_block * c_->dom.ny_block;
-  auto pin = [&](const void* h, size_t bytes) {
-    if (!h) return;
-    if (hipHostRegister(const_cast<void*>(h), bytes, hipHostRegisterDefault) == hipSuccess)
-      c_->pinned.push_back(const_cast<void*>(h));
-    else
-      (void)hipGetLastError();
-  };
+  auto pin = [&](const void* h, size_t bytes) { c_->pin_range(h, bytes); };
   const double* r8[] = {f->aice, f->vice, f->vsno, f->aice0, f->strairxT, f->strairyT, f->uocn, f->vocn,
                         f->ss_tltx, f->ss_tlty, f->uvel, f->vvel, f->stressp_1, f->stressp_2, f->stressp_3,
                         f->stressp_4, f->stressm_1, f->stressm_2, f->stressm_3, f->stressm_4, f->stress12_1,
@@ -696,7 +731,9 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
     CICE_HIP(hipMemcpyAsync(d.p + (size_t)plane * np, h, (size_t)planes * np * 8, hipMemcpyHostToDevice, s));
   };
-  up(A_AICEN, aicen); up(A_TRCRN, trcrn, NTRCR); up(A_VICEN, vicen); up(A_VSNON, vsnon);
+  // of the tracers only Tsfc is read and written by the column physics (:137-142, :508-513)
+  const int it_T = c_->tp.nt_Tsfc - 1;
+  up(A_AICEN, aicen); up(A_TRCRN + it_T, trcrn + (size_t)it_T * np); up(A_VICEN, vicen); up(A_VSNON, vsnon);
   up(A_EICEN, eicen, NILYR); up(A_ESNON, esnon, NSLYR);
   up(A_FLW, flw); up(A_POTT, potT); up(A_QA, Qa); up(A_RHOA, rhoa); up(A_FSNOW, fsnow);
   up(A_FBOT, fbot); up(A_TBOT, Tbot); up(A_LH, lhcoef); up(A_SH, shcoef);
@@ -733,7 +770,7 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
     CICE_HIP(hipMemcpyAsync(h, d.p + (size_t)plane * np, (size_t)planes * np * 8, hipMemcpyDeviceToHost, s));
   };
-  down(A_AICEN, aicen); down(A_TRCRN, trcrn, NTRCR); down(A_VICEN, vicen); down(A_VSNON, vsnon);
+  down(A_AICEN, aicen); down(A_TRCRN + it_T, trcrn + (size_t)it_T * np); down(A_VICEN, vicen); down(A_VSNON, vsnon);
   down(A_EICEN, eicen, NILYR); down(A_ESNON, esnon, NSLYR);
   down(A_FSWSFC, fswsfc); down(A_FSWINT, fswint); down(A_SSW, Sswabs, NSLYR); down(A_ISW, Iswabs, NILYR);
   double* houts[15] = {fsurfn, fcondtopn, fsensn, flatn, fswabsn, flwoutn, evapn, freshn, fsaltn,

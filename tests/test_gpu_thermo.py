@@ -361,3 +361,4 @@ def test_fortran_dropin_thermo_module(orc):
             np.full((ny, nx), -1.8), rng.uniform(-0.2, 0.2, (ny, nx)), rng.uniform(-0.2, 0.2, (ny, nx)))
     for x, y, nm in zip(ref.frzmlt_bottom_lateral(*args), orc.frzmlt_bottom_lateral(*args), ("Tbot", "fbot", "rside")):
         assert relerr(x, y) <= TOL_POW, nm
+
