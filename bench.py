@@ -612,7 +612,9 @@ def main():
                   rside=np.zeros((nb, ny, nx)))
         pc = {k: np.zeros(tb["aicen"].shape) for k in ("strairxn", "strairyn", "Trefn", "Qrefn")}
         acc = {k: np.zeros((nb, ny, nx)) for k in lib.MERGE_ORDER}
-        keep = [tb, fz, pc, acc]
+        atm = dict(uatm=np.full((nb, ny, nx), 5.0), vatm=np.full((nb, ny, nx), 5.0), wind=np.full((nb, ny, nx), 50.0 ** 0.5),
+                   zlvl=np.full((nb, ny, nx), 10.0))
+        keep = [tb, fz, pc, acc, atm]
         for d in keep:
             for v in d.values():
                 if isinstance(v, np.ndarray):
@@ -625,14 +627,23 @@ def main():
             t1 = time.perf_counter()
             st = ctx.step_therm1(DT, 150.0, tb, fz, pc, acc)
             times.append(time.perf_counter() - t1)
+        times_abl = []
+        for _ in range(3):     # the same with atmo_boundary_layer on the device: 26 planes fewer to upload
+            for k, v in state0.items():
+                tb[k][...] = v
+            t1 = time.perf_counter()
+            st_abl = ctx.step_therm1(DT, 150.0, tb, fz, {}, acc, atm=atm)
+            times_abl.append(time.perf_counter() - t1)
         ctx.host_unregister_all()
-        del keep, tb, fz, pc, acc
+        del keep, tb, fz, pc, acc, atm
         if not st["l_stop"]:
             pcie["step_therm1"] = {"what": "cice_step_therm1: ONE upload (state, forcing, shortwave, per-category atmo outputs, "
                                            "20 accumulators ~ 150 planes), frzmlt_bottom_lateral + thermo_vertical x 5 categories + "
                                            "merge_fluxes on the device, ONE download (~80 planes: state, shortwave, the per-category module arrays, accumulators, Tbot/fbot/rside); page-locked host arrays",
                                    "ms_per_call": 1e3 * min(times[1:]), "column_updates": st["n_updates"],
                                    "updates_per_s": st["n_updates"] / min(times[1:])}
+            if not st_abl["l_stop"]:
+                pcie["step_therm1"]["with_atmo_boundary_layer_on_device_ms"] = 1e3 * min(times_abl[1:])
             pcie["therm1_plus_evp_ms"] = pcie["ms_per_call"] + pcie["step_therm1"]["ms_per_call"]
             pcie["resident_ms"] = 1e3 * m["t_evp"] / args.steps + thermo["ms_per_pass"]
 

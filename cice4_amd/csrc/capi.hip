@@ -14,6 +14,7 @@
 #include "domain.h"
 #include "evp.h"
 #include "halo.h"
+#include "atmo.h"
 #include "therm.h"
 #include "transport.h"
 
@@ -91,6 +92,7 @@ struct cice_ctx {
     DevBuf<double> aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot,
         lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, out15, mlt_onset, frz_onset;
     DevBuf<double> mrg_in, mrg_acc, fz_in;   // merge_fluxes inputs / accumulators, frzmlt inputs + rside
+    DevBuf<double> atm_in;                   // uatm, vatm, wind, zlvl, strax, stray (cice_step_therm1_abl)
     std::vector<int32_t> hblk;               // ilo, ihi, jlo, jhi per block (host copy of blk)
   } tb;
   // device is required lazily: domain queries work on a CPU-only host
@@ -818,7 +820,7 @@ int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
   CICE_CATCH
 }
 
-static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fbot_tbot) {
+static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fbot_tbot, bool with_coef = true) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
   struct U { DevBuf<double>* d; const double* h; };
@@ -830,6 +832,7 @@ static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fb
             {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset}, {&t.frz_onset, h->frz_onset}};
   for (U& x : us) {
     if (!with_fbot_tbot && (x.d == &t.fbot || x.d == &t.Tbot)) continue;   // produced on the device
+    if (!with_coef && (x.d == &t.lhcoef || x.d == &t.shcoef)) continue;    // likewise (atmo_boundary_layer)
     CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
     x.d->upload(x.h, c_->stream);
   }
@@ -934,7 +937,8 @@ int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
 
 // aicen_init_dev: device copy of the initial concentrations (cice_step_therm1 keeps one); otherwise
 // f->aicen_init is uploaded
-static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* aicen_init_dev) {
+static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* aicen_init_dev,
+                        bool atmo_on_device = false) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && f, "cice_thermo_batch_alloc has not been called");
   hipStream_t s = c_->stream;
@@ -943,6 +947,7 @@ static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* 
   const double* hin[5] = {f->aicen_init, f->strairxn, f->strairyn, f->Trefn, f->Qrefn};
   for (int k = 0; k < 5; ++k) {
     if (k == 0 && aicen_init_dev) continue;
+    if (k > 0 && atmo_on_device) continue;    // strairxn, strairyn, Trefn, Qrefn were produced in place
     CICE_REQUIRE(hin[k] != nullptr, "cice_thermo_batch_merge: NULL input");
     CICE_HIP(hipMemcpyAsync(up.p + (size_t)k * nc, hin[k], nc * 8, hipMemcpyHostToDevice, s));
   }
@@ -979,10 +984,9 @@ int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
 // drivers/cice4/CICE_RunMod.F90:260-598, minus atmo_boundary_layer, whose per-category outputs are inputs
 // here): ONE upload, frzmlt_bottom_lateral (:363) -> thermo_vertical for every category (:502) ->
 // merge_fluxes (:565) on the device, ONE download, one synchronisation.
-int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* st,
-                     const cice_frzmlt_fields* fz, const cice_merge_fields* mg, long long* n_updates,
-                     int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop, int32_t* bstop) {
-  CICE_TRY(ctx)
+static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields* st, const cice_frzmlt_fields* fz,
+                        const cice_merge_fields* mg, const cice_atmo_fields* atm, long long* n_updates,
+                        int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop, int32_t* bstop) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
   CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
@@ -990,7 +994,25 @@ int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* 
   CICE_REQUIRE(fz->aice && fz->frzmlt && fz->sst && fz->Tf && fz->strocnxT && fz->strocnyT, "NULL frzmlt input");
   hipStream_t s = c_->stream;
   const size_t np = (size_t)t.nx * t.ny, n2 = np * t.nb, nc = n2 * NCAT;
-  batch_upload(c_, st, false);
+  batch_upload(c_, st, false, atm == nullptr);
+  if (atm) {   // atmo_boundary_layer for every category (CICE_RunMod.F90:402-425), on the state before the update
+    CICE_REQUIRE(atm->uatm && atm->vatm && atm->wind && atm->zlvl, "NULL atmosphere input");
+    CICE_REQUIRE(atm->calc_strair || (atm->strax && atm->stray), "calc_strair = F needs strax, stray");
+    if (t.atm_in.n < 6 * n2) t.atm_in.alloc(6 * n2);
+    const double* ain[6] = {atm->uatm, atm->vatm, atm->wind, atm->zlvl, atm->strax, atm->stray};
+    for (int k = 0; k < (atm->calc_strair ? 4 : 6); ++k)
+      CICE_HIP(hipMemcpyAsync(t.atm_in.p + (size_t)k * n2, ain[k], n2 * 8, hipMemcpyHostToDevice, s));
+    AtmoArgs a{};
+    a.p.init();
+    a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.ocn = 0; a.calc_strair = atm->calc_strair != 0;
+    a.blk = t.blk.p; a.aicen = t.aicen.p; a.Tsf = t.trcrn.p; a.it_Tsfc = c_->tp.nt_Tsfc - 1;
+    a.potT = t.potT.p; a.Qa = t.Qa.p; a.rhoa = t.rhoa.p;
+    a.uatm = t.atm_in.p; a.vatm = t.atm_in.p + n2; a.wind = t.atm_in.p + 2 * n2; a.zlvl = t.atm_in.p + 3 * n2;
+    a.strax = t.atm_in.p + 4 * n2; a.stray = t.atm_in.p + 5 * n2;
+    a.strx = t.mrg_in.p + nc; a.stry = t.mrg_in.p + 2 * nc; a.Tref = t.mrg_in.p + 3 * nc; a.Qref = t.mrg_in.p + 4 * nc;
+    a.lhcoef = t.lhcoef.p; a.shcoef = t.shcoef.p;
+    atmo_launch_dense(a, s);
+  }
   const double* fin[6] = {fz->aice, fz->frzmlt, fz->sst, fz->Tf, fz->strocnxT, fz->strocnyT};
   for (int k = 0; k < 6; ++k)
     CICE_HIP(hipMemcpyAsync(t.fz_in.p + (size_t)k * n2, fin[k], n2 * 8, hipMemcpyHostToDevice, s));
@@ -1009,14 +1031,84 @@ int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* 
   CICE_HIP(hipMemcpyAsync(t.mrg_in.p, t.aicen.p, nc * 8, hipMemcpyDeviceToDevice, s));
   unsigned long long h[2];
   batch_step(c_, dt, yday, h, nullptr, nullptr);
-  batch_merge(c_, mg, t.mrg_in.p);
+  batch_merge(c_, mg, t.mrg_in.p, atm != nullptr);
   batch_download(c_, st);
+  if (atm) {
+    double* aout[6] = {atm->strairxn, atm->strairyn, atm->Trefn, atm->Qrefn, atm->lhcoef, atm->shcoef};
+    const double* asrc[6] = {t.mrg_in.p + nc, t.mrg_in.p + 2 * nc, t.mrg_in.p + 3 * nc, t.mrg_in.p + 4 * nc,
+                             t.lhcoef.p, t.shcoef.p};
+    for (int k = 0; k < 6; ++k)
+      if (aout[k]) CICE_HIP(hipMemcpyAsync(aout[k], asrc[k], nc * 8, hipMemcpyDeviceToHost, s));
+  }
   if (fz->Tbot) t.Tbot.download(fz->Tbot, s);
   if (fz->fbot) t.fbot.download(fz->fbot, s);
   if (fz->rside) CICE_HIP(hipMemcpyAsync(fz->rside, t.fz_in.p + 6 * n2, n2 * 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipStreamSynchronize(s));
   if (n_updates) *n_updates = (long long)h[1];
   decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
+}
+
+int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* st,
+                     const cice_frzmlt_fields* fz, const cice_merge_fields* mg, long long* n_updates,
+                     int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop, int32_t* bstop) {
+  CICE_TRY(ctx)
+  step_therm1(c_, dt, yday, st, fz, mg, nullptr, n_updates, l_stop, istop, jstop, nstop, bstop);
+  CICE_CATCH
+}
+
+// ... with atmo_boundary_layer on the device as well: lhcoef / shcoef of `st` and the four atmosphere fields of `mg`
+// are not read; what the routine produced comes back through `atm` where asked for.
+int cice_step_therm1_abl(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* st,
+                         const cice_frzmlt_fields* fz, const cice_merge_fields* mg, const cice_atmo_fields* atm,
+                         long long* n_updates, int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
+                         int32_t* bstop) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(atm != nullptr, "NULL argument");
+  step_therm1(c_, dt, yday, st, fz, mg, atm, n_updates, l_stop, istop, jstop, nstop, bstop);
+  CICE_CATCH
+}
+
+// atmo_boundary_layer (source/ice_atmo.F90:56-384), one block, host pointers, the reference's argument list
+// (sfctype: 0 'ice', 1 'ocn'; calc_strair is the module variable of ice_atmo).
+int cice_atmo_boundary_layer(cice_ctx* ctx, int nx, int ny, int sfctype, int icells, const int32_t* indxi,
+                             const int32_t* indxj, const double* Tsf, const double* potT, const double* uatm,
+                             const double* vatm, const double* wind, const double* zlvl, const double* Qa,
+                             const double* rhoa, int calc_strair, double* strx, double* stry, double* Tref,
+                             double* Qref, double* delt, double* delq, double* lhcoef, double* shcoef) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(nx >= 1 && ny >= 1 && icells >= 0 && (size_t)icells <= (size_t)nx * ny, "bad dimensions");
+  CICE_REQUIRE(sfctype == 0 || sfctype == 1, "sfctype: 0 'ice' or 1 'ocn'");
+  CICE_REQUIRE(Tsf && potT && uatm && vatm && wind && zlvl && Qa && rhoa && strx && stry && Tref && Qref && delt &&
+                   delq && lhcoef && shcoef && (icells == 0 || (indxi && indxj)), "atmo_boundary_layer: NULL array");
+  c_->need_device();
+  hipStream_t s = c_->stream;
+  const size_t np = (size_t)nx * ny;
+  DevBuf<double>& d = c_->fz_stage;
+  if (d.n < 16 * np) d.alloc(16 * np);
+  DevBuf<int32_t>& li = c_->tv_list;
+  if (li.n < 2 * np) li.alloc(2 * np);
+  const double* in[8] = {Tsf, potT, uatm, vatm, wind, zlvl, Qa, rhoa};
+  for (int k = 0; k < 8; ++k) CICE_HIP(hipMemcpyAsync(d.p + (size_t)k * np, in[k], np * 8, hipMemcpyHostToDevice, s));
+  if (!calc_strair) {   // strx, stry are left as they are (:309)
+    CICE_HIP(hipMemcpyAsync(d.p + 8 * np, strx, np * 8, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(d.p + 9 * np, stry, np * 8, hipMemcpyHostToDevice, s));
+  }
+  if (icells > 0) {
+    CICE_HIP(hipMemcpyAsync(li.p, indxi, (size_t)icells * 4, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, s));
+  }
+  AtmoArgs a{};
+  a.p.init();
+  a.nx = nx; a.ny = ny; a.ncat = 1; a.nblocks = 1; a.ocn = sfctype; a.calc_strair = calc_strair != 0;
+  a.icells = icells; a.indxi = li.p; a.indxj = li.p + np;
+  a.Tsf = d.p; a.potT = d.p + np; a.uatm = d.p + 2 * np; a.vatm = d.p + 3 * np; a.wind = d.p + 4 * np;
+  a.zlvl = d.p + 5 * np; a.Qa = d.p + 6 * np; a.rhoa = d.p + 7 * np;
+  double* out[8] = {strx, stry, Tref, Qref, delt, delq, lhcoef, shcoef};
+  double** dev[8] = {&a.strx, &a.stry, &a.Tref, &a.Qref, &a.delt, &a.delq, &a.lhcoef, &a.shcoef};
+  for (int k = 0; k < 8; ++k) *dev[k] = d.p + (size_t)(8 + k) * np;
+  atmo_launch_list(a, s);
+  for (int k = 0; k < 8; ++k) CICE_HIP(hipMemcpyAsync(out[k], *dev[k], np * 8, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipStreamSynchronize(s));
   CICE_CATCH
 }
 

@@ -76,7 +76,40 @@ module cice4_amd_c
       type(c_ptr) :: acc(20)
    end type
 
+   ! atmo_boundary_layer on the device inside the one-call half-step (cice_step_therm1_abl)
+   type, bind(C) :: cice_atmo_fields
+      type(c_ptr) :: uatm, vatm, wind, zlvl
+      type(c_ptr) :: strax = c_null_ptr, stray = c_null_ptr
+      integer(c_int) :: calc_strair = 1
+      type(c_ptr) :: strairxn = c_null_ptr, strairyn = c_null_ptr, Trefn = c_null_ptr, Qrefn = c_null_ptr, &
+                     lhcoef = c_null_ptr, shcoef = c_null_ptr
+   end type
+
    interface
+      integer(c_int) function cice_step_therm1_abl(ctx, dt, yday, st, fz, mg, atm, n_updates, l_stop, istop, &
+            jstop, nstop, bstop) bind(C, name='cice_step_therm1_abl')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: dt, yday
+         type(cice_thermo_fields), intent(in) :: st
+         type(cice_frzmlt_fields), intent(in) :: fz
+         type(cice_merge_fields), intent(in) :: mg
+         type(cice_atmo_fields), intent(in) :: atm
+         integer(c_long_long), intent(out) :: n_updates
+         integer(c_int), intent(out) :: l_stop, istop, jstop, nstop, bstop
+      end function
+      ! atmo_boundary_layer (source/ice_atmo.F90:56), one block; sfctype 0 'ice', 1 'ocn'
+      integer(c_int) function cice_atmo_boundary_layer(ctx, nx_block, ny_block, sfctype, icells, indxi, indxj, &
+            Tsf, potT, uatm, vatm, wind, zlvl, Qa, rhoa, calc_strair, strx, stry, Tref, Qref, delt, delq, &
+            lhcoef, shcoef) bind(C, name='cice_atmo_boundary_layer')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: nx_block, ny_block, sfctype, icells, calc_strair
+         integer(c_int), intent(in) :: indxi(*), indxj(*)
+         real(c_double), intent(in) :: Tsf(*), potT(*), uatm(*), vatm(*), wind(*), zlvl(*), Qa(*), rhoa(*)
+         real(c_double), intent(inout) :: strx(*), stry(*)
+         real(c_double), intent(out) :: Tref(*), Qref(*), delt(*), delq(*), lhcoef(*), shcoef(*)
+      end function
       integer(c_int) function cice_step_therm1(ctx, dt, yday, st, fz, mg, n_updates, l_stop, istop, jstop, &
             nstop, bstop) bind(C, name='cice_step_therm1')
          import

@@ -84,6 +84,12 @@ class FrzmltFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("aice", "frzmlt", "sst", "Tf", "strocnxT", "strocnyT", "Tbot", "fbot", "rside")]
 
 
+class AtmoFields(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("uatm", "vatm", "wind", "zlvl", "strax", "stray")] + \
+               [("calc_strair", C.c_int)] + \
+               [(n, C.c_void_p) for n in ("strairxn", "strairyn", "Trefn", "Qrefn", "lhcoef", "shcoef")]
+
+
 class ThermoFields(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in THERMO_STATE + THERMO_FORCING + THERMO_CAT_IN + THERMO_SW
                 + THERMO_OUT + THERMO_ONSET]
@@ -490,11 +496,28 @@ class Context:
         self._ck(self.lib.cice_transport_debug(self.h, stop_stage, which, _f8(out), C.byref(cnt)))
         return out
 
-    def step_therm1(self, dt, yday, state, fz, percat, acc):
+    ATMO_OUT = ("strx", "stry", "Tref", "Qref", "delt", "delq", "lhcoef", "shcoef")
+
+    def atmo_boundary_layer(self, sfctype, icells, indxi, indxj, a, calc_strair=True, strx=None, stry=None):
+        """cice_atmo_boundary_layer (source/ice_atmo.F90:56).  a: Tsf, potT, uatm, vatm, wind, zlvl, Qa, rhoa (ny, nx);
+        returns the eight outputs (strx, stry keep the given values when calc_strair is false)."""
+        ny, nx = a["Tsf"].shape
+        o = {k: np.zeros((ny, nx)) for k in self.ATMO_OUT}
+        if strx is not None:
+            o["strx"][...] = strx; o["stry"][...] = stry
+        ins = [np.ascontiguousarray(a[k], np.float64) for k in ("Tsf", "potT", "uatm", "vatm", "wind", "zlvl", "Qa", "rhoa")]
+        self._ck(self.lib.cice_atmo_boundary_layer(
+            self.h, nx, ny, 0 if sfctype == "ice" else 1, icells, _i4(indxi), _i4(indxj), *[_f8(x) for x in ins],
+            int(calc_strair), *[_f8(o[k]) for k in self.ATMO_OUT]))
+        return o
+
+    def step_therm1(self, dt, yday, state, fz, percat, acc, atm=None):
         """cice_step_therm1: one upload, frzmlt_bottom_lateral + thermo_vertical for every category + merge_fluxes on
         the device, one download.  state: thermo_batch_upload's dict (fbot/Tbot not needed); fz: aice, frzmlt, sst,
         Tf, strocnxT, strocnyT (+ optional outputs Tbot, fbot, rside), (nb,ny,nx); percat / acc as thermo_batch_merge
-        (percat['aicen_init'] optional)."""
+        (percat['aicen_init'] optional).  atm (cice_step_therm1_abl): uatm, vatm, wind, zlvl (+ strax, stray and
+        calc_strair=False) -- atmo_boundary_layer runs on the device too, state's lhcoef/shcoef and percat's
+        strairxn/strairyn/Trefn/Qrefn are not read; arrays found in atm under those six names are filled."""
         f = self._thermo_fields(state)
         z = FrzmltFields()
         for n, _t in FrzmltFields._fields_:
@@ -507,8 +530,18 @@ class Context:
             assert acc[n].dtype == np.float64 and acc[n].flags["C_CONTIGUOUS"]
         nupd = C.c_longlong(0)
         st = [C.c_int32(0) for _ in range(5)]
-        self._ck(self.lib.cice_step_therm1(self.h, C.c_double(dt), C.c_double(yday), C.byref(f), C.byref(z), C.byref(m),
-                                           C.byref(nupd), *[C.byref(x) for x in st]))
+        if atm is None:
+            self._ck(self.lib.cice_step_therm1(self.h, C.c_double(dt), C.c_double(yday), C.byref(f), C.byref(z),
+                                               C.byref(m), C.byref(nupd), *[C.byref(x) for x in st]))
+        else:
+            af = AtmoFields()
+            for n, t in AtmoFields._fields_:
+                if n == "calc_strair":
+                    af.calc_strair = int(atm.get("calc_strair", True))
+                else:
+                    setattr(af, n, _f8(atm[n]) if n in atm else None)
+            self._ck(self.lib.cice_step_therm1_abl(self.h, C.c_double(dt), C.c_double(yday), C.byref(f), C.byref(z),
+                                                   C.byref(m), C.byref(af), C.byref(nupd), *[C.byref(x) for x in st]))
         return dict(n_updates=nupd.value, l_stop=st[0].value, istop=st[1].value, jstop=st[2].value,
                     nstop=st[3].value, bstop=st[4].value)
 

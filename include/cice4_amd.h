@@ -320,6 +320,34 @@ int cice_step_therm1(cice_ctx *ctx, double dt, double yday, cice_thermo_fields *
                      const cice_frzmlt_fields *fz, const cice_merge_fields *mg, long long *n_updates,
                      int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop, int32_t *bstop);
 
+/* ... and atmo_boundary_layer (source/ice_atmo.F90:56-384; CICE_RunMod.F90:402-425) on the device too, in front of
+ * thermo_vertical: for every category the cells with aicen > puny, Tsf = trcrn(:,:,nt_Tsfc,n,iblk) before the column
+ * update.  state->lhcoef / shcoef and mg->strairxn / strairyn / Trefn / Qrefn are then NOT read (may be NULL); what
+ * the routine produced is handed back through the six output pointers below where they are non-NULL
+ * ((nx,ny,ncat,nb), zero outside a category's cells).  calc_strair = 0: strairxn/yn = strax/stray (:435-439).
+ * exp is glibc's; log and atan are the device library's (<= 1 ulp), so this stage agrees with the reference to
+ * ~1e-13, not bit for bit (tests/test_gpu_atmo.py) -- the bit-exact configuration is cice_step_therm1. */
+typedef struct {
+  const double *uatm, *vatm, *wind, *zlvl; /* (nx,ny,nb) in */
+  const double *strax, *stray;             /* (nx,ny,nb) in, calc_strair = 0 only */
+  int calc_strair;
+  double *strairxn, *strairyn, *Trefn, *Qrefn, *lhcoef, *shcoef; /* (nx,ny,ncat,nb) out, may be NULL */
+} cice_atmo_fields;
+int cice_step_therm1_abl(cice_ctx *ctx, double dt, double yday, cice_thermo_fields *state,
+                         const cice_frzmlt_fields *fz, const cice_merge_fields *mg, const cice_atmo_fields *atm,
+                         long long *n_updates, int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop,
+                         int32_t *bstop);
+
+/* atmo_boundary_layer (source/ice_atmo.F90:56-384) with the reference's argument list, one block, host pointers:
+ * sfctype 0 = 'ice', 1 = 'ocn'; calc_strair = the module variable of ice_atmo (0: strx, stry are left untouched).
+ * All arrays (nx_block,ny_block); every output is zero outside the list. */
+int cice_atmo_boundary_layer(cice_ctx *ctx, int nx_block, int ny_block, int sfctype, int icells,
+                             const int32_t *indxi, const int32_t *indxj, const double *Tsf, const double *potT,
+                             const double *uatm, const double *vatm, const double *wind, const double *zlvl,
+                             const double *Qa, const double *rhoa, int calc_strair, double *strx, double *stry,
+                             double *Tref, double *Qref, double *delt, double *delq, double *lhcoef,
+                             double *shcoef);
+
 /* frzmlt_bottom_lateral (:605-824), one block, host pointers;
  * eicen (nx,ny,ntilyr), esnon (nx,ny,ntslyr). */
 int cice_frzmlt_bottom_lateral(cice_ctx *ctx, int nx_block, int ny_block, int ilo, int ihi,

@@ -288,6 +288,25 @@ contains
          esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside)
    end subroutine ref_frzmlt_bottom_lateral
 
+   ! atmo_boundary_layer (source/ice_atmo.F90:56), ocn = 0 'ice' / 1 'ocn'; calc_strair is the module variable
+   subroutine ref_atmo_boundary_layer(nx, ny, ocn, icells, indxi, indxj, Tsf, potT, uatm, vatm, wind, zlvl, &
+         Qa, rhoa, calc_strair_in, strx, stry, Tref, Qref, delt, delq, lhcoef, shcoef) &
+         bind(C, name='ref_atmo_boundary_layer')
+      use ice_atmo, only: atmo_boundary_layer, calc_strair
+      integer(c_int), value :: nx, ny, ocn, icells, calc_strair_in
+      integer(c_int), intent(in) :: indxi(nx*ny), indxj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: Tsf, potT, uatm, vatm, wind, zlvl, Qa, rhoa
+      real(c_double), dimension(nx,ny), intent(inout) :: strx, stry
+      real(c_double), dimension(nx,ny), intent(out) :: Tref, Qref, delt, delq, lhcoef, shcoef
+      character(len=3) :: sfctype
+      sfctype = 'ice'
+      if (ocn /= 0) sfctype = 'ocn'
+      calc_strair = (calc_strair_in /= 0)
+      call atmo_boundary_layer(nx, ny, sfctype, icells, indxi, indxj, Tsf, potT, uatm, vatm, wind, zlvl, &
+         Qa, rhoa, strx, stry, Tref, Qref, delt, delq, lhcoef, shcoef)
+      calc_strair = .true.
+   end subroutine ref_atmo_boundary_layer
+
    !--------------------------------------------------------------------
    ! whole-domain set-up (cice_init subset, CICE_InitMod.F90:124-150) so that
    ! evp(dt) can run on the reference's own module arrays, blocks and halos.

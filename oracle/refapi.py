@@ -183,6 +183,20 @@ class Ref:
                                            _p(strocnxT), _p(strocnyT), _p(Tbot), _p(fbot), _p(rside))
         return Tbot, fbot, rside
 
+    ATMO_OUT = ("strx", "stry", "Tref", "Qref", "delt", "delq", "lhcoef", "shcoef")
+
+    def atmo_boundary_layer(self, sfctype, icells, indxi, indxj, a, calc_strair=True, strx=None, stry=None):
+        """a: Tsf, potT, uatm, vatm, wind, zlvl, Qa, rhoa (ny, nx) -> dict of the eight outputs."""
+        ny, nx = a["Tsf"].shape
+        o = {k: np.zeros((ny, nx)) for k in self.ATMO_OUT}
+        if strx is not None:
+            o["strx"][...] = strx; o["stry"][...] = stry
+        self.lib.ref_atmo_boundary_layer(
+            C.c_int(nx), C.c_int(ny), C.c_int(0 if sfctype == "ice" else 1), C.c_int(icells), _p(indxi), _p(indxj),
+            *[_p(np.ascontiguousarray(a[k])) for k in ("Tsf", "potT", "uatm", "vatm", "wind", "zlvl", "Qa", "rhoa")],
+            C.c_int(int(calc_strair)), *[_p(o[k]) for k in self.ATMO_OUT])
+        return o
+
     MERGE_ORDER = ("strairx", "strairy", "fsurf", "fcondtop", "fsens", "flat", "fswabs", "flwout", "evap",
                    "Tref", "Qref", "fresh", "fsalt", "fhocn", "fswthru", "meltt", "meltb", "melts", "congel",
                    "snoice")
