@@ -36,6 +36,8 @@ class Evp {
   bool derives_metrics() const;
   int tile_waves() const { return waves; }
   int tile_rows() const { return rows_per_wave; }
+  bool can_reside() const;   // the whole subcycle loop in one launch, state in registers (k_evp_resident)
+  int resident_waves() const;  // its wavefronts per workgroup (0: grid too large for one tile per CU)
   bool can_fuse() const;     // two subcycles per launch on this domain
   int fused_waves() const;   // wavefronts per workgroup of the fused kernel
 
@@ -62,6 +64,16 @@ class Evp {
   bool fuse_on = true;
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
   mutable int waves2_auto = 0;  // the automatic choice, once made
+  // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
+  bool resident_on = true, resident_failed = false;
+  int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
+  int res_w = 0, res_tiles = 0;  // what res_deps was built for
+  unsigned res_epoch = 0;
+  DevBuf<int32_t> res_deps;
+  DevBuf<unsigned> res_prog;     // [tiles * 32] progress words, then the abort word
+  DevBuf<double> res_xu[2];      // exchange copies of (u, v)
+  void build_resident(int W);
+  bool run_resident(int ksub0, int nsub);
   int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop
   bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)
   size_t n = 0;  // nblocks*ny*nx

@@ -15,6 +15,7 @@
 #include "evp.h"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void stress_cell(const EvpScalars& sc, double u_ne, d
                                             double v_sw, double v_se, double Dxt, double Dyt,
                                             double Dxhy, double Dyhx, double Cxp, double Cyp,
                                             double Cxm, double Cym, double Tarear, double Tiny,
-                                            double St, double* s, StressOut& o) {
+                                            double St, double* s, StressOut& o, const bool last_rt = true) {
   // :1065-1092 strain rates * area
   const double divune = Cyp * u_ne - Dyt * u_nw + Cxp * v_ne - Dxt * v_se;
   const double divunw = Cym * u_nw + Dyt * u_ne + Cxp * v_nw - Dxt * v_sw;
@@ -71,7 +72,7 @@ __device__ __forceinline__ void stress_cell(const EvpScalars& sc, double u_ne, d
   const double Deltanw = sqrt(divunw * divunw + ecci * (tensionnw * tensionnw + shearnw * shearnw));
   const double Deltase = sqrt(divuse * divuse + ecci * (tensionse * tensionse + shearse * shearse));
   const double Deltasw = sqrt(divusw * divusw + ecci * (tensionsw * tensionsw + shearsw * shearsw));
-  if (LAST) {  // :1103-1115
+  if (LAST && last_rt) {  // :1103-1115
     o.divu = p25 * (divune + divunw + divuse + divusw) * Tarear;
     const double tmp = p25 * (Deltane + Deltanw + Deltase + Deltasw) * Tarear;
     o.rdg_conv = -fmin(o.divu, c0);
@@ -767,6 +768,268 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
 }
 
 // ---- list-driven, unfused forms with the reference's argument lists (tests) --------------
+// ---- the WHOLE subcycle loop in one launch, state resident in registers (grids of at most one tile per CU) --------
+//
+// At gx1 a launch of k_subcycle2 is 2.2 us of launch gap + 6.3 us of loads and stores + 2 x 4.3 us of arithmetic, the
+// phases in series.  Everything but the velocity is private to a T-cell or read-only, so a
+// workgroup that stays on its CU for all ndte subcycles keeps the 12 stresses, the metrics, the strength and the
+// ten U-cell inputs of its lanes in registers, and only u, v on tile edges travel: the producing tile writes them to
+// an exchange copy of (u, v) and raises its progress word; a tile starts subcycle k+1 when the tiles it reads from have
+// reached k.  No launch gap, no re-load of sigma, no redundant second stress evaluation on a rim.
+//
+// Geometry = k_subcycle with R = 1: tile = 64 x W T-cells, tiles overlap by one T-row / T-column (recomputed, same
+// bits); lane lx < 63 of wavefront w < W-1 owns U-cell (i0+lx, j0+w).  Velocities a lane does not produce itself --
+// column 63 and row W-1 (owned by the east / north tile), ghost cells (mirrors, written by the owner of the mirrored
+// cell), the row below wavefront 0 and the column west of lane 0 -- are re-read from the exchange copy every subcycle.
+// Hand-off (MI355X_MICROARCH.md, "Valid forms", first row of the table): every published byte is an agent-scope
+// (sc1) store, every storing wavefront drains vmcnt, workgroup barrier, ONE lane stores the progress word (sc1);
+// the consumer's wavefront 0 polls the progress words of its producers (sc1 loads, one lane each), workgroup barrier,
+// then every load of exchanged bytes is an sc1 load.  Exchange buffers are double-buffered by subcycle parity: the
+// dependence is symmetric (a tile reads from every tile that reads from it), so no tile gets two subcycles ahead of a
+// reader.  Every spin is bounded by wall-clock ticks; on time-out (a tile that is not resident) the abort word is
+// raised, every workgroup leaves, nothing of the caller's state has been touched (inputs are read from st[cur],
+// results go to st[1-cur] after the last subcycle) and the host falls back to the launch-per-pair loop.
+constexpr int RES_MAXDEP = 16;
+constexpr int RES_STRIDE = 32;   // progress words 128 B apart
+
+struct ResArgs {
+  SubArgs a;             // u_in, v_in, sig_in = st[cur] (read once); u_out, v_out, sig_out = st[1-cur] (final result)
+  int nsub, last;        // subcycles of this launch; last != 0: the final one is subcycle ndte (diagnostics)
+  unsigned epoch0;       // progress of a tile after subcycle k of this launch = epoch0 + k + 1
+  unsigned* prog;        // [tiles * RES_STRIDE]
+  unsigned* abort_flag;
+  const int32_t* deps;   // [tiles][RES_MAXDEP] producer tiles, -1 padded
+  double* xu[2];         // exchange copies: u at 0, v at a.n; subcycle k publishes into xu[k & 1]
+  long long spin_ticks;  // wall_clock64() ticks (100 MHz) a poll may take
+};
+
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int W, bool DAMP>
+__global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(const ResArgs r) {
+  const SubArgs& a = r.a;
+  __shared__ double s_uv[W][2][TX];
+  __shared__ double s_west[W][2];
+  __shared__ double s_edge[W][4][TX];
+  __shared__ double s_x[W][8][TX];
+  __shared__ int s_abort;
+  const int nt = a.tiles_x * a.tiles_y;
+  const int chunk = (nt + 7) >> 3;
+  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile >= nt) return;  // whole workgroup
+  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+  const int ilo = a.blk[0], ihi = a.blk[1], jlo = a.blk[2], jhi = a.blk[3];
+  const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+  const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nx = a.nx;
+  const int i = i0 + lx, j = j0 + w;
+  const bool in_i = i <= ihi + 1;
+  const bool ok = in_i && j <= jhi + 1;
+  const size_t q = ok ? (size_t)(j - 1) * nx + (i - 1) : 0;
+  const bool own_i = (min(i, ihi) - i0) < (TX - 1);
+  const bool uown = lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
+  const bool uact = uown && a.iceumask[q];
+  const bool foreign = ok && !uown;                 // velocity of this lane's own position comes from elsewhere
+  const bool tact = ok && a.icetmask[q] == 1;
+  const bool sown = tact && own_i && (min(j, jhi) - j0) < (W - 1);
+  const bool south_h = w == 0 && in_i;              // row j0-1 (>= 1) from the exchange copy
+  const bool west_h = lx == 0 && ok;                // column i0-1 (>= 1)
+  // a late workgroup of an aborted launch leaves at once
+  if (threadIdx.x == 0) s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_abort) return;
+
+  // ---- resident state ----
+  double un = c0, vn = c0, us = c0, vs = c0, uwh = c0, vwh = c0, uswh = c0, vswh = c0;
+  if (ok) {
+    un = a.u_in[q];
+    vn = a.v_in[q];
+  }
+  if (south_h) {
+    us = a.u_in[q - nx];
+    vs = a.v_in[q - nx];
+  }
+  if (west_h) {
+    uwh = a.u_in[q - 1];
+    vwh = a.v_in[q - 1];
+    if (w == 0) {
+      uswh = a.u_in[q - nx - 1];
+      vswh = a.v_in[q - nx - 1];
+    }
+  }
+  double s[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) s[c] = tact ? a.sig_in[(size_t)c * a.n + q] : c0;
+  // the four primary lengths of the cell (the nine metrics are recomputed from them every subcycle, exactly as
+  // k_subcycle<DERIVE> does: ice_grid.F90:335-361) and its strength
+  double hn = c0, he = c0, hn_s = c0, hew = c0, St = c0;
+  if (tact) {
+    hn = a.HTN[q]; he = a.HTE[q]; hn_s = a.HTN[q - nx]; hew = a.HTE[q - 1];
+    St = a.strength[q];
+  }
+  // the eight read-only inputs of the momentum equation wait in LDS (read back by the same lane once per subcycle)
+  if (uact) {
+    s_x[w][0][lx] = a.aiu[q]; s_x[w][1][lx] = a.uocn[q]; s_x[w][2][lx] = a.vocn[q]; s_x[w][3][lx] = a.forcex[q];
+    s_x[w][4][lx] = a.forcey[q]; s_x[w][5][lx] = a.umassdtei[q]; s_x[w][6][lx] = a.fm[q]; s_x[w][7][lx] = a.uarear[q];
+  }
+  // velocities other tiles read: the tile's first / last owned row and column, and cells that ghosts mirror
+  int fd0 = -1, fd1 = -1, fd2 = -1;
+  if (uact && a.ring_slot) {
+    const int slot = a.ring_slot[q];
+    if (slot >= 0) {
+      fd0 = a.fwd[3 * slot];
+      fd1 = a.fwd[3 * slot + 1];
+      fd2 = a.fwd[3 * slot + 2];
+    }
+  }
+  const bool edge = uact && (lx == 0 || lx == TX - 2 || w == 0 || w == W - 2 || i == ihi || j == jhi || fd0 >= 0);
+  StressOut o;
+  StepuOut ro{};
+
+#pragma clang loop unroll(disable)
+  for (int k = 0; k < r.nsub; ++k) {
+    const bool lastk = r.last && k == r.nsub - 1;
+    // (A) velocities of the row below and of the western neighbour
+    s_uv[w][0][lx] = un;
+    s_uv[w][1][lx] = vn;
+    if (lx == 0) {
+      s_west[w][0] = uwh;
+      s_west[w][1] = vwh;
+    }
+    __syncthreads();
+    if (w > 0) {
+      us = s_uv[w - 1][0][lx];
+      vs = s_uv[w - 1][1][lx];
+    }
+    double uw = up1(un), vw = up1(vn), usw = up1(us), vsw = up1(vs);
+    if (lx == 0) {
+      uw = uwh;
+      vw = vwh;
+      usw = w > 0 ? s_west[w - 1][0] : uswh;
+      vsw = w > 0 ? s_west[w - 1][1] : vswh;
+    }
+    // (B) stress (ice_dyn_evp.F90:1065-1289)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o.str[c] = c0;
+    if (tact) {
+      const double Dxt = p5 * (hn + hn_s), Dyt = p5 * (he + hew), Dxhy = p5 * (he - hew), Dyhx = p5 * (hn - hn_s);
+      const double Cyp = 1.5 * he - p5 * hew, Cxp = 1.5 * hn - p5 * hn_s, Cym = -(1.5 * hew - p5 * he),
+                   Cxm = -(1.5 * hn_s - p5 * hn), Tiny = puny * (Dxt * Dyt);
+      stress_cell<true, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm, Cym,
+                              lastk ? a.tarear[q] : c0, Tiny, St, s, o, lastk);
+    }
+    // (C) momentum (:1390-1435): str of the eastern neighbour by wave shift, of the row above through LDS
+    const double e1 = down1(o.str[1]), e3 = down1(o.str[3]), e6 = down1(o.str[6]), e7 = down1(o.str[7]);
+    if (w > 0) {
+      s_edge[w][0][lx] = o.str[2];
+      s_edge[w][1][lx] = e3;
+      s_edge[w][2][lx] = o.str[5];
+      s_edge[w][3][lx] = e7;
+    }
+    __syncthreads();
+    if (uact) {
+      const double sx = o.str[0] + e1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];   // :1415-1416 order
+      const double sy = o.str[4] + s_edge[w + 1][2][lx] + e6 + s_edge[w + 1][3][lx];   // :1417-1418 order
+      const double uocn = s_x[w][1][lx], vocn = s_x[w][2][lx];
+      stepu_cell(un, vn, s_x[w][0][lx], uocn, vocn, uocn * cosw - vocn * sinw, vocn * cosw + uocn * sinw,   // :915-916
+                 s_x[w][3][lx], s_x[w][4][lx], s_x[w][5][lx], s_x[w][6][lx], s_x[w][7][lx], sx, sy, ro);
+      un = ro.u;
+      vn = ro.v;
+    }
+    if (k + 1 == r.nsub) break;
+    // (D) publish the edge velocities of subcycle k, then the progress word
+    double* xu = r.xu[k & 1];
+    if (edge) {
+      st_agent(xu + q, un);
+      st_agent(xu + a.n + q, vn);
+      if (fd0 >= 0) { st_agent(xu + fd0, un); st_agent(xu + a.n + fd0, vn); }
+      if (fd1 >= 0) { st_agent(xu + fd1, un); st_agent(xu + a.n + fd1, vn); }
+      if (fd2 >= 0) { st_agent(xu + fd2, un); st_agent(xu + a.n + fd2, vn); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned target = r.epoch0 + (unsigned)k + 1u;
+    if (threadIdx.x == 0)
+      __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (E) wait until every producer of this tile's halo has published subcycle k
+    if (w == 0) {
+      const int dep = lx < RES_MAXDEP ? r.deps[tile * RES_MAXDEP + lx] : -1;
+      bool have = dep < 0;
+      int bad = 0;
+      const long long t0 = wall_clock64();
+      while (true) {
+        if (!have) {
+          const unsigned v = __hip_atomic_load(r.prog + (size_t)dep * RES_STRIDE, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+          have = (int)(v - target) >= 0;
+        }
+        if (__all(have)) break;
+        if (lx == 0) {
+          bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!bad && wall_clock64() - t0 > r.spin_ticks) {
+            __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bad = 1;
+          }
+        }
+        bad = __shfl(bad, 0);
+        if (bad) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lx == 0) s_abort = bad;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    // every exchanged velocity is an agent-scope load
+    if (foreign) {
+      un = ld_agent(xu + q);
+      vn = ld_agent(xu + a.n + q);
+    }
+    if (south_h) {
+      us = ld_agent(xu + q - nx);
+      vs = ld_agent(xu + a.n + q - nx);
+    }
+    if (west_h) {
+      uwh = ld_agent(xu + q - 1);
+      vwh = ld_agent(xu + a.n + q - 1);
+      if (w == 0) {
+        uswh = ld_agent(xu + q - nx - 1);
+        vswh = ld_agent(xu + a.n + q - nx - 1);
+      }
+    }
+  }
+
+  // ---- results (owners only), into the other copy of the state ----
+  if (sown) {
+#pragma unroll
+    for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
+    if (r.last) {
+      a.divu[q] = o.divu;
+      a.rdg_conv[q] = o.rdg_conv;
+      a.rdg_shear[q] = o.rdg_shear;
+      a.shear[q] = o.shear;
+      a.prs_sig[q] = o.prs_sig;
+    }
+  }
+  if (uact) {
+    a.u_out[q] = un;
+    a.v_out[q] = vn;
+    if (fd0 >= 0) { a.u_out[fd0] = un; a.v_out[fd0] = vn; }
+    if (fd1 >= 0) { a.u_out[fd1] = un; a.v_out[fd1] = vn; }
+    if (fd2 >= 0) { a.u_out[fd2] = un; a.v_out[fd2] = vn; }
+    if (r.last) {
+      a.strintx[q] = ro.strintx;
+      a.strinty[q] = ro.strinty;
+      a.strocnx[q] = ro.taux;
+      a.strocny[q] = ro.tauy;
+    }
+  }
+}
+
 struct StressListArgs {
   EvpScalars sc;
   int nx, ny, ksub, icellt;
@@ -1119,6 +1382,13 @@ void Evp::set_option(const char* key, int value) {
     comm_graph = value != 0;
   } else if (!std::strcmp(key, "fuse")) {          // two subcycles per launch where the domain allows
     fuse_on = value != 0;
+  } else if (!std::strcmp(key, "resident")) {      // whole loop in one launch where the grid fits (default on)
+    resident_on = value != 0;
+    if (value == 2) resident_failed = false;       // 2: also forget an earlier time-out
+  } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
+    CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
+                 "resident_waves must be 0, 4, 6, 8, 11 or 12");
+    res_w_opt = value;
   } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 13 || value == 14 || value == 16,
                  "fused_waves must be 0, 8, 12, 13, 14 or 16");
@@ -1495,6 +1765,139 @@ void Evp::launch_subcycle_pair(int ksub) {
   after_subcycle(ksub + 1);
 }
 
+// ---- resident loop ------------------------------------------------------------------------------------------------
+// One block on this rank, nothing to exchange with other ranks or across a tripole fold during the subcycling, on-rank
+// ghosts served by forwarding, and at most one tile per CU (the hand-off form used is the one measured for one
+// workgroup per CU, and every tile has to be resident for the progress words to advance).
+bool Evp::can_reside() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT"); return e && e[0] == '0'; }();
+  if (!resident_on || resident_failed || env_off) return false;
+  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || !(derive_ok && derive_on)) return false;
+  if (halo.has_refresh() || halo.has_fold() || halo.multi_rank()) return false;
+  return resident_waves() > 0;
+}
+
+int Evp::resident_waves() const {
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+  auto tiles = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
+  if (res_w_opt) return tiles(res_w_opt) <= ncu ? res_w_opt : 0;
+  for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
+    if (tiles(w) <= ncu) return w;
+  return 0;
+}
+
+// producer tiles of every tile's halo: the cells it re-reads each subcycle, traced through the on-rank ghost copies
+void Evp::build_resident(int W) {
+  const int nx = dom.nx_block, ny = dom.ny_block;
+  const Block& bl = dom.all[dom.local[0]];
+  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
+  const int tiles_x = ((nx - 2) + (TX - 1) - 1) / (TX - 1), tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1);
+  const int nt = tiles_x * tiles_y;
+  std::vector<int32_t> src_of((size_t)nx * ny, -1);
+  for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
+  auto owner = [&](int i, int j) -> int {   // 1-based cell -> tile that produces its velocity, -1: nobody (constant)
+    if (i < 1 || i > nx || j < 1 || j > ny) return -1;
+    int q = (j - 1) * nx + (i - 1);
+    if (src_of[q] >= 0) q = src_of[q];
+    const int si = q % nx + 1, sj = q / nx + 1;
+    if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
+    return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
+  };
+  std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
+  for (int t = 0; t < nt; ++t) {
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    int nd = 0;
+    auto add = [&](int i, int j) {
+      const int o = owner(i, j);
+      if (o < 0 || o == t) return;
+      for (int k = 0; k < nd; ++k)
+        if (deps[(size_t)t * RES_MAXDEP + k] == o) return;
+      CICE_REQUIRE(nd < RES_MAXDEP, "resident EVP loop: a tile has more producers than RES_MAXDEP");
+      deps[(size_t)t * RES_MAXDEP + nd++] = o;
+    };
+    for (int w = -1; w < W; ++w)
+      for (int lx = -1; lx < TX; ++lx) {
+        const int i = i0 + lx, j = j0 + w;
+        if (i > ihi + 1 || j > jhi + 1) continue;
+        const bool uown = lx >= 0 && w >= 0 && lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
+        if (!uown) add(i, j);
+      }
+  }
+  res_deps.alloc(deps.size());
+  res_deps.upload(deps.data(), stream);
+  res_prog.alloc((size_t)(nt + 1) * RES_STRIDE);
+  res_prog.zero(stream);
+  res_epoch = 0;
+  for (int k = 0; k < 2; ++k)
+    if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
+  CICE_HIP(hipStreamSynchronize(stream));
+  res_w = W;
+  res_tiles = nt;
+}
+
+template <int W>
+static void launch_res(const ResArgs& r, bool damp, dim3 g, hipStream_t s) {
+  if (damp) hipLaunchKernelGGL((k_evp_resident<W, true>), g, dim3(64 * W), 0, s, r);
+  else hipLaunchKernelGGL((k_evp_resident<W, false>), g, dim3(64 * W), 0, s, r);
+}
+
+// subcycles ksub0 .. ksub0+nsub-1 in one launch; false: not done (time-out), the state is as it was
+bool Evp::run_resident(int ksub0, int nsub) {
+  const int W = resident_waves();
+  if (W != res_w || res_deps.n == 0) build_resident(W);
+  if (res_epoch > 0x70000000u) {   // progress words are compared modulo 2^32 over at most 2^31
+    res_prog.zero(stream);
+    res_epoch = 0;
+  }
+  ResArgs r{};
+  r.a = make_args();
+  r.a.tiles_x = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+  r.a.tiles_y = ((dom.ny_block - 2) + (W - 1) - 1) / (W - 1);
+  r.nsub = nsub;
+  r.last = (ksub0 + nsub - 1 == sc.ndte) ? 1 : 0;
+  r.epoch0 = res_epoch;
+  r.prog = res_prog.p;
+  r.abort_flag = res_prog.p + (size_t)res_tiles * RES_STRIDE;
+  r.deps = res_deps.p;
+  r.xu[0] = res_xu[0].p;
+  r.xu[1] = res_xu[1].p;
+  r.spin_ticks = 20000000;   // 0.2 s of the 100 MHz wall clock
+  for (int k = 0; k < 2; ++k)   // cells nobody publishes keep their value: both exchange copies start as (u, v)
+    CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
+  const dim3 g(8 * ((res_tiles + 7) / 8));
+  const bool damp = sc.evp_damping != 0;
+  switch (W) {
+    case 4: launch_res<4>(r, damp, g, stream); break;
+    case 6: launch_res<6>(r, damp, g, stream); break;
+    case 8: launch_res<8>(r, damp, g, stream); break;
+    case 11: launch_res<11>(r, damp, g, stream); break;
+    case 12: launch_res<12>(r, damp, g, stream); break;
+    default: throw Error{CICE_EINVAL, "resident_waves must be 4, 6, 8, 11 or 12"};
+  }
+  CICE_HIP(hipGetLastError());
+  unsigned aborted = 0;
+  CICE_HIP(hipMemcpyAsync(&aborted, r.abort_flag, 4, hipMemcpyDeviceToHost, stream));
+  CICE_HIP(hipStreamSynchronize(stream));
+  res_epoch += (unsigned)nsub;
+  if (aborted) {
+    std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident); "
+                         "falling back to one launch per pair of subcycles\n");
+    resident_failed = true;
+    res_prog.zero(stream);
+    res_epoch = 0;
+    return false;
+  }
+  cur = 1 - cur;   // the result is in the other copy whatever the parity of nsub
+  ++flips;
+  return true;
+}
+
 // subcycles ksub0 .. ksub0+nsub-1: pairs where possible
 void Evp::launch_range(int ksub0, int nsub) {
   const bool fuse = can_fuse();
@@ -1530,7 +1933,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   static const bool env_comm_graph = std::getenv("CICE4_AMD_COMM_GRAPH") != nullptr;
   const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
   bool replayed = false;
-  if (graph_ok) {
+  if (nsub >= 2 && can_reside()) replayed = run_resident(ksub0, nsub);
+  if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         (((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 64 +
                             (halo.generation() & 63)};

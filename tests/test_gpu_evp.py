@@ -526,7 +526,7 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
     s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
     keys = EVP_OUT_FIELDS + ("iceumask",)
     for ndte, damping in ((NDTE, False), (7, True), (2, False)):
-        ref, info = _evp_with(ctx, grid, s, ndte, damping, fuse=0)
+        ref, info = _evp_with(ctx, grid, s, ndte, damping, fuse=0, resident=0)
         assert info[0] == 0
         if (ndte, damping) == (NDTE, False):
             orc.set_evp_parameters(DT, ndte, damping); orc.set_strength_parameters(1, 0, 0, 4.0)
@@ -538,10 +538,57 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
         for opts in (dict(fused_waves=8), dict(fused_waves=12), dict(fused_waves=13), dict(fused_waves=14),
                      dict(fused_waves=16), dict(),
                      dict(derive_metrics=0), dict(use_graph=0)):
-            got, info = _evp_with(ctx, grid, s, ndte, damping, fuse=1, **opts)
+            got, info = _evp_with(ctx, grid, s, ndte, damping, fuse=1, resident=0, **opts)
             assert info[0] == 1 and info[1] in (8, 12, 13, 14, 16)
             for k in keys:
                 assert np.array_equal(got[k], ref[k]), (ndte, damping, opts, k)
+
+
+@pytest.mark.parametrize("nxg,nyg,ew,ns", [(96, 70, 1, 0), (20, 33, 1, 0), (62, 18, 1, 0), (63, 18, 1, 0), (64, 18, 1, 0),
+                                            (125, 9, 1, 0), (126, 41, 1, 0), (127, 5, 1, 0), (200, 50, 1, 0),
+                                            (96, 70, 0, 0), (130, 27, 2, 2), (7, 6, 1, 0), (96, 40, 1, 1), (320, 384, 1, 0)])
+def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
+    """k_evp_resident (all subcycles in ONE launch: stresses, metrics and forcing stay in registers / LDS, tile-edge
+    velocities travel through agent-scope stores, progress words and agent-scope loads) against one launch per
+    subcycle and the checker: bit for bit.  Widths around the 63-column tile stride, blocks narrower than a tile, every
+    boundary type incl. cyclic N-S (ghost rows mirrored by far tiles), every workgroup height, damping, 1- and
+    2-subcycle loops (2 = one hand-off), odd counts, and a loop cut into ranges (the stepwise API); gx1 size."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
+    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    big = nxg * nyg > 50000
+    for ndte, damping in (((NDTE, False),) if big else ((NDTE, False), (7, True), (2, False), (3, False))):
+        ref, _ = _evp_with(ctx, grid, s, ndte, damping, fuse=0, resident=0)
+        if (ndte, damping) == (NDTE, False):
+            orc.set_evp_parameters(DT, ndte, damping); orc.set_strength_parameters(1, 0, 0, 4.0)
+            so = {k: v.copy() for k, v in s.items()}
+            orc.evp(orc.make_domain(dom, grid), so)
+            orc.set_strength_parameters()
+            for k in keys:
+                assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
+        for W in ((0, 11, 12) if big else (0, 4, 6, 8, 11, 12)):
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+            ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
+            if not ctx.evp_get_info("resident"):
+                assert big and W == 0 or W in (4, 6, 8), (W, "grid should fit")    # more tiles than CUs at this height
+                continue
+            ctx.evp(DT, sg)
+            assert ctx.evp_get_info("resident") == 1, "the resident loop timed out and fell back"
+            for k in keys:
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, k)
+    # a loop cut into ranges: 1..5 (one launch), 6 (single subcycle: the ordinary kernel), 7..NDTE
+    b = {k: v.copy() for k, v in s.items()}
+    ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident", 2)
+    ctx.evp_upload(b); ctx.evp_prepare(DT)
+    ctx.evp_subcycles(1, 5); ctx.evp_subcycles(6, 1); ctx.evp_subcycles(7, NDTE - 6)
+    ctx.evp_finish(); ctx.evp_download(b)
+    ref, _ = _evp_with(ctx, grid, s, NDTE, False, fuse=0, resident=0)
+    for k in EVP_OUT_FIELDS:
+        assert np.array_equal(b[k], ref[k]), ("ranges", k)
 
 
 def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
