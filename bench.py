@@ -75,6 +75,7 @@ def parse():
     p.add_argument("--slabs", type=int, default=0,
                    help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
                         "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
+    p.add_argument("--no-resident", action="store_true", help="do not run the whole subcycle loop in one launch (k_evp_resident)")
     p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
     p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/13/14/16); 0 = auto")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
@@ -342,6 +343,24 @@ def pmc_traffic(workload, kernel_substr):
     return None, None
 
 
+def pmc_counters(workload, kernel_substr):
+    """VALU instructions per wavefront (and per subcycle for the resident loop) from an archived SQ counter pass
+    (profiles/r*_sq_counters*.csv), newest round first; None if there is none for this kernel."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sq_counters*.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                name = row.get("kernel") or row.get("kernel (gx1)") or ""
+                if kernel_substr in name and row.get("workload", workload) == workload and row.get("subcycles_per_launch"):
+                    per_wave = float(row["VALU_instr_per_wave"])
+                    return {"valu_per_wave_subcycle": per_wave / float(row["subcycles_per_launch"]),
+                            "source": "archived SQ pass " + os.path.relpath(path, ROOT)}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
 def cpu_baseline_worker(args):
     """Child process: no GPU is touched.  Rebuilds the same synthetic case on the host, times
     the checker, writes JSON to the given file.  Keeps the Fortran runtime's stdout away from
@@ -410,6 +429,12 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     fw = ctx.evp_get_info("fused_waves") if fused else 0
     if fused:
         tile = f"two subcycles per launch; workgroup {fw} wavefronts x 64 lanes owns {fw - 3} rows x 59 columns"
+    ctx.evp_set_option("resident", 0 if args.no_resident else 1)
+    resident = bool(ctx.evp_get_info("resident"))
+    rw = ctx.evp_get_info("resident_waves") if resident else 0
+    if resident:
+        tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
+                f"(owns {rw - 1} rows x 63 columns), one workgroup per CU")
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
     nt, nu = ctx.evp_active_cells()
@@ -457,7 +482,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     nsub_total = ndte * steps
     value = nsub_total / t_evp
     # dominant kernel: the subcycle kernel; HIP-event time of the launches on the library's stream / launches
-    n_launch = launches_per_step(ndte, fused, dom.get("overlap", 0)) * steps
+    resident = resident and bool(ctx.evp_get_info("resident"))    # 0 if a launch timed out and the library fell back
+    n_launch = steps if resident else launches_per_step(ndte, fused, dom.get("overlap", 0)) * steps
     us_per_launch = dev_ms * 1e3 / n_launch
     sub_per_launch = nsub_total / n_launch
     cells_rank = nt_all / world
@@ -468,9 +494,12 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     # "fractions" > 1 in round 1), so it is reported separately as `survey_8d` and is NOT a roofline fraction.
     bytes_per_launch = EVP_BYTES_PER_CELL * cells_rank
     achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
-    kname = ("k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
+    kname = ("k_evp_resident (all ndte subcycles in one launch: stresses, metrics, forcing resident in registers / LDS; "
+             "tile-edge velocities through agent-scope stores, progress words and agent-scope loads)" if resident else
+             "k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
              else "k_subcycle (fused stress + stepu + on-rank halo)")
-    ksub = (f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
+    ksub = (f"k_evp_resident<{rw}, false>" if resident else
+            f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
             else f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>")
     traffic, traffic_src = pmc_traffic(wl, ksub) if world == 1 else (None, None)
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -489,6 +518,18 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                               "ratio_to_peak": achieved * sub_per_launch / HBM_PEAK_GBS,
                               "note": "north_star's per-subcycle figure (what an unfused subcycle would have to move per "
                                       "second at this rate); exceeds what this kernel moves by the factor subcycles_per_launch"}}
+    if resident:
+        # The resident loop reads and writes the state once per ndte subcycles: HBM is no longer what bounds it, and the
+        # fraction above says only that.  What does: fp64 issue on the busiest SIMD (3 of the 12 wavefronts of a
+        # workgroup) and the cross-XCD hand-off of the tile-edge velocities once per subcycle.
+        sq = pmc_counters(wl, ksub)
+        us_sub = us_per_launch / sub_per_launch
+        roofline["not_hbm_bound"] = {
+            "us_per_subcycle": us_sub,
+            "binding": "fp64 VALU issue of the busiest SIMD + one cross-XCD hand-off (agent-scope store -> load through memory) per subcycle",
+            "valu_inst_per_wave_per_subcycle": sq.get("valu_per_wave_subcycle") if sq else None,
+            "issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz": (3 * sq["valu_per_wave_subcycle"] * 4 / 2400.0) if sq else None,
+            "counters_source": sq.get("source") if sq else None}
     config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
               "subcycles_per_step": ndte,
               "decomposition": f"1x{world} j-slabs, one block per GPU" + (

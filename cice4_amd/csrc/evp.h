@@ -67,11 +67,11 @@ class Evp {
   // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
-  int res_w = 0, res_tiles = 0;
-  unsigned res_epoch = 0;        // tags handed out so far
-  DevBuf<int32_t> res_src;       // per cell: the U-cell whose velocity it holds
-  DevBuf<unsigned> res_abort;
-  DevBuf<double> res_gran[2];    // tagged granules, 32 B per cell, by subcycle parity
+  int res_w = 0, res_tiles = 0;  // what res_deps was built for
+  unsigned res_epoch = 0;
+  DevBuf<int32_t> res_deps;
+  DevBuf<unsigned> res_prog;     // [tiles * 32] progress words, then the abort word
+  DevBuf<double> res_xu[2];      // exchange copies of (u, v)
   void build_resident(int W);
   bool run_resident(int ksub0, int nsub);
   int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop

@@ -772,70 +772,53 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
 //
 // At gx1 a launch of k_subcycle2 is 2.2 us of launch gap + 6.3 us of loads and stores + 2 x 4.3 us of arithmetic, the
 // phases in series.  Everything but the velocity is private to a T-cell or read-only, so a
-// workgroup that stays on its CU for all ndte subcycles keeps the 12 stresses, the primary lengths and the strength of
-// its lanes in registers and the eight U-cell inputs in LDS, and only u, v on tile edges travel.  No launch gap, no
-// re-load of sigma, no redundant second stress evaluation on a rim.
+// workgroup that stays on its CU for all ndte subcycles keeps the 12 stresses, the metrics, the strength and the
+// ten U-cell inputs of its lanes in registers, and only u, v on tile edges travel: the producing tile writes them to
+// an exchange copy of (u, v) and raises its progress word; a tile starts subcycle k+1 when the tiles it reads from have
+// reached k.  No launch gap, no re-load of sigma, no redundant second stress evaluation on a rim.
 //
 // Geometry = k_subcycle with R = 1: tile = 64 x W T-cells, tiles overlap by one T-row / T-column (recomputed, same
-// bits); lane lx < 63 of wavefront w < W-1 owns U-cell (i0+lx, j0+w).  The velocities a tile does not produce itself
-// form its HALO TABLE in LDS: the row below wavefront 0, the tile's last row (owned by the north tile, or the ghost
-// row), the column west of lane 0 and the tile's last column (owned by the east tile, or the ghost column) -- ghost
-// cells included, which the owner of the mirrored cell writes (the forwarding lists of Halo).
-// Hand-off by data-tagged granules (MI355X_MICROARCH.md, handoff-1to1): a published velocity is ONE 16-byte
-// agent-scope (sc1) store {value, tag = subcycle number}; thread t of the consuming workgroup polls table entry t
-// with 16-byte sc1 loads until the tag is the subcycle it waits for, and puts the value into the LDS table in front of
-// the barrier the loop needs anyway.  No flag, no fence, two barriers per subcycle.  Granules are double-buffered by
-// subcycle parity: the dependence is symmetric (a tile reads from every tile that reads from it -- edge cells are
-// published with or without ice on them, so that this is geometry), hence no tile gets two subcycles ahead of a reader.  Every poll is bounded by wall-clock ticks; on time-out (a tile that is not resident)
-// the abort word is raised, every workgroup leaves, nothing of the caller's state has been touched (inputs are read
-// from st[cur], results go to st[1-cur] after the last subcycle) and the host falls back to the launch-per-pair loop.
+// bits); lane lx < 63 of wavefront w < W-1 owns U-cell (i0+lx, j0+w).  Velocities a lane does not produce itself --
+// column 63 and row W-1 (owned by the east / north tile), ghost cells (mirrors, written by the owner of the mirrored
+// cell), the row below wavefront 0 and the column west of lane 0 -- are re-read from the exchange copy every subcycle.
+// Hand-off (MI355X_MICROARCH.md, "Valid forms", first row of the table): every published byte is an agent-scope
+// (sc1) store, every storing wavefront drains vmcnt, workgroup barrier, ONE lane stores the progress word (sc1);
+// the consumer's wavefront 0 polls the progress words of its producers (sc1 loads, one lane each), workgroup barrier,
+// then every load of exchanged bytes is an sc1 load.  Exchange buffers are double-buffered by subcycle parity: the
+// dependence is symmetric (a tile reads from every tile that reads from it), so no tile gets two subcycles ahead of a
+// reader.  Every spin is bounded by wall-clock ticks; on time-out (a tile that is not resident) the abort word is
+// raised, every workgroup leaves, nothing of the caller's state has been touched (inputs are read from st[cur],
+// results go to st[1-cur] after the last subcycle) and the host falls back to the launch-per-pair loop.
+constexpr int RES_MAXDEP = 16;
+constexpr int RES_STRIDE = 32;   // progress words 128 B apart
+
 struct ResArgs {
   SubArgs a;             // u_in, v_in, sig_in = st[cur] (read once); u_out, v_out, sig_out = st[1-cur] (final result)
   int nsub, last;        // subcycles of this launch; last != 0: the final one is subcycle ndte (diagnostics)
-  unsigned epoch0;       // tag of the velocities of subcycle k of this launch = epoch0 + k + 1 (never 0, monotone)
+  unsigned epoch0;       // progress of a tile after subcycle k of this launch = epoch0 + k + 1
+  unsigned* prog;        // [tiles * RES_STRIDE]
   unsigned* abort_flag;
-  const int32_t* src;    // per cell: the U-cell whose velocity it holds (itself, or the cell a ghost mirrors), -1: none
-  char* gran[2];         // granules, 32 B per cell: {u, tag, 0}, {v, tag, 0}; subcycle k publishes into gran[k & 1]
+  const int32_t* deps;   // [tiles][RES_MAXDEP] producer tiles, -1 padded
+  double* xu[2];         // exchange copies: u at 0, v at a.n; subcycle k publishes into xu[k & 1]
   long long spin_ticks;  // wall_clock64() ticks (100 MHz) a poll may take
 };
 
-typedef unsigned res_u4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void st_granules(char* p, double u, double v, unsigned tag) {
-  const res_u4 gu = {(unsigned)__double2loint(u), (unsigned)__double2hiint(u), tag, 0u};
-  const res_u4 gv = {(unsigned)__double2loint(v), (unsigned)__double2hiint(v), tag, 0u};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
-               :: "v"(p), "v"(gu), "v"(gv) : "memory");
+__device__ __forceinline__ double ld_agent(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void ld_granules(const char* p, res_u4& gu, res_u4& gv) {
-  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
-               "s_waitcnt vmcnt(0)" : "=&v"(gu), "=&v"(gv) : "v"(p) : "memory");
+__device__ __forceinline__ void st_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void ld_granules3(const char* p0, const char* p1, const char* p2, res_u4& a0, res_u4& b0,
-                                             res_u4& a1, res_u4& b1, res_u4& a2, res_u4& b2) {
-  asm volatile("global_load_dwordx4 %0, %6, off sc1\n\tglobal_load_dwordx4 %1, %6, off offset:16 sc1\n\t"
-               "global_load_dwordx4 %2, %7, off sc1\n\tglobal_load_dwordx4 %3, %7, off offset:16 sc1\n\t"
-               "global_load_dwordx4 %4, %8, off sc1\n\tglobal_load_dwordx4 %5, %8, off offset:16 sc1\n\t"
-               "s_waitcnt vmcnt(0)"
-               : "=&v"(a0), "=&v"(b0), "=&v"(a1), "=&v"(b1), "=&v"(a2), "=&v"(b2) : "v"(p0), "v"(p1), "v"(p2) : "memory");
-}
-
-// W computing wavefronts + ONE fetching wavefront (index W): it never stores to memory, so its polls do not queue
-// behind the write-through stores of a publishing wavefront (loads and stores retire in order within a wavefront)
 template <int W, bool DAMP>
-__global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_evp_resident(const ResArgs r) {
+__global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(const ResArgs r) {
   const SubArgs& a = r.a;
-  constexpr int HROW = TX + 1;                 // entries of a table row: columns -1 .. 63
-  constexpr int HS = 2 * HROW + 2 * W;         // row -1 | row wf | column -1 (rows 0..) | column lxf (rows 0..)
-  static_assert(HS <= 3 * 64, "three table entries per lane of the fetching wavefront");
   __shared__ double s_uv[W][2][TX];
+  __shared__ double s_west[W][2];
   __shared__ double s_edge[W][4][TX];
   __shared__ double s_x[W][8][TX];
-  __shared__ double s_h[2][3 * 64];
   __shared__ double s_m[W][5][TX];
   __shared__ int s_fd[W][3][TX];
-  __shared__ int s_q[3][TX];                   // the fetching wavefront's entries: cell or -1
   __shared__ int s_abort;
   const int nt = a.tiles_x * a.tiles_y;
   const int chunk = (nt + 7) >> 3;
@@ -845,63 +828,41 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
   const int ilo = a.blk[0], ihi = a.blk[1], jlo = a.blk[2], jhi = a.blk[3];
   const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
   const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const bool cw = w < W;                       // computing wavefront
   const int nx = a.nx;
   const int i = i0 + lx, j = j0 + w;
-  const int lxf = min(TX - 1, ihi + 1 - i0), wf = min(W - 1, jhi + 1 - j0);   // the tile's last column / row of T-cells
-  const bool ok = lx <= lxf && w <= wf;
+  const bool in_i = i <= ihi + 1;
+  const bool ok = in_i && j <= jhi + 1;
   const size_t q = ok ? (size_t)(j - 1) * nx + (i - 1) : 0;
   const bool own_i = (min(i, ihi) - i0) < (TX - 1);
-  const bool uown = lx < lxf && w < wf;             // = lx < 63, i <= ihi, w < W-1, j <= jhi
+  const bool uown = lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
   const bool uact = uown && a.iceumask[q];
-  const bool foreign = ok && !uown;                 // velocity of this lane's own position comes from the table
+  const bool foreign = ok && !uown;                 // velocity of this lane's own position comes from elsewhere
   const bool tact = ok && a.icetmask[q] == 1;
   const bool sown = tact && own_i && (min(j, jhi) - j0) < (W - 1);
-  // table entry e: position (hl, hw) relative to the tile -> cell, or -1
-  auto entry_cell = [&](int e) -> long long {
-    int hl, hw;
-    bool v = e < HS;
-    if (e < HROW) { hw = -1; hl = e - 1; }
-    else if (e < 2 * HROW) { hw = wf; hl = e - HROW - 1; }
-    else if (e < 2 * HROW + W) { hl = -1; hw = e - 2 * HROW; v = v && hw < wf; }
-    else { hl = lxf; hw = e - 2 * HROW - W; v = v && hw < wf; }
-    v = v && hl <= lxf && hw <= wf;
-    return v ? (long long)(j0 + hw - 1) * nx + (i0 + hl - 1) : -1;
-  };
-  // the fetching wavefront's three entries per lane; live = some tile owns the cell the entry holds (itself, or the
-  // cell a ghost mirrors).  Owners publish their edge cells whether or not there is ice on them: which tiles wait for
-  // which is then a matter of geometry alone and therefore symmetric, which is what keeps a producer from lapping a
-  // reader (see above)
-  bool any_live = false;
-  if (!cw) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      long long qe = entry_cell(lx + 64 * c);
-      if (qe >= 0 && r.src[qe] < 0) qe = -1;
-      s_q[c][lx] = (int)qe;
-      any_live = any_live || qe >= 0;
-    }
-  }
-  for (int e = threadIdx.x; e < 3 * 64; e += 64 * (W + 1)) {   // initial table
-    const long long qe = entry_cell(e);
-    s_h[0][e] = qe >= 0 ? a.u_in[qe] : c0;
-    s_h[1][e] = qe >= 0 ? a.v_in[qe] : c0;
-  }
-  // table slots this lane reads
-  const int slot_own = w == wf ? HROW + lx + 1 : 2 * HROW + W + w;                 // (lx, wf) or (lxf, w)
-  const int slot_s = w == 0 ? lx + 1 : 2 * HROW + W + (w - 1);                     // (lx, -1) or (lxf, w-1)
-  const int slot_w = w == wf ? HROW : 2 * HROW + w;                                // (-1, wf) or (-1, w)
-  const int slot_sw = w == 0 ? 0 : 2 * HROW + (w - 1);                             // (-1, -1) or (-1, w-1)
+  const bool south_h = w == 0 && in_i;              // row j0-1 (>= 1) from the exchange copy
+  const bool west_h = lx == 0 && ok;                // column i0-1 (>= 1)
   // a late workgroup of an aborted launch leaves at once
   if (threadIdx.x == 0) s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if (s_abort) return;
 
   // ---- resident state ----
-  double un = c0, vn = c0;
+  double un = c0, vn = c0, us = c0, vs = c0, uwh = c0, vwh = c0, uswh = c0, vswh = c0;
   if (ok) {
     un = a.u_in[q];
     vn = a.v_in[q];
+  }
+  if (south_h) {
+    us = a.u_in[q - nx];
+    vs = a.v_in[q - nx];
+  }
+  if (west_h) {
+    uwh = a.u_in[q - 1];
+    vwh = a.v_in[q - 1];
+    if (w == 0) {
+      uswh = a.u_in[q - nx - 1];
+      vswh = a.v_in[q - nx - 1];
+    }
   }
   double s[12];
 #pragma unroll
@@ -922,7 +883,7 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
   bool edge = false;
   {
     int fd0 = -1, fd1 = -1, fd2 = -1;
-    if (uown && a.ring_slot) {
+    if (uact && a.ring_slot) {
       const int slot = a.ring_slot[q];
       if (slot >= 0) {
         fd0 = a.fwd[3 * slot];
@@ -930,8 +891,8 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
         fd2 = a.fwd[3 * slot + 2];
       }
     }
-    if (cw) { s_fd[w][0][lx] = fd0; s_fd[w][1][lx] = fd1; s_fd[w][2][lx] = fd2; }
-    edge = uown && (lx == 0 || lx == lxf - 1 || w == 0 || w == wf - 1 || fd0 >= 0);
+    s_fd[w][0][lx] = fd0; s_fd[w][1][lx] = fd1; s_fd[w][2][lx] = fd2;
+    edge = uact && (lx == 0 || lx == TX - 2 || w == 0 || w == W - 2 || i == ihi || j == jhi || fd0 >= 0);
   }
   StressOut o;
   StepuOut ro{};
@@ -939,60 +900,24 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
-    // (A) this subcycle's velocities: own rows into LDS for the wavefront above; halo table entries (k > 0) from the
-    //     granules of subcycle k-1, one entry per thread
-    if (cw) {
-      s_uv[w][0][lx] = un;
-      s_uv[w][1][lx] = vn;
-    } else if (k > 0 && any_live) {
-      const unsigned want = r.epoch0 + (unsigned)k;
-      const char* g = r.gran[(k - 1) & 1];
-      const int qh[3] = {s_q[0][lx], s_q[1][lx], s_q[2][lx]};
-      const int qd = qh[0] >= 0 ? qh[0] : (qh[1] >= 0 ? qh[1] : qh[2]);   // an entry that is not live reads a live one
-      const char* p0 = g + (size_t)(qh[0] >= 0 ? qh[0] : qd) * 32;
-      const char* p1 = g + (size_t)(qh[1] >= 0 ? qh[1] : qd) * 32;
-      const char* p2 = g + (size_t)(qh[2] >= 0 ? qh[2] : qd) * 32;
-      res_u4 u0, v0, u1, v1, u2, v2;
-      const long long t0 = wall_clock64();
-      int spins = 0;
-      while (true) {
-        ld_granules3(p0, p1, p2, u0, v0, u1, v1, u2, v2);
-        if (u0.z == want && v0.z == want && u1.z == want && v1.z == want && u2.z == want && v2.z == want) break;
-        if ((++spins & 63) == 0) {
-          if (__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { s_abort = 1; break; }
-          if (wall_clock64() - t0 > r.spin_ticks) {
-            __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_abort = 1;
-            break;
-          }
-        }
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (qh[0] >= 0) { s_h[0][lx] = __hiloint2double((int)u0.y, (int)u0.x); s_h[1][lx] = __hiloint2double((int)v0.y, (int)v0.x); }
-      if (qh[1] >= 0) { s_h[0][lx + 64] = __hiloint2double((int)u1.y, (int)u1.x); s_h[1][lx + 64] = __hiloint2double((int)v1.y, (int)v1.x); }
-      if (qh[2] >= 0) { s_h[0][lx + 128] = __hiloint2double((int)u2.y, (int)u2.x); s_h[1][lx + 128] = __hiloint2double((int)v2.y, (int)v2.x); }
+    // (A) velocities of the row below and of the western neighbour
+    s_uv[w][0][lx] = un;
+    s_uv[w][1][lx] = vn;
+    if (lx == 0) {
+      s_west[w][0] = uwh;
+      s_west[w][1] = vwh;
     }
     __syncthreads();
-    if (s_abort) return;
-    if (foreign) {
-      un = s_h[0][slot_own];
-      vn = s_h[1][slot_own];
-    }
-    double us = c0, vs = c0;
-    if (!cw) {
-    } else if (w == 0 || lx == lxf) {
-      us = s_h[0][slot_s];
-      vs = s_h[1][slot_s];
-    } else {
+    if (w > 0) {
       us = s_uv[w - 1][0][lx];
       vs = s_uv[w - 1][1][lx];
     }
     double uw = up1(un), vw = up1(vn), usw = up1(us), vsw = up1(vs);
     if (lx == 0) {
-      uw = s_h[0][slot_w];
-      vw = s_h[1][slot_w];
-      usw = s_h[0][slot_sw];
-      vsw = s_h[1][slot_sw];
+      uw = uwh;
+      vw = vwh;
+      usw = w > 0 ? s_west[w - 1][0] : uswh;
+      vsw = w > 0 ? s_west[w - 1][1] : vswh;
     }
     // (B) stress (ice_dyn_evp.F90:1065-1289)
 #pragma unroll
@@ -1007,7 +932,7 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
     }
     // (C) momentum (:1390-1435): str of the eastern neighbour by wave shift, of the row above through LDS
     const double e1 = down1(o.str[1]), e3 = down1(o.str[3]), e6 = down1(o.str[6]), e7 = down1(o.str[7]);
-    if (w > 0 && cw) {
+    if (w > 0) {
       s_edge[w][0][lx] = o.str[2];
       s_edge[w][1][lx] = e3;
       s_edge[w][2][lx] = o.str[5];
@@ -1023,15 +948,69 @@ __global__ __launch_bounds__(64 * (W + 1), (64 * (W + 1) + 255) / 256) void k_ev
       un = ro.u;
       vn = ro.v;
     }
-    // (D) publish the edge velocities of subcycle k: one tagged 16-byte store each
-    if (edge && k + 1 < r.nsub) {
-      char* g = r.gran[k & 1];
-      const unsigned tag = r.epoch0 + (unsigned)k + 1u;
-      st_granules(g + q * 32, un, vn, tag);
+    if (k + 1 == r.nsub) break;
+    // (D) publish the edge velocities of subcycle k, then the progress word
+    double* xu = r.xu[k & 1];
+    if (edge) {
+      st_agent(xu + q, un);
+      st_agent(xu + a.n + q, vn);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int fd = s_fd[w][c][lx];
-        if (fd >= 0) st_granules(g + (size_t)fd * 32, un, vn, tag);
+        if (fd >= 0) {
+          st_agent(xu + fd, un);
+          st_agent(xu + a.n + fd, vn);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const unsigned target = r.epoch0 + (unsigned)k + 1u;
+    if (threadIdx.x == 0)
+      __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (E) wait until every producer of this tile's halo has published subcycle k
+    if (w == 0) {
+      const int dep = lx < RES_MAXDEP ? r.deps[tile * RES_MAXDEP + lx] : -1;
+      bool have = dep < 0;
+      int bad = 0;
+      const long long t0 = wall_clock64();
+      while (true) {
+        if (!have) {
+          const unsigned v = __hip_atomic_load(r.prog + (size_t)dep * RES_STRIDE, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+          have = (int)(v - target) >= 0;
+        }
+        if (__all(have)) break;
+        if (lx == 0) {
+          bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!bad && wall_clock64() - t0 > r.spin_ticks) {
+            __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bad = 1;
+          }
+        }
+        bad = __shfl(bad, 0);
+        if (bad) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (lx == 0) s_abort = bad;
+    }
+    __syncthreads();
+    if (s_abort) return;
+    // every exchanged velocity is an agent-scope load
+    if (foreign) {
+      un = ld_agent(xu + q);
+      vn = ld_agent(xu + a.n + q);
+    }
+    if (south_h) {
+      us = ld_agent(xu + q - nx);
+      vs = ld_agent(xu + a.n + q - nx);
+    }
+    if (west_h) {
+      uwh = ld_agent(xu + q - 1);
+      vwh = ld_agent(xu + a.n + q - 1);
+      if (w == 0) {
+        uswh = ld_agent(xu + q - nx - 1);
+        vswh = ld_agent(xu + a.n + q - nx - 1);
       }
     }
   }
@@ -1424,8 +1403,8 @@ void Evp::set_option(const char* key, int value) {
     resident_on = value != 0;
     if (value == 2) resident_failed = false;       // 2: also forget an earlier time-out
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
-    CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11,
-                 "resident_waves must be 0, 4, 6, 8 or 11");
+    CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
+                 "resident_waves must be 0, 4, 6, 8, 11 or 12");
     res_w_opt = value;
   } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 13 || value == 14 || value == 16,
@@ -1824,50 +1803,73 @@ int Evp::resident_waves() const {
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
   auto tiles = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
   if (res_w_opt) return tiles(res_w_opt) <= ncu ? res_w_opt : 0;
-  for (int w : {4, 6, 8, 11})    // the shortest workgroup that still gives every tile its own CU
+  for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
     if (tiles(w) <= ncu) return w;
   return 0;
 }
 
-// which U-cell's velocity a cell holds: itself inside the physical domain, the mirrored cell for an on-rank ghost
+// producer tiles of every tile's halo: the cells it re-reads each subcycle, traced through the on-rank ghost copies
 void Evp::build_resident(int W) {
   const int nx = dom.nx_block, ny = dom.ny_block;
   const Block& bl = dom.all[dom.local[0]];
+  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
   const int tiles_x = ((nx - 2) + (TX - 1) - 1) / (TX - 1), tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1);
-  std::vector<int32_t> src((size_t)nx * ny, -1);
-  for (int j = bl.jlo; j <= bl.jhi; ++j)
-    for (int i = bl.ilo; i <= bl.ihi; ++i) src[(size_t)(j - 1) * nx + (i - 1)] = (j - 1) * nx + (i - 1);
-  for (size_t e = 0; e < dom.hsrc.size(); ++e) src[dom.hdst[e]] = src[dom.hsrc[e]];
-  res_src.alloc(src.size());
-  res_src.upload(src.data(), stream);
-  if (res_abort.n == 0) {
-    res_abort.alloc(32);
-    res_abort.zero(stream);
+  const int nt = tiles_x * tiles_y;
+  std::vector<int32_t> src_of((size_t)nx * ny, -1);
+  for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
+  auto owner = [&](int i, int j) -> int {   // 1-based cell -> tile that produces its velocity, -1: nobody (constant)
+    if (i < 1 || i > nx || j < 1 || j > ny) return -1;
+    int q = (j - 1) * nx + (i - 1);
+    if (src_of[q] >= 0) q = src_of[q];
+    const int si = q % nx + 1, sj = q / nx + 1;
+    if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
+    return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
+  };
+  std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
+  for (int t = 0; t < nt; ++t) {
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    int nd = 0;
+    auto add = [&](int i, int j) {
+      const int o = owner(i, j);
+      if (o < 0 || o == t) return;
+      for (int k = 0; k < nd; ++k)
+        if (deps[(size_t)t * RES_MAXDEP + k] == o) return;
+      CICE_REQUIRE(nd < RES_MAXDEP, "resident EVP loop: a tile has more producers than RES_MAXDEP");
+      deps[(size_t)t * RES_MAXDEP + nd++] = o;
+    };
+    for (int w = -1; w < W; ++w)
+      for (int lx = -1; lx < TX; ++lx) {
+        const int i = i0 + lx, j = j0 + w;
+        if (i > ihi + 1 || j > jhi + 1) continue;
+        const bool uown = lx >= 0 && w >= 0 && lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
+        if (!uown) add(i, j);
+      }
   }
+  res_deps.alloc(deps.size());
+  res_deps.upload(deps.data(), stream);
+  res_prog.alloc((size_t)(nt + 1) * RES_STRIDE);
+  res_prog.zero(stream);
+  res_epoch = 0;
   for (int k = 0; k < 2; ++k)
-    if (res_gran[k].n < 4 * n) {      // 32 B per cell; tags start at 0 = never published
-      res_gran[k].alloc(4 * n);
-      res_gran[k].zero(stream);
-      res_epoch = 0;
-    }
+    if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
   CICE_HIP(hipStreamSynchronize(stream));
   res_w = W;
-  res_tiles = tiles_x * tiles_y;
+  res_tiles = nt;
 }
 
 template <int W>
 static void launch_res(const ResArgs& r, bool damp, dim3 g, hipStream_t s) {
-  if (damp) hipLaunchKernelGGL((k_evp_resident<W, true>), g, dim3(64 * (W + 1)), 0, s, r);
-  else hipLaunchKernelGGL((k_evp_resident<W, false>), g, dim3(64 * (W + 1)), 0, s, r);
+  if (damp) hipLaunchKernelGGL((k_evp_resident<W, true>), g, dim3(64 * W), 0, s, r);
+  else hipLaunchKernelGGL((k_evp_resident<W, false>), g, dim3(64 * W), 0, s, r);
 }
 
 // subcycles ksub0 .. ksub0+nsub-1 in one launch; false: not done (time-out), the state is as it was
 bool Evp::run_resident(int ksub0, int nsub) {
   const int W = resident_waves();
-  if (W != res_w || res_src.n == 0) build_resident(W);
-  if (res_epoch > 0xf0000000u) {   // tags are compared for equality: start over long before they wrap
-    res_gran[0].zero(stream);
-    res_gran[1].zero(stream);
+  if (W != res_w || res_deps.n == 0) build_resident(W);
+  if (res_epoch > 0x70000000u) {   // progress words are compared modulo 2^32 over at most 2^31
+    res_prog.zero(stream);
     res_epoch = 0;
   }
   ResArgs r{};
@@ -1877,11 +1879,14 @@ bool Evp::run_resident(int ksub0, int nsub) {
   r.nsub = nsub;
   r.last = (ksub0 + nsub - 1 == sc.ndte) ? 1 : 0;
   r.epoch0 = res_epoch;
-  r.abort_flag = res_abort.p;
-  r.src = res_src.p;
-  r.gran[0] = (char*)res_gran[0].p;
-  r.gran[1] = (char*)res_gran[1].p;
+  r.prog = res_prog.p;
+  r.abort_flag = res_prog.p + (size_t)res_tiles * RES_STRIDE;
+  r.deps = res_deps.p;
+  r.xu[0] = res_xu[0].p;
+  r.xu[1] = res_xu[1].p;
   r.spin_ticks = 20000000;   // 0.2 s of the 100 MHz wall clock
+  for (int k = 0; k < 2; ++k)   // cells nobody publishes keep their value: both exchange copies start as (u, v)
+    CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
   const dim3 g(8 * ((res_tiles + 7) / 8));
   const bool damp = sc.evp_damping != 0;
   switch (W) {
@@ -1889,7 +1894,8 @@ bool Evp::run_resident(int ksub0, int nsub) {
     case 6: launch_res<6>(r, damp, g, stream); break;
     case 8: launch_res<8>(r, damp, g, stream); break;
     case 11: launch_res<11>(r, damp, g, stream); break;
-    default: throw Error{CICE_EINVAL, "resident_waves must be 4, 6, 8 or 11"};
+    case 12: launch_res<12>(r, damp, g, stream); break;
+    default: throw Error{CICE_EINVAL, "resident_waves must be 4, 6, 8, 11 or 12"};
   }
   CICE_HIP(hipGetLastError());
   unsigned aborted = 0;
@@ -1900,7 +1906,8 @@ bool Evp::run_resident(int ksub0, int nsub) {
     std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident); "
                          "falling back to one launch per pair of subcycles\n");
     resident_failed = true;
-    res_abort.zero(stream);
+    res_prog.zero(stream);
+    res_epoch = 0;
     return false;
   }
   cur = 1 - cur;   // the result is in the other copy whatever the parity of nsub

@@ -568,7 +568,7 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
             orc.set_strength_parameters()
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
-        for W in ((0, 11) if big else (0, 4, 6, 8, 11)):
+        for W in ((0, 11, 12) if big else (0, 4, 6, 8, 11, 12)):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
