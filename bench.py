@@ -75,6 +75,7 @@ def parse():
     p.add_argument("--slabs", type=int, default=0,
                    help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
                         "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
+    p.add_argument("--resident-waves", type=int, default=0, help="wavefronts per workgroup of k_evp_resident (0 = library's choice)")
     p.add_argument("--no-resident", action="store_true", help="do not run the whole subcycle loop in one launch (k_evp_resident)")
     p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
     p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/13/14/16); 0 = auto")
@@ -430,11 +431,15 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     if fused:
         tile = f"two subcycles per launch; workgroup {fw} wavefronts x 64 lanes owns {fw - 3} rows x 59 columns"
     ctx.evp_set_option("resident", 0 if args.no_resident else 1)
+    if tune and args.resident_waves:
+        ctx.evp_set_option("resident_waves", args.resident_waves)
     resident = bool(ctx.evp_get_info("resident"))
     rw = ctx.evp_get_info("resident_waves") if resident else 0
     if resident:
+        dense = bool(ctx.evp_get_info("resident_dense"))
         tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
-                f"(owns {rw - 1} rows x 63 columns), one workgroup per CU")
+                f"(owns {rw - 1} rows x 63 columns), " + ("three workgroups per CU (every slot of the chip)" if dense
+                                                          else "one workgroup per CU"))
     ctx.evp_upload(state)
     ctx.evp_prepare(DT)
     nt, nu = ctx.evp_active_cells()

@@ -552,6 +552,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "fused_waves")) *value = c_->evp->fused_waves();
   else if (!std::strcmp(key, "resident")) *value = c_->evp->can_reside() ? 1 : 0;
   else if (!std::strcmp(key, "resident_waves")) *value = c_->evp->resident_waves();
+  else if (!std::strcmp(key, "resident_dense")) *value = c_->evp->can_reside() && c_->evp->resident_dense() ? 1 : 0;
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
   CICE_CATCH
 }

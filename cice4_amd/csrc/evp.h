@@ -37,7 +37,8 @@ class Evp {
   int tile_waves() const { return waves; }
   int tile_rows() const { return rows_per_wave; }
   bool can_reside() const;   // the whole subcycle loop in one launch, state in registers (k_evp_resident)
-  int resident_waves() const;  // its wavefronts per workgroup (0: grid too large for one tile per CU)
+  int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
+  bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_fuse() const;     // two subcycles per launch on this domain
   int fused_waves() const;   // wavefronts per workgroup of the fused kernel
 
@@ -67,6 +68,8 @@ class Evp {
   // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
+  bool res_dense = true;         // allow three 4-wavefront workgroups per CU
+  int res_level = 0;             // 0: dense allowed, 1: one workgroup per CU only (after a dense time-out)
   int res_w = 0, res_tiles = 0;  // what res_deps was built for
   unsigned res_epoch = 0;
   DevBuf<int32_t> res_deps;

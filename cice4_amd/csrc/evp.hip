@@ -1401,7 +1401,12 @@ void Evp::set_option(const char* key, int value) {
     fuse_on = value != 0;
   } else if (!std::strcmp(key, "resident")) {      // whole loop in one launch where the grid fits (default on)
     resident_on = value != 0;
-    if (value == 2) resident_failed = false;       // 2: also forget an earlier time-out
+    if (value == 2) {                              // 2: also forget an earlier time-out
+      resident_failed = false;
+      res_level = 0;
+    }
+  } else if (!std::strcmp(key, "resident_dense")) {   // three 4-wavefront workgroups per CU where that fills the chip
+    res_dense = value != 0;
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
                  "resident_waves must be 0, 4, 6, 8, 11 or 12");
@@ -1794,6 +1799,23 @@ bool Evp::can_reside() const {
   return resident_waves() > 0;
 }
 
+// Shape of the resident launch.  One workgroup per CU (W wavefronts, the shortest W that gives every tile its own CU),
+// or -- "dense" -- three 4-wavefront workgroups per CU (one wavefront per SIMD each, 3 x 148 VGPRs and 3 x 42 KB of LDS
+// fit): the same three wavefronts per SIMD as 11- or 12-wavefront tiles, but while one workgroup waits for its
+// hand-off the other two compute.  Dense needs EVERY slot of the chip (gx1: 768 tiles on 256 CUs); if the dispatcher
+// does not place them all, the launch times out and the next one uses one workgroup per CU (res_level).
+bool Evp::resident_dense() const {   // more tiles than CUs: several workgroups per CU
+  const int W = resident_waves();
+  if (W == 0) return false;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+  return tx * (((dom.ny_block - 2) + (W - 1) - 1) / (W - 1)) > ncu;
+}
+
 int Evp::resident_waves() const {
   int ncu = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -1802,10 +1824,17 @@ int Evp::resident_waves() const {
   }
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
   auto tiles = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
-  if (res_w_opt) return tiles(res_w_opt) <= ncu ? res_w_opt : 0;
+  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu;
+  if (res_w_opt) return tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok) ? res_w_opt : 0;
+  int single = 0;
   for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
-    if (tiles(w) <= ncu) return w;
-  return 0;
+    if (tiles(w) <= ncu) {
+      single = w;
+      break;
+    }
+  // wavefronts on the busiest SIMD: dense ceil(tiles / CUs), single ceil(W / 4); a tie goes to dense (hand-offs overlap)
+  if (dense_ok && (single == 0 || (tiles(4) + ncu - 1) / ncu <= (single + 3) / 4)) return 4;
+  return single;
 }
 
 // producer tiles of every tile's halo: the cells it re-reads each subcycle, traced through the on-rank ghost copies
@@ -1889,6 +1918,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
     CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
   const dim3 g(8 * ((res_tiles + 7) / 8));
   const bool damp = sc.evp_damping != 0;
+  const bool dense = resident_dense();
   switch (W) {
     case 4: launch_res<4>(r, damp, g, stream); break;
     case 6: launch_res<6>(r, damp, g, stream); break;
@@ -1903,9 +1933,11 @@ bool Evp::run_resident(int ksub0, int nsub) {
   CICE_HIP(hipStreamSynchronize(stream));
   res_epoch += (unsigned)nsub;
   if (aborted) {
-    std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident); "
-                         "falling back to one launch per pair of subcycles\n");
-    resident_failed = true;
+    std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident); this range runs as one "
+                         "launch per pair of subcycles%s\n",
+                 dense ? ", later ones with one workgroup per CU" : " and so do later ones");
+    if (dense) res_level = 1;   // not every slot of the chip was free: one workgroup per CU from now on
+    else resident_failed = true;
     res_prog.zero(stream);
     res_epoch = 0;
     return false;

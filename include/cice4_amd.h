@@ -180,11 +180,15 @@ int cice_evp_finish(cice_ctx *ctx);
  * "fused_waves" (0 = auto, 8, 12, 13, 14, 16), "resident" (0/1, default 1: the whole subcycle loop in ONE launch with
  * the state in registers -- one block per rank, no inter-rank or tripole exchange during the subcycling, at most one
  * 64 x W tile per compute unit (gx3, gx1; not 0.1 degree); 2 = on and forget an earlier time-out; environment
- * CICE4_AMD_RESIDENT=0 switches it off), "resident_waves" (0 = auto, 4, 6, 8, 11, 12).
+ * CICE4_AMD_RESIDENT=0 switches it off), "resident_waves" (0 = auto, 4, 6, 8, 11, 12), "resident_dense" (0/1, default 1:
+ * three 4-wavefront workgroups per compute unit where that fills the chip exactly -- gx1 -- so that hand-offs of one
+ * overlap the arithmetic of the others; a launch that does not get every slot times out and later ones use one workgroup
+ * per compute unit).
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
  * (1 if this domain runs two subcycles per launch), "fused_waves", "resident" (1 if the next cice_evp_subcycles
- * of two or more subcycles runs as one launch), "resident_waves". */
+ * of two or more subcycles runs as one launch), "resident_waves", "resident_dense" (1 if with several workgroups per
+ * compute unit). */
 int cice_evp_set_option(cice_ctx *ctx, const char *key, int value);
 int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare

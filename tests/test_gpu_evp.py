@@ -568,17 +568,22 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
             orc.set_strength_parameters()
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
-        for W in ((0, 11, 12) if big else (0, 4, 6, 8, 11, 12)):
+        # (W, dense): at gx1 size the default is "dense" -- three 4-wavefront workgroups on every CU
+        for W, dense in (((0, 1), (4, 1), (0, 0), (11, 0), (12, 0)) if big else
+                         ((0, 1), (4, 1), (6, 1), (8, 1), (11, 1), (12, 1))):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
-            if not ctx.evp_get_info("resident"):
-                assert big and W == 0 or W in (4, 6, 8), (W, "grid should fit")    # more tiles than CUs at this height
-                continue
+            ctx.evp_set_option("resident_dense", dense)
+            assert ctx.evp_get_info("resident") == 1, (W, dense, "grid should fit")
+            assert ctx.evp_get_info("resident_dense") == (1 if big and dense else 0)
+            if big and W == 0:
+                assert ctx.evp_get_info("resident_waves") == (4 if dense else 11)
             ctx.evp(DT, sg)
-            assert ctx.evp_get_info("resident") == 1, "the resident loop timed out and fell back"
+            assert ctx.evp_get_info("resident") == 1 and ctx.evp_get_info("resident_dense") == (1 if big and dense else 0), \
+                "the resident loop timed out and fell back"
             for k in keys:
-                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, k)
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, dense, k)
     # a loop cut into ranges: 1..5 (one launch), 6 (single subcycle: the ordinary kernel), 7..NDTE
     b = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
