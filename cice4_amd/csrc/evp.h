@@ -69,6 +69,7 @@ class Evp {
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
   bool res_dense = true;         // allow three 4-wavefront workgroups per CU
+  int res_spin_us = 200000;      // bound of every wait inside the resident kernel
   int res_level = 0;             // 0: dense allowed, 1: one workgroup per CU only (after a dense time-out)
   int res_w = 0, res_tiles = 0;  // what res_deps was built for
   unsigned res_epoch = 0;

@@ -1405,6 +1405,9 @@ void Evp::set_option(const char* key, int value) {
       resident_failed = false;
       res_level = 0;
     }
+  } else if (!std::strcmp(key, "resident_spin_us")) {   // how long a tile waits for its neighbours before giving up
+    CICE_REQUIRE(value >= 0, "resident_spin_us must be >= 0");
+    res_spin_us = value;
   } else if (!std::strcmp(key, "resident_dense")) {   // three 4-wavefront workgroups per CU where that fills the chip
     res_dense = value != 0;
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
@@ -1913,7 +1916,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
   r.deps = res_deps.p;
   r.xu[0] = res_xu[0].p;
   r.xu[1] = res_xu[1].p;
-  r.spin_ticks = 20000000;   // 0.2 s of the 100 MHz wall clock
+  r.spin_ticks = (long long)res_spin_us * 100;   // wall_clock64() runs at 100 MHz
   for (int k = 0; k < 2; ++k)   // cells nobody publishes keep their value: both exchange copies start as (u, v)
     CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
   const dim3 g(8 * ((res_tiles + 7) / 8));

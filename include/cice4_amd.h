@@ -183,7 +183,8 @@ int cice_evp_finish(cice_ctx *ctx);
  * CICE4_AMD_RESIDENT=0 switches it off), "resident_waves" (0 = auto, 4, 6, 8, 11, 12), "resident_dense" (0/1, default 1:
  * three 4-wavefront workgroups per compute unit where that fills the chip exactly -- gx1 -- so that hand-offs of one
  * overlap the arithmetic of the others; a launch that does not get every slot times out and later ones use one workgroup
- * per compute unit).
+ * per compute unit), "resident_spin_us" (default 200000: how long a tile of the resident loop waits for a neighbour
+ * before the launch gives up and the range is run by the launch-per-pair loop; 0 makes every wait fail -- tests).
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
  * (1 if this domain runs two subcycles per launch), "fused_waves", "resident" (1 if the next cice_evp_subcycles

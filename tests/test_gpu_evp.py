@@ -596,6 +596,37 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
         assert np.array_equal(b[k], ref[k]), ("ranges", k)
 
 
+def test_resident_loop_gives_up_cleanly(ctx, orc):
+    """A tile of the one-launch loop that does not hear from a neighbour in time raises the abort word, every
+    workgroup leaves, and the caller's state is as it was: the range is then run by the launch-per-pair loop.  With
+    resident_spin_us = 0 every wait fails: the dense shape (gx1 size) falls back to one workgroup per CU for the next
+    call, that one falls back for good -- and all three calls give the bits of the ordinary loop."""
+    nxg, nyg = 320, 384
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=5)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=3, cover="patchy")
+    ref, _ = _evp_with(ctx, grid, s, 12, False, fuse=1, resident=0)
+    ctx.evp_init(grid, ndte=12, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_spin_us", 0)
+    want = [(1, 1, 4), (1, 0, 11), (0, 0, None)]            # (resident, dense, waves) before each call
+    for call in range(3):
+        assert (ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")) == want[call][:2], call
+        if want[call][2]:
+            assert ctx.evp_get_info("resident_waves") == want[call][2]
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp(DT, sg)
+        for k in EVP_OUT_FIELDS + ("iceumask",):
+            assert np.array_equal(sg[k], ref[k]), (call, k)
+    ctx.evp_set_option("resident_spin_us", 200000); ctx.evp_set_option("resident", 2)    # forgiven: dense again, and it works
+    assert (ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")) == (1, 1)
+    sg = {k: v.copy() for k, v in s.items()}
+    ctx.evp(DT, sg)
+    assert ctx.evp_get_info("resident_dense") == 1
+    for k in EVP_OUT_FIELDS + ("iceumask",):
+        assert np.array_equal(sg[k], ref[k]), ("after", k)
+
+
 def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
     """Several blocks per rank without overlap rows, or a cyclic N-S edge: ghost rows are refreshed
     after every subcycle, so the one-subcycle kernel must run."""
