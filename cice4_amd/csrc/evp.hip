@@ -817,7 +817,7 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   __shared__ double s_west[W][2];
   __shared__ double s_edge[W][4][TX];
   __shared__ double s_x[W][8][TX];
-  __shared__ double s_m[W][5][TX];
+  __shared__ double s_m[W][10][TX];             // nine metrics + strength
   __shared__ int s_fd[W][3][TX];
   __shared__ int s_abort;
   const int nt = a.tiles_x * a.tiles_y;
@@ -867,12 +867,12 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   double s[12];
 #pragma unroll
   for (int c = 0; c < 12; ++c) s[c] = tact ? a.sig_in[(size_t)c * a.n + q] : c0;
-  // the four primary lengths of the cell (the nine metrics are recomputed from them every subcycle, exactly as
-  // k_subcycle<DERIVE> does: ice_grid.F90:335-361) and its strength
-  // (they wait in LDS too, like everything that is read once per subcycle: registers are for the stresses)
-  if (tact) {
-    s_m[w][0][lx] = a.HTN[q]; s_m[w][1][lx] = a.HTE[q]; s_m[w][2][lx] = a.HTN[q - nx]; s_m[w][3][lx] = a.HTE[q - 1];
+  // everything that is read once per subcycle waits in LDS: registers are for the stresses
+  if (tact) {   // the nine metrics (from memory: re-deriving them from HTN / HTE every subcycle cost 2 %) and the strength
+    s_m[w][0][lx] = a.dxt[q]; s_m[w][1][lx] = a.dyt[q]; s_m[w][2][lx] = a.dxhy[q]; s_m[w][3][lx] = a.dyhx[q];
     s_m[w][4][lx] = a.strength[q];
+    s_m[w][5][lx] = a.cxp[q]; s_m[w][6][lx] = a.cyp[q]; s_m[w][7][lx] = a.cxm[q]; s_m[w][8][lx] = a.cym[q];
+    s_m[w][9][lx] = a.tinyarea[q];
   }
   // the eight read-only inputs of the momentum equation wait in LDS (read back by the same lane once per subcycle)
   if (uact) {
@@ -923,10 +923,9 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
 #pragma unroll
     for (int c = 0; c < 8; ++c) o.str[c] = c0;
     if (tact) {
-      const double hn = s_m[w][0][lx], he = s_m[w][1][lx], hn_s = s_m[w][2][lx], hew = s_m[w][3][lx];
-      const double Dxt = p5 * (hn + hn_s), Dyt = p5 * (he + hew), Dxhy = p5 * (he - hew), Dyhx = p5 * (hn - hn_s);
-      const double Cyp = 1.5 * he - p5 * hew, Cxp = 1.5 * hn - p5 * hn_s, Cym = -(1.5 * hew - p5 * he),
-                   Cxm = -(1.5 * hn_s - p5 * hn), Tiny = puny * (Dxt * Dyt);
+      const double Dxt = s_m[w][0][lx], Dyt = s_m[w][1][lx], Dxhy = s_m[w][2][lx], Dyhx = s_m[w][3][lx],
+                   Cxp = s_m[w][5][lx], Cyp = s_m[w][6][lx], Cxm = s_m[w][7][lx], Cym = s_m[w][8][lx],
+                   Tiny = s_m[w][9][lx];
       stress_cell<true, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm, Cym,
                               lastk ? a.tarear[q] : c0, Tiny, s_m[w][4][lx], s, o, lastk);
     }
@@ -943,7 +942,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
       const double sx = o.str[0] + e1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];   // :1415-1416 order
       const double sy = o.str[4] + s_edge[w + 1][2][lx] + e6 + s_edge[w + 1][3][lx];   // :1417-1418 order
       const double uocn = s_x[w][1][lx], vocn = s_x[w][2][lx];
-      stepu_cell(un, vn, s_x[w][0][lx], uocn, vocn, uocn * cosw - vocn * sinw, vocn * cosw + uocn * sinw,   // :915-916
+      // waterx, watery are evp_prep2's own expressions of uocn, vocn (:915-916): recomputed, same bits
+      stepu_cell(un, vn, s_x[w][0][lx], uocn, vocn, uocn * cosw - vocn * sinw, vocn * cosw + uocn * sinw,
                  s_x[w][3][lx], s_x[w][4][lx], s_x[w][5][lx], s_x[w][6][lx], s_x[w][7][lx], sx, sy, ro);
       un = ro.u;
       vn = ro.v;
@@ -1797,7 +1797,7 @@ void Evp::launch_subcycle_pair(int ksub) {
 bool Evp::can_reside() const {
   static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT"); return e && e[0] == '0'; }();
   if (!resident_on || resident_failed || env_off) return false;
-  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || !(derive_ok && derive_on)) return false;
+  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0) return false;
   if (halo.has_refresh() || halo.has_fold() || halo.multi_rank()) return false;
   return resident_waves() > 0;
 }
