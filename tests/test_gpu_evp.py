@@ -596,6 +596,38 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
         assert np.array_equal(b[k], ref[k]), ("ranges", k)
 
 
+def test_resident_loop_is_repeatable(ctx):
+    """300 one-launch loops (36,000 subcycles, 768 tiles, ~90 exchanged velocities per tile and subcycle) from the same
+    state: every call must return the bits of the first one, which are those of the launch-per-pair loop.  A hand-off
+    that once in a while let a stale velocity through would show here: one wrong ulp grows to 1e-2 within a step."""
+    nxg, nyg = 320, 384
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=8, cover="patchy")
+    ref, _ = _evp_with(ctx, grid, s, NDTE, False, fuse=1, resident=0)
+    ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident", 2)
+    assert ctx.evp_get_info("resident_dense") == 1
+    ctx.evp_upload({k: v.copy() for k, v in s.items()})
+    out = {k: np.empty_like(v) for k, v in s.items()}
+    for rep in range(300):
+        if rep % 100 == 0:                      # the whole call now and then, the loop alone otherwise
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp(DT, sg)
+            for k in EVP_OUT_FIELDS:
+                assert np.array_equal(sg[k], ref[k]), (rep, k)
+            ctx.evp_upload({k: v.copy() for k, v in s.items()})
+        ctx.evp_prepare(DT)
+        ctx.evp_subcycles(1, NDTE)
+        ctx.evp_finish()
+        ctx.evp_download(out)
+        for k in ("uvel", "vvel", "stressp_1", "stress12_3"):
+            assert np.array_equal(out[k], ref[k]), (rep, k)
+        ctx.evp_upload({k: v.copy() for k, v in s.items()})
+    assert ctx.evp_get_info("resident") == 1
+
+
 def test_resident_loop_gives_up_cleanly(ctx, orc):
     """A tile of the one-launch loop that does not hear from a neighbour in time raises the abort word, every
     workgroup leaves, and the caller's state is as it was: the range is then run by the launch-per-pair loop.  With
