@@ -693,6 +693,44 @@ def main():
             pcie["therm1_plus_evp_ms"] = pcie["ms_per_call"] + pcie["step_therm1"]["ms_per_call"]
             pcie["resident_ms"] = 1e3 * m["t_evp"] / args.steps + thermo["ms_per_pass"]
 
+    # ---- PCIe-inclusive horizontal transport: cice_transport_remap = upload of the state,
+    # state_to_tracers -> horizontal_remap -> tracers_to_state -> bound_state on the device, download.  Never `value`.
+    if pcie is not None and thermo is not None:
+        progress("gx1: PCIe-inclusive transport_remap")
+        try:
+            tb, _ = thermo_case(dom, coherent=args.thermo_coherence)
+            g = m["grid"]
+            ctx.transport_init({k: g[k] for k in ("HTN", "HTE", "dxt", "dyt", "dxu", "dyu", "tarear", "hm")},
+                               ntrcr=2, trcr_depend=(0, 1))
+            tot = tb["aicen"].sum(axis=1)
+            sc_ = np.where(tot > 0.95, 0.95 / np.maximum(tot, 1e-30), 1.0)[:, None]
+            ts = {k: np.ascontiguousarray(tb[k] * sc_) for k in ("aicen", "vicen", "vsnon", "eicen", "esnon")}
+            ts["trcrn"] = np.ascontiguousarray(tb["trcrn"])
+            ts["aice0"] = np.ascontiguousarray(1.0 - ts["aicen"].sum(axis=1))
+            nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
+            jj, ii = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+            ts["uvel"] = np.array(np.broadcast_to(0.2 * np.sin(2 * np.pi * ii / nx) * np.cos(np.pi * jj / ny), (nb, ny, nx)))
+            ts["vvel"] = np.array(np.broadcast_to(0.2 * np.cos(2 * np.pi * ii / nx) * np.sin(2 * np.pi * jj / ny), (nb, ny, nx)))
+            for v in ts.values():
+                ctx.host_register(v)
+            t0s = {k: v.copy() for k, v in ts.items()}
+            ttimes = []
+            for _ in range(4):
+                for k, v in t0s.items():
+                    ts[k][...] = v
+                t1 = time.perf_counter()
+                rc = ctx.transport_remap(DT, ts)
+                ttimes.append(time.perf_counter() - t1)
+            ctx.host_unregister_all()
+            if rc == (0, 0, 0):
+                pcie["transport_remap"] = {
+                    "what": "cice_transport_remap (advection = 'remap', ncat = 5, 9 tracers per category incl. 5 enthalpies): upload "
+                            "of the state (36 planes) + velocities, seven kernels + nine halo updates on the device, download (34 planes); "
+                            "page-locked host arrays", "ms_per_call": 1e3 * min(ttimes[1:])}
+            del ts, t0s, tb
+        except lib.CiceError as e:
+            progress("transport timing skipped: %s" % e)
+
     # ---- the 0.1-degree configuration (BASELINE.json configs[4]) inside the same line: a short run, EVP only + thermo
     tenth = None
     if args.workload == "gx1" and not args.no_tenth:
