@@ -814,7 +814,6 @@ template <int W, bool DAMP>
 __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(const ResArgs r) {
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
-  __shared__ double s_west[W][2];
   __shared__ double s_edge[W][4][TX];
   __shared__ double s_x[W][8][TX];
   __shared__ double s_m[W][10][TX];             // nine metrics + strength
@@ -839,8 +838,10 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   const bool foreign = ok && !uown;                 // velocity of this lane's own position comes from elsewhere
   const bool tact = ok && a.icetmask[q] == 1;
   const bool sown = tact && own_i && (min(j, jhi) - j0) < (W - 1);
-  const bool south_h = w == 0 && in_i;              // row j0-1 (>= 1) from the exchange copy
-  const bool west_h = lx == 0 && ok;                // column i0-1 (>= 1)
+  // the velocity south of this lane comes from the wavefront below through LDS where that wavefront owns it, else
+  // (row j0-1, or a column owned by the east tile / the ghost column) from the exchange copy
+  const bool south_h = ok && (w == 0 || !(lx < TX - 1 && i <= ihi));
+  const bool west_h = lx == 0 && ok;                // column i0-1 (>= 1): west and south-west of lane 0
   // a late workgroup of an aborted launch leaves at once
   if (threadIdx.x == 0) s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
@@ -859,10 +860,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   if (west_h) {
     uwh = a.u_in[q - 1];
     vwh = a.v_in[q - 1];
-    if (w == 0) {
-      uswh = a.u_in[q - nx - 1];
-      vswh = a.v_in[q - nx - 1];
-    }
+    uswh = a.u_in[q - nx - 1];
+    vswh = a.v_in[q - nx - 1];
   }
   double s[12];
 #pragma unroll
@@ -897,18 +896,16 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   StressOut o;
   StepuOut ro{};
 
+  // three barriers per subcycle: (C) str rows, (D) stores drained before the progress word, (E) progress of the
+  // producers seen -- (E) also publishes the wavefronts' own velocity rows (s_uv) to the wavefront above
+  s_uv[w][0][lx] = un;
+  s_uv[w][1][lx] = vn;
+  __syncthreads();
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
     // (A) velocities of the row below and of the western neighbour
-    s_uv[w][0][lx] = un;
-    s_uv[w][1][lx] = vn;
-    if (lx == 0) {
-      s_west[w][0] = uwh;
-      s_west[w][1] = vwh;
-    }
-    __syncthreads();
-    if (w > 0) {
+    if (!south_h && w > 0) {
       us = s_uv[w - 1][0][lx];
       vs = s_uv[w - 1][1][lx];
     }
@@ -916,8 +913,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     if (lx == 0) {
       uw = uwh;
       vw = vwh;
-      usw = w > 0 ? s_west[w - 1][0] : uswh;
-      vsw = w > 0 ? s_west[w - 1][1] : vswh;
+      usw = uswh;
+      vsw = vswh;
     }
     // (B) stress (ice_dyn_evp.F90:1065-1289)
 #pragma unroll
@@ -949,6 +946,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
       vn = ro.v;
     }
     if (k + 1 == r.nsub) break;
+    s_uv[w][0][lx] = un;     // read after (E); the reads of the previous values lie before (C)
+    s_uv[w][1][lx] = vn;
     // (D) publish the edge velocities of subcycle k, then the progress word
     double* xu = r.xu[k & 1];
     if (edge) {
@@ -1008,10 +1007,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     if (west_h) {
       uwh = ld_agent(xu + q - 1);
       vwh = ld_agent(xu + a.n + q - 1);
-      if (w == 0) {
-        uswh = ld_agent(xu + q - nx - 1);
-        vswh = ld_agent(xu + a.n + q - nx - 1);
-      }
+      uswh = ld_agent(xu + q - nx - 1);
+      vswh = ld_agent(xu + a.n + q - nx - 1);
     }
   }
 
