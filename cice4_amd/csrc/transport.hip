@@ -228,40 +228,30 @@ __global__ __launch_bounds__(256) void k_tr_departure(const TransportKernelArgs 
 }
 
 // ---- locate_triangles :1763-3146 + triangle_coordinates :3155-3297 (cubic) for one edge ------------------
-struct Tri {
-  double xp[NG][4], yp[NG][4], area[NG];  // vertex 0 = centroid after triangle_coordinates
-  int di[NG], dj[NG];                     // iflux - i, jflux - j
-  bool on[NG];                            // |triarea| >= eps16 * areafac_c
+// The geometry of an edge's departure region (Geo) is worked out once; the six triangle groups are then produced ONE AT
+// A TIME (tri_group<G>: the reference's case analysis with only group G's assignments kept -- the conditions are a
+// handful of comparisons), so that a thread holds one triangle (9 doubles) instead of six while it integrates.
+struct Geo {
+  double xdl0, ydl0, xdr0, ydr0;   // departure points of the two corners (edge-local coordinates)
+  double xdl, ydl, xdr, ydr;       // ... after the redefinition of points that lie in side cells (:2230-2238)
+  double xdm, ydm, xil, yil, xir, yir, xic;
+  double afl, afr, afc;
+};
+struct Tri1 {
+  double xp[4], yp[4], area;       // vertex 0 = centroid after triangle_coordinates; 1..3 quadrature points
+  int di, dj;                      // iflux - i, jflux - j
+  bool on;                         // |triarea| >= eps16 * areafac_c
 };
 
-__device__ __forceinline__ void set_tri(Tri& t, double* fact, int ng, double x1, double y1, double x2, double y2,
-                                        double x3, double y3, int di, int dj, double f) {
-  t.xp[ng][1] = x1; t.yp[ng][1] = y1;
-  t.xp[ng][2] = x2; t.yp[ng][2] = y2;
-  t.xp[ng][3] = x3; t.yp[ng][3] = y3;
-  t.di[ng] = di; t.dj[ng] = dj;
-  fact[ng] = f;
-}
-
 // north: dir = 1, east: dir = 0.  Returns false if the edge has no departure region (both corner points at rest).
-__device__ bool locate_triangles(const TransportKernelArgs& a, const Cell& k, int dir, Tri& t) {
+__device__ __forceinline__ bool edge_geometry(const TransportKernelArgs& a, const Cell& k, int dir, Geo& q) {
   const size_t c = k.c;
   const int nx = a.nx;
   const size_t cl = dir ? c - 1 : c, cr = dir ? c : c - nx;   // left / right corner of the edge (U points)
   if (!(a.dpx[cl] != c0 || a.dpy[cl] != c0 || a.dpx[cr] != c0 || a.dpy[cr] != c0)) return false;
-  const double afl = a.dxu[cl] * a.dyu[cl], afr = a.dxu[cr] * a.dyu[cr];
-  const double afc = p5 * (afl + afr);
-  // shifts of the cells a triangle can lie in (:1888-1939)
-  const int tl_i = dir ? -1 : 1, tl_j = 1, bl_i = dir ? -1 : 0, bl_j = dir ? 0 : 1;
-  const int tr_i = 1, tr_j = dir ? 1 : -1, br_i = dir ? 1 : 0, br_j = dir ? 0 : -1;
-  const int tc_i = dir ? 0 : 1, tc_j = dir ? 1 : 0, bc_i = 0, bc_j = 0;
-  double fact[NG];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    fact[g] = c0; t.di[g] = 0; t.dj[g] = 0;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) { t.xp[g][v] = c0; t.yp[g][v] = c0; }
-  }
+  q.afl = a.dxu[cl] * a.dyu[cl];
+  q.afr = a.dxu[cr] * a.dyu[cr];
+  q.afc = p5 * (q.afl + q.afr);
   const double dxl = a.dpx[cl] / a.dxu[cl], dyl = a.dpy[cl] / a.dyu[cl];
   const double dxr = a.dpx[cr] / a.dxu[cr], dyr = a.dpy[cr] / a.dyu[cr];
   const double xcl = -p5, ycl = c0, xcr = p5, ycr = c0;
@@ -269,122 +259,207 @@ __device__ bool locate_triangles(const TransportKernelArgs& a, const Cell& k, in
   if (dir) { xdl = xcl + dxl; ydl = ycl + dyl; xdr = xcr + dxr; ydr = ycr + dyr; }
   else { xdl = xcl - dyl; ydl = ycl + dxl; xdr = xcr - dyr; ydr = ycr + dxr; }   // rotate trajectory by pi/2
   const double xdm = p5 * (xdr + xdl), ydm = p5 * (ydr + ydl);
-  const double xil = xcl, yil = (xcl * (ydm - ydl) + xdm * ydl - xdl * ydm) / (xdm - xdl);
-  const double xir = xcr, yir = (xcr * (ydr - ydm) - xdm * ydr + xdr * ydm) / (xdr - xdm);
+  q.xil = xcl; q.yil = (xcl * (ydm - ydl) + xdm * ydl - xdl * ydm) / (xdm - xdl);
+  q.xir = xcr; q.yir = (xcr * (ydr - ydm) - xdm * ydr + xdr * ydm) / (xdr - xdm);
   const double md = (ydr - ydl) / (xdr - xdl);
-  const double xic = fabs(md) > puny ? xdl - ydl / md : c0;
-  const double yic = c0;
-  const double xicl = xic, yicl = yic, xicr = xic, yicr = yic;   // l_fixed_area = F
-  // groups are 1-based in the reference: index g-1 here
-  if (yil > c0 && xdl < xcl && ydl >= c0) {
-    set_tri(t, fact, 0, xcl, ycl, xil, yil, xdl, ydl, tl_i, tl_j, -afl);
-  } else if (yil < c0 && xdl < xcl && ydl < c0) {
-    set_tri(t, fact, 0, xcl, ycl, xdl, ydl, xil, yil, bl_i, bl_j, afl);
-  } else if (yil < c0 && xdl < xcl && ydl >= c0) {
-    set_tri(t, fact, 0, xcl, ycl, xdl, ydl, xic, yic, tl_i, tl_j, afl);
-    set_tri(t, fact, 2, xcl, ycl, xic, yic, xil, yil, bl_i, bl_j, afl);
-  } else if (yil > c0 && xdl < xcl && ydl < c0) {
-    set_tri(t, fact, 2, xcl, ycl, xil, yil, xic, yic, tl_i, tl_j, -afl);
-    set_tri(t, fact, 0, xcl, ycl, xic, yic, xdl, ydl, bl_i, bl_j, -afl);
-  }
-  if (yir > c0 && xdr >= xcr && ydr >= c0) {
-    set_tri(t, fact, 1, xcr, ycr, xdr, ydr, xir, yir, tr_i, tr_j, -afr);
-  } else if (yir < c0 && xdr >= xcr && ydr < c0) {
-    set_tri(t, fact, 1, xcr, ycr, xir, yir, xdr, ydr, br_i, br_j, afr);
-  } else if (yir < c0 && xdr >= xcr && ydr >= c0) {
-    set_tri(t, fact, 1, xcr, ycr, xic, yic, xdr, ydr, tr_i, tr_j, afr);
-    set_tri(t, fact, 2, xcr, ycr, xir, yir, xic, yic, br_i, br_j, afr);
-  } else if (yir > c0 && xdr >= xcr && ydr < c0) {
-    set_tri(t, fact, 2, xcr, ycr, xic, yic, xir, yir, tr_i, tr_j, -afr);
-    set_tri(t, fact, 1, xcr, ycr, xdr, ydr, xic, yic, br_i, br_j, -afr);
-  }
+  q.xic = fabs(md) > puny ? xdl - ydl / md : c0;
+  q.xdm = xdm; q.ydm = ydm;
+  q.xdl0 = xdl; q.ydl0 = ydl; q.xdr0 = xdr; q.ydr0 = ydr;
   // redefine departure points that lie in side cells (:2230-2238)
-  if (xdl < xcl) { xdl = xil; ydl = yil; }
-  if (xdr > xcr) { xdr = xir; ydr = yir; }
-  // central triangles (:2343-2983)
-  if (ydl >= c0 && ydr >= c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xcr, ycr, xdl, ydl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xdl, ydl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 5, xdl, ydl, xdr, ydr, xdm, ydm, tc_i, tc_j, -afc);
-  } else if (ydl >= c0 && ydr >= c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afc);
-    set_tri(t, fact, 5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
-  } else if (ydl < c0 && ydr < c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xcr, ycr, bc_i, bc_j, afc);
-    set_tri(t, fact, 4, xcr, ycr, xdl, ydl, xdr, ydr, bc_i, bc_j, afc);
-    set_tri(t, fact, 5, xdl, ydl, xdm, ydm, xdr, ydr, bc_i, bc_j, afc);
-  } else if (ydl < c0 && ydr < c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afc);
-    set_tri(t, fact, 4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afc);
-    set_tri(t, fact, 5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
-  } else if (ydl >= c0 && ydr < c0 && xic >= c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xicr, yicr, xdl, ydl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afr);
-    set_tri(t, fact, 5, xdl, ydl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
-  } else if (ydl >= c0 && ydr < c0 && xic >= c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afr);
-    set_tri(t, fact, 5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
-  } else if (ydl >= c0 && ydr < c0 && xic < c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afl);
-    set_tri(t, fact, 4, xcr, ycr, xicl, yicl, xdr, ydr, bc_i, bc_j, afc);
-    set_tri(t, fact, 5, xdr, ydr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
-  } else if (ydl >= c0 && ydr < c0 && xic < c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afl);
-    set_tri(t, fact, 4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afc);
-    set_tri(t, fact, 5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
-  } else if (ydl < c0 && ydr >= c0 && xic < c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afl);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xicl, yicl, tc_i, tc_j, -afc);
-    set_tri(t, fact, 5, xicl, yicl, xdr, ydr, xdm, ydm, tc_i, tc_j, -afc);
-  } else if (ydl < c0 && ydr >= c0 && xic < c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afl);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afc);
-    set_tri(t, fact, 5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
-  } else if (ydl < c0 && ydr >= c0 && xic >= c0 && ydm < c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xicr, yicr, bc_i, bc_j, afc);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afr);
-    set_tri(t, fact, 5, xicr, yicr, xdl, ydl, xdm, ydm, bc_i, bc_j, afc);
-  } else if (ydl < c0 && ydr >= c0 && xic >= c0 && ydm >= c0) {
-    set_tri(t, fact, 3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afc);
-    set_tri(t, fact, 4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afr);
-    set_tri(t, fact, 5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
-  }
-  // triangle areas :3029-3050, coordinates relative to the cell that contributes :3086-3117, quadrature points
-  // :3268-3293 (cubic)
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const double ar = p5 * ((t.xp[g][2] - t.xp[g][1]) * (t.yp[g][3] - t.yp[g][1]) -
-                            (t.yp[g][2] - t.yp[g][1]) * (t.xp[g][3] - t.xp[g][1])) * fact[g];
-    t.on[g] = !(fabs(ar) < eps16 * afc);
-    t.area[g] = t.on[g] ? ar : c0;
-    if (!t.on[g]) continue;
-#pragma unroll
-    for (int v = 1; v <= 3; ++v) {
-      if (dir) {
-        t.xp[g][v] = t.xp[g][v] - c1 * t.di[g];
-        t.yp[g][v] = t.yp[g][v] + p5 - c1 * t.dj[g];
-      } else {
-        const double w1 = t.xp[g][v];
-        t.xp[g][v] = t.yp[g][v] + p5 - c1 * t.di[g];
-        t.yp[g][v] = -w1 - c1 * t.dj[g];
-      }
-    }
-    t.xp[g][0] = p333 * (t.xp[g][1] + t.xp[g][2] + t.xp[g][3]);
-    t.yp[g][0] = p333 * (t.yp[g][1] + t.yp[g][2] + t.yp[g][3]);
-#pragma unroll
-    for (int v = 1; v <= 3; ++v) {
-      t.xp[g][v] = p4 * t.xp[g][v] + p6 * t.xp[g][0];
-      t.yp[g][v] = p4 * t.yp[g][v] + p6 * t.yp[g][0];
-    }
-  }
+  if (xdl < xcl) { xdl = q.xil; ydl = q.yil; }
+  if (xdr > xcr) { xdr = q.xir; ydr = q.yir; }
+  q.xdl = xdl; q.ydl = ydl; q.xdr = xdr; q.ydr = ydr;
   return true;
 }
 
+template <int G>
+__device__ __forceinline__ void tri_group(const Geo& q, int dir, Tri1& t) {
+  // shifts of the cells a triangle can lie in (:1888-1939)
+  const int tl_i = dir ? -1 : 1, tl_j = 1, bl_i = dir ? -1 : 0, bl_j = dir ? 0 : 1;
+  const int tr_i = 1, tr_j = dir ? 1 : -1, br_i = dir ? 1 : 0, br_j = dir ? 0 : -1;
+  const int tc_i = dir ? 0 : 1, tc_j = dir ? 1 : 0, bc_i = 0, bc_j = 0;
+  const double xcl = -p5, ycl = c0, xcr = p5, ycr = c0;
+  const double afl = q.afl, afr = q.afr, afc = q.afc;
+  const double xil = q.xil, yil = q.yil, xir = q.xir, yir = q.yir, xic = q.xic, yic = c0, xdm = q.xdm, ydm = q.ydm;
+  const double xicl = xic, yicl = yic, xicr = xic, yicr = yic;   // l_fixed_area = F
+  double x1 = c0, y1 = c0, x2 = c0, y2 = c0, x3 = c0, y3 = c0, fact = c0;
+  t.di = 0; t.dj = 0;
+#define SET(ng, X1, Y1, X2, Y2, X3, Y3, DI, DJ, F) \
+  do { if ((ng) == G) { x1 = (X1); y1 = (Y1); x2 = (X2); y2 = (Y2); x3 = (X3); y3 = (Y3); t.di = (DI); t.dj = (DJ); fact = (F); } } while (0)
+  if (G <= 2) {   // side triangles, with the departure points as they are (:1950-2228)
+    const double xdl = q.xdl0, ydl = q.ydl0, xdr = q.xdr0, ydr = q.ydr0;
+  // groups are 1-based in the reference: index g-1 here
+    if (yil > c0 && xdl < xcl && ydl >= c0) {
+      SET(0, xcl, ycl, xil, yil, xdl, ydl, tl_i, tl_j, -afl);
+    } else if (yil < c0 && xdl < xcl && ydl < c0) {
+      SET(0, xcl, ycl, xdl, ydl, xil, yil, bl_i, bl_j, afl);
+    } else if (yil < c0 && xdl < xcl && ydl >= c0) {
+      SET(0, xcl, ycl, xdl, ydl, xic, yic, tl_i, tl_j, afl);
+      SET(2, xcl, ycl, xic, yic, xil, yil, bl_i, bl_j, afl);
+    } else if (yil > c0 && xdl < xcl && ydl < c0) {
+      SET(2, xcl, ycl, xil, yil, xic, yic, tl_i, tl_j, -afl);
+      SET(0, xcl, ycl, xic, yic, xdl, ydl, bl_i, bl_j, -afl);
+    }
+    if (yir > c0 && xdr >= xcr && ydr >= c0) {
+      SET(1, xcr, ycr, xdr, ydr, xir, yir, tr_i, tr_j, -afr);
+    } else if (yir < c0 && xdr >= xcr && ydr < c0) {
+      SET(1, xcr, ycr, xir, yir, xdr, ydr, br_i, br_j, afr);
+    } else if (yir < c0 && xdr >= xcr && ydr >= c0) {
+      SET(1, xcr, ycr, xic, yic, xdr, ydr, tr_i, tr_j, afr);
+      SET(2, xcr, ycr, xir, yir, xic, yic, br_i, br_j, afr);
+    } else if (yir > c0 && xdr >= xcr && ydr < c0) {
+      SET(2, xcr, ycr, xic, yic, xir, yir, tr_i, tr_j, -afr);
+      SET(1, xcr, ycr, xdr, ydr, xic, yic, br_i, br_j, -afr);
+    }
+  }
+  if (G >= 3) {   // central triangles, with the redefined departure points (:2343-2983)
+    const double xdl = q.xdl, ydl = q.ydl, xdr = q.xdr, ydr = q.ydr;
+  // central triangles (:2343-2983)
+    if (ydl >= c0 && ydr >= c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xcr, ycr, xdl, ydl, tc_i, tc_j, -afc);
+      SET(4, xcr, ycr, xdr, ydr, xdl, ydl, tc_i, tc_j, -afc);
+      SET(5, xdl, ydl, xdr, ydr, xdm, ydm, tc_i, tc_j, -afc);
+    } else if (ydl >= c0 && ydr >= c0 && ydm < c0) {
+      SET(3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afc);
+      SET(4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afc);
+      SET(5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
+    } else if (ydl < c0 && ydr < c0 && ydm < c0) {
+      SET(3, xcl, ycl, xdl, ydl, xcr, ycr, bc_i, bc_j, afc);
+      SET(4, xcr, ycr, xdl, ydl, xdr, ydr, bc_i, bc_j, afc);
+      SET(5, xdl, ydl, xdm, ydm, xdr, ydr, bc_i, bc_j, afc);
+    } else if (ydl < c0 && ydr < c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afc);
+      SET(4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afc);
+      SET(5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
+    } else if (ydl >= c0 && ydr < c0 && xic >= c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xicr, yicr, xdl, ydl, tc_i, tc_j, -afc);
+      SET(4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afr);
+      SET(5, xdl, ydl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
+    } else if (ydl >= c0 && ydr < c0 && xic >= c0 && ydm < c0) {
+      SET(3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afc);
+      SET(4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afr);
+      SET(5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
+    } else if (ydl >= c0 && ydr < c0 && xic < c0 && ydm < c0) {
+      SET(3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afl);
+      SET(4, xcr, ycr, xicl, yicl, xdr, ydr, bc_i, bc_j, afc);
+      SET(5, xdr, ydr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
+    } else if (ydl >= c0 && ydr < c0 && xic < c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xicl, yicl, xdl, ydl, tc_i, tc_j, -afl);
+      SET(4, xcr, ycr, xicr, yicr, xdr, ydr, bc_i, bc_j, afc);
+      SET(5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
+    } else if (ydl < c0 && ydr >= c0 && xic < c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afl);
+      SET(4, xcr, ycr, xdr, ydr, xicl, yicl, tc_i, tc_j, -afc);
+      SET(5, xicl, yicl, xdr, ydr, xdm, ydm, tc_i, tc_j, -afc);
+    } else if (ydl < c0 && ydr >= c0 && xic < c0 && ydm < c0) {
+      SET(3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afl);
+      SET(4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afc);
+      SET(5, xicr, yicr, xicl, yicl, xdm, ydm, bc_i, bc_j, afc);
+    } else if (ydl < c0 && ydr >= c0 && xic >= c0 && ydm < c0) {
+      SET(3, xcl, ycl, xdl, ydl, xicr, yicr, bc_i, bc_j, afc);
+      SET(4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afr);
+      SET(5, xicr, yicr, xdl, ydl, xdm, ydm, bc_i, bc_j, afc);
+    } else if (ydl < c0 && ydr >= c0 && xic >= c0 && ydm >= c0) {
+      SET(3, xcl, ycl, xdl, ydl, xicl, yicl, bc_i, bc_j, afc);
+      SET(4, xcr, ycr, xdr, ydr, xicr, yicr, tc_i, tc_j, -afr);
+      SET(5, xicl, yicl, xicr, yicr, xdm, ydm, tc_i, tc_j, -afc);
+    }
+  }
+#undef SET
+  // triangle area :3029-3050, coordinates relative to the cell that contributes :3086-3117, quadrature points
+  // :3268-3293 (cubic)
+  const double ar = p5 * ((x2 - x1) * (y3 - y1) - (y2 - y1) * (x3 - x1)) * fact;
+  t.on = !(fabs(ar) < eps16 * afc);
+  t.area = t.on ? ar : c0;
+  if (!t.on) return;
+  t.xp[1] = x1; t.yp[1] = y1; t.xp[2] = x2; t.yp[2] = y2; t.xp[3] = x3; t.yp[3] = y3;
+#pragma unroll
+  for (int v = 1; v <= 3; ++v) {
+    if (dir) {
+      t.xp[v] = t.xp[v] - c1 * t.di;
+      t.yp[v] = t.yp[v] + p5 - c1 * t.dj;
+    } else {
+      const double w1 = t.xp[v];
+      t.xp[v] = t.yp[v] + p5 - c1 * t.di;
+      t.yp[v] = -w1 - c1 * t.dj;
+    }
+  }
+  t.xp[0] = p333 * (t.xp[1] + t.xp[2] + t.xp[3]);
+  t.yp[0] = p333 * (t.yp[1] + t.yp[2] + t.yp[3]);
+#pragma unroll
+  for (int v = 1; v <= 3; ++v) {
+    t.xp[v] = p4 * t.xp[v] + p6 * t.xp[0];
+    t.yp[v] = p4 * t.yp[v] + p6 * t.yp[0];
+  }
+}
+
 // ---- transport_integrals :3307-3632 (cubic) for one (edge, direction, category) ------------------------
+// Every loop is unrolled and every array index a compile-time constant (the dependency of a tracer on an earlier one
+// is resolved by an unrolled select): the tracer sums stay in registers.  With run-time indices, a non-inlined
+// locate_triangles and all six triangles held at once the kernel sat at 256 VGPRs + 120 B of scratch, one wavefront
+// per SIMD.  x / y sums of a tracer are kept only for tracers 0 and 1 (hice, hsno): only those have volume-weighted
+// dependents (tracer_type 2 depends on ice or snow volume, ice_transport_driver.F90:120-160), and Transport::init
+// creates no other dependency.
+struct FluxAcc {
+  double mflx, mtflx[TR_MAXTRACE];
+};
+
+template <int G>
+__device__ __forceinline__ void flux_group(const TransportKernelArgs& a, const Cell& k, const Geo& q, int dir, int n,
+                                           const double* mc, const double* mx, const double* my, FluxAcc& f) {
+  Tri1 t;
+  tri_group<G>(q, dir, t);
+  if (!t.on) return;
+  const size_t c2 = k.c + (long)t.dj * a.nx + t.di;
+  const double mc2 = mc[c2], mx2 = mx[c2], my2 = my[c2];
+  const double m0 = p5625m * (mc2 + t.xp[0] * mx2 + t.yp[0] * my2);
+  const double m1 = p52083 * (mc2 + t.xp[1] * mx2 + t.yp[1] * my2);
+  const double m2 = p52083 * (mc2 + t.xp[2] * mx2 + t.yp[2] * my2);
+  const double m3 = p52083 * (mc2 + t.xp[3] * mx2 + t.yp[3] * my2);
+  const double msum = m0 + m1 + m2 + m3;
+  f.mflx = f.mflx + t.area * msum;
+  if (n == 0) return;
+  double w0 = m0 * t.xp[0], w1 = m1 * t.xp[1], w2 = m2 * t.xp[2], w3 = m3 * t.xp[3];
+  const double mxsum = w0 + w1 + w2 + w3;
+  const double mxxsum = w0 * t.xp[0] + w1 * t.xp[1] + w2 * t.xp[2] + w3 * t.xp[3];
+  const double mxysum = w0 * t.yp[0] + w1 * t.yp[1] + w2 * t.yp[2] + w3 * t.yp[3];
+  w0 = m0 * t.yp[0]; w1 = m1 * t.yp[1]; w2 = m2 * t.yp[2]; w3 = m3 * t.yp[3];
+  const double mysum = w0 + w1 + w2 + w3;
+  const double myysum = w0 * t.yp[0] + w1 * t.yp[1] + w2 * t.yp[2] + w3 * t.yp[3];
+  double mtsum[TR_MAXTRACE], mtxsum[2] = {c0, c0}, mtysum[2] = {c0, c0};
+#pragma unroll
+  for (int nt = 0; nt < TR_MAXTRACE; ++nt) mtsum[nt] = c0;
+#pragma unroll
+  for (int nt = 0; nt < TR_MAXTRACE; ++nt) {
+    if (nt >= a.ntrace) continue;      // (not `break`: the loop has to unroll completely)
+    const size_t T = lvl(a, tl(a, n, nt)) + c2;
+    const double tc = a.tc[T], tx = a.tx[T], ty = a.ty[T];
+    const int ty_ = a.type[nt], nt1 = a.dep[nt];
+    if (ty_ == 1) {
+      mtsum[nt] = msum * tc + mxsum * tx + mysum * ty;
+      f.mtflx[nt] = f.mtflx[nt] + t.area * mtsum[nt];
+      if (nt < 2) {
+        mtxsum[nt] = mxsum * tc + mxxsum * tx + mxysum * ty;
+        mtysum[nt] = mysum * tc + mxysum * tx + myysum * ty;
+      }
+    } else if (ty_ == 2) {   // depends on tracer 0 or 1
+      const double ds = nt1 == 0 ? mtsum[0] : mtsum[1], dx = nt1 == 0 ? mtxsum[0] : mtxsum[1],
+                   dy = nt1 == 0 ? mtysum[0] : mtysum[1];
+      mtsum[nt] = ds * tc + dx * tx + dy * ty;
+      f.mtflx[nt] = f.mtflx[nt] + t.area * mtsum[nt];
+    } else {                 // depends on an earlier tracer of any type
+      double ds = c0;
+#pragma unroll
+      for (int m = 0; m < nt; ++m)
+        if (m == nt1) ds = mtsum[m];
+      mtsum[nt] = ds * tc;
+      f.mtflx[nt] = f.mtflx[nt] + t.area * mtsum[nt];
+    }
+  }
+}
+
 // grid: (cells, 2*(ncat+1), nblocks): blockIdx.y = dir * (ncat+1) + n
-__global__ __launch_bounds__(256) void k_tr_fluxes(const TransportKernelArgs a) {
+__global__ __launch_bounds__(256, 3) void k_tr_fluxes(const TransportKernelArgs a) {
   Cell k;
   if (!cell_of(a, k)) return;
   const int dir = blockIdx.y / (NCAT + 1), n = blockIdx.y % (NCAT + 1);
@@ -394,56 +469,28 @@ __global__ __launch_bounds__(256) void k_tr_fluxes(const TransportKernelArgs a) 
                         : (k.i >= e[0] - 1 && k.i <= e[1] && k.j >= e[2] && k.j <= e[3]);
   const size_t F = (size_t)dir * (NCAT + 1) * a.nb * a.nx * a.ny;                    // mflx of this direction
   const size_t FT = (size_t)dir * NCAT * a.ntrace * a.nb * a.nx * a.ny;             // mtflx of this direction
-  double mflx = c0, mtflx[TR_MAXTRACE];
+  FluxAcc f;
+  f.mflx = c0;
 #pragma unroll
-  for (int nt = 0; nt < TR_MAXTRACE; ++nt) mtflx[nt] = c0;
-  Tri t;
-  if (edge && locate_triangles(a, k, dir, t)) {
+  for (int nt = 0; nt < TR_MAXTRACE; ++nt) f.mtflx[nt] = c0;
+  Geo q;
+  if (edge && edge_geometry(a, k, dir, q)) {
     const double* mc = a.mc + lvl(a, n);
     const double* mx = a.mx + lvl(a, n);
     const double* my = a.my + lvl(a, n);
-    double mtsum[TR_MAXTRACE], mtxsum[TR_MAXTRACE], mtysum[TR_MAXTRACE];
-    for (int g = 0; g < NG; ++g) {
-      if (!t.on[g]) continue;
-      const size_t c2 = k.c + (long)t.dj[g] * a.nx + t.di[g];
-      const double mc2 = mc[c2], mx2 = mx[c2], my2 = my[c2];
-      const double m0 = p5625m * (mc2 + t.xp[g][0] * mx2 + t.yp[g][0] * my2);
-      const double m1 = p52083 * (mc2 + t.xp[g][1] * mx2 + t.yp[g][1] * my2);
-      const double m2 = p52083 * (mc2 + t.xp[g][2] * mx2 + t.yp[g][2] * my2);
-      const double m3 = p52083 * (mc2 + t.xp[g][3] * mx2 + t.yp[g][3] * my2);
-      const double msum = m0 + m1 + m2 + m3;
-      mflx = mflx + t.area[g] * msum;
-      if (n == 0) continue;
-      double w0 = m0 * t.xp[g][0], w1 = m1 * t.xp[g][1], w2 = m2 * t.xp[g][2], w3 = m3 * t.xp[g][3];
-      const double mxsum = w0 + w1 + w2 + w3;
-      const double mxxsum = w0 * t.xp[g][0] + w1 * t.xp[g][1] + w2 * t.xp[g][2] + w3 * t.xp[g][3];
-      const double mxysum = w0 * t.yp[g][0] + w1 * t.yp[g][1] + w2 * t.yp[g][2] + w3 * t.yp[g][3];
-      w0 = m0 * t.yp[g][0]; w1 = m1 * t.yp[g][1]; w2 = m2 * t.yp[g][2]; w3 = m3 * t.yp[g][3];
-      const double mysum = w0 + w1 + w2 + w3;
-      const double myysum = w0 * t.yp[g][0] + w1 * t.yp[g][1] + w2 * t.yp[g][2] + w3 * t.yp[g][3];
-      for (int nt = 0; nt < a.ntrace; ++nt) {
-        const size_t T = lvl(a, tl(a, n, nt)) + c2;
-        const double tc = a.tc[T], tx = a.tx[T], ty = a.ty[T];
-        if (a.type[nt] == 1) {
-          mtsum[nt] = msum * tc + mxsum * tx + mysum * ty;
-          mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-          mtxsum[nt] = mxsum * tc + mxxsum * tx + mxysum * ty;
-          mtysum[nt] = mysum * tc + mxysum * tx + myysum * ty;
-        } else if (a.type[nt] == 2) {
-          const int nt1 = a.dep[nt];
-          mtsum[nt] = mtsum[nt1] * tc + mtxsum[nt1] * tx + mtysum[nt1] * ty;
-          mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-        } else {
-          const int nt1 = a.dep[nt];
-          mtsum[nt] = mtsum[nt1] * tc;
-          mtflx[nt] = mtflx[nt] + t.area[g] * mtsum[nt];
-        }
-      }
-    }
+    flux_group<0>(a, k, q, dir, n, mc, mx, my, f);   // the six groups in the reference's order (:3395)
+    flux_group<1>(a, k, q, dir, n, mc, mx, my, f);
+    flux_group<2>(a, k, q, dir, n, mc, mx, my, f);
+    flux_group<3>(a, k, q, dir, n, mc, mx, my, f);
+    flux_group<4>(a, k, q, dir, n, mc, mx, my, f);
+    flux_group<5>(a, k, q, dir, n, mc, mx, my, f);
   }
-  a.mflx[F + lvl(a, n) + k.c] = mflx;
-  if (n >= 1)
-    for (int nt = 0; nt < a.ntrace; ++nt) a.mtflx[FT + lvl(a, tl(a, n, nt)) + k.c] = mtflx[nt];
+  a.mflx[F + lvl(a, n) + k.c] = f.mflx;
+  if (n >= 1) {
+#pragma unroll
+    for (int nt = 0; nt < TR_MAXTRACE; ++nt)
+      if (nt < a.ntrace) a.mtflx[FT + lvl(a, tl(a, n, nt)) + k.c] = f.mtflx[nt];
+  }
 }
 
 // ---- update_fields :3642-3868 for one (physical cell, category) ------------------------------------------
