@@ -45,3 +45,17 @@ def test_workload_names():
     assert bench.workload("64x40x8")[:3] == (64, 40, 8)
     with pytest.raises(SystemExit):
         bench.workload("nonsense")
+
+
+def test_archived_counter_passes_are_found_for_the_kernels_the_bench_reports():
+    """roofline.traffic / not_hbm_bound come from archived rocprofv3 passes looked up by kernel name: a renamed kernel
+    or a reshaped workgroup would silently turn them into null.  The names the library uses
+    today must be in profiles/."""
+    for wl, k in (("gx1", "k_evp_resident<4, false>"), ("gx1", "k_evp_resident<11, false>"),
+                  ("gx1", "k_subcycle2<13, false, false, true>"), ("tenth", "k_subcycle2<16, false, false, true>"),
+                  ("gx1", "k_thermo_dense<true>"), ("tenth", "k_thermo_dense<true>")):
+        traffic, src = bench.pmc_traffic(wl, k)
+        assert traffic and traffic > 1e6 and src.startswith("archived PMC pass profiles/"), (wl, k)
+    for k in ("k_evp_resident<4, false>", "k_evp_resident<11, false>"):
+        sq = bench.pmc_counters("gx1", k)
+        assert sq and 500 < sq["valu_per_wave_subcycle"] < 700, k
