@@ -803,11 +803,13 @@ struct ResArgs {
   long long spin_ticks;  // wall_clock64() ticks (100 MHz) a poll may take
 };
 
-__device__ __forceinline__ double ld_agent(const double* p) {
-  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// agent-scope (sc1) access at a uniform base + 32-bit byte offset: SGPR base + VGPR offset addressing, no 64-bit
+// address arithmetic per access (the exchange copies of a one-block domain are far below 4 GB)
+__device__ __forceinline__ double ld_agent(const double* base, unsigned off) {
+  return __hip_atomic_load((double*)((char*)const_cast<double*>(base) + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void st_agent(double* p, double v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void st_agent(double* base, unsigned off, double v) {
+  __hip_atomic_store((double*)((char*)base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int W, bool DAMP>
@@ -832,6 +834,7 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   const bool in_i = i <= ihi + 1;
   const bool ok = in_i && j <= jhi + 1;
   const size_t q = ok ? (size_t)(j - 1) * nx + (i - 1) : 0;
+  const unsigned qb = (unsigned)q * 8u, nxb = (unsigned)nx * 8u;   // byte offsets into an exchange copy
   const bool own_i = (min(i, ihi) - i0) < (TX - 1);
   const bool uown = lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
   const bool uact = uown && a.iceumask[q];
@@ -950,15 +953,16 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     s_uv[w][1][lx] = vn;
     // (D) publish the edge velocities of subcycle k, then the progress word
     double* xu = r.xu[k & 1];
+    double* xv = xu + a.n;
     if (edge) {
-      st_agent(xu + q, un);
-      st_agent(xu + a.n + q, vn);
+      st_agent(xu, qb, un);
+      st_agent(xv, qb, vn);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const int fd = s_fd[w][c][lx];
         if (fd >= 0) {
-          st_agent(xu + fd, un);
-          st_agent(xu + a.n + fd, vn);
+          st_agent(xu, (unsigned)fd * 8u, un);
+          st_agent(xv, (unsigned)fd * 8u, vn);
         }
       }
     }
@@ -997,18 +1001,18 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     if (s_abort) return;
     // every exchanged velocity is an agent-scope load
     if (foreign) {
-      un = ld_agent(xu + q);
-      vn = ld_agent(xu + a.n + q);
+      un = ld_agent(xu, qb);
+      vn = ld_agent(xv, qb);
     }
     if (south_h) {
-      us = ld_agent(xu + q - nx);
-      vs = ld_agent(xu + a.n + q - nx);
+      us = ld_agent(xu, qb - nxb);
+      vs = ld_agent(xv, qb - nxb);
     }
     if (west_h) {
-      uwh = ld_agent(xu + q - 1);
-      vwh = ld_agent(xu + a.n + q - 1);
-      uswh = ld_agent(xu + q - nx - 1);
-      vswh = ld_agent(xu + a.n + q - nx - 1);
+      uwh = ld_agent(xu, qb - 8u);
+      vwh = ld_agent(xv, qb - 8u);
+      uswh = ld_agent(xu, qb - nxb - 8u);
+      vswh = ld_agent(xv, qb - nxb - 8u);
     }
   }
 
