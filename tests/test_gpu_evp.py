@@ -546,19 +546,21 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
 
 @pytest.mark.parametrize("nxg,nyg,ew,ns", [(96, 70, 1, 0), (20, 33, 1, 0), (62, 18, 1, 0), (63, 18, 1, 0), (64, 18, 1, 0),
                                             (125, 9, 1, 0), (126, 41, 1, 0), (127, 5, 1, 0), (200, 50, 1, 0),
-                                            (96, 70, 0, 0), (130, 27, 2, 2), (7, 6, 1, 0), (96, 40, 1, 1), (320, 384, 1, 0)])
+                                            (96, 70, 0, 0), (130, 27, 2, 2), (7, 6, 1, 0), (96, 40, 1, 1), (320, 384, 1, 0),
+                                            (250, 200, 1, 0)])
 def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
     """k_evp_resident (all subcycles in ONE launch: stresses, metrics and forcing stay in registers / LDS, tile-edge
     velocities travel through agent-scope stores, progress words and agent-scope loads) against one launch per
     subcycle and the checker: bit for bit.  Widths around the 63-column tile stride, blocks narrower than a tile, every
     boundary type incl. cyclic N-S (ghost rows mirrored by far tiles), every workgroup height, damping, 1- and
-    2-subcycle loops (2 = one hand-off), odd counts, and a loop cut into ranges (the stepwise API); gx1 size."""
+    2-subcycle loops (2 = one hand-off), odd counts, and a loop cut into ranges (the stepwise API); gx1 size (768
+    four-wavefront tiles: three on every CU) and 250 x 200 (268 tiles: one or two per CU)."""
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=ns)
     gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
     grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
     s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
     keys = EVP_OUT_FIELDS + ("iceumask",)
-    big = nxg * nyg > 50000
+    big = nxg * nyg >= 50000                 # more 4-wavefront tiles than CUs: the dense shape
     for ndte, damping in (((NDTE, False),) if big else ((NDTE, False), (7, True), (2, False), (3, False))):
         ref, _ = _evp_with(ctx, grid, s, ndte, damping, fuse=0, resident=0)
         if (ndte, damping) == (NDTE, False):
@@ -569,7 +571,7 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
         # (W, dense): at gx1 size the default is "dense" -- three 4-wavefront workgroups on every CU
-        for W, dense in (((0, 1), (4, 1), (0, 0), (11, 0), (12, 0)) if big else
+        for W, dense in (((0, 1), (4, 1), (0, 0), (8 if nxg == 250 else 11, 0), (12, 0)) if big else
                          ((0, 1), (4, 1), (6, 1), (8, 1), (11, 1), (12, 1))):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
@@ -578,7 +580,7 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
             assert ctx.evp_get_info("resident") == 1, (W, dense, "grid should fit")
             assert ctx.evp_get_info("resident_dense") == (1 if big and dense else 0)
             if big and W == 0:
-                assert ctx.evp_get_info("resident_waves") == (4 if dense else 11)
+                assert ctx.evp_get_info("resident_waves") == (4 if dense else (6 if nxg == 250 else 11))
             ctx.evp(DT, sg)
             assert ctx.evp_get_info("resident") == 1 and ctx.evp_get_info("resident_dense") == (1 if big and dense else 0), \
                 "the resident loop timed out and fell back"
