@@ -535,6 +535,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
             "valu_inst_per_wave_per_subcycle": sq.get("valu_per_wave_subcycle") if sq else None,
             "issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz": (3 * sq["valu_per_wave_subcycle"] * 4 / 2400.0) if sq else None,
             "counters_source": sq.get("source") if sq else None}
+        if sq:   # the fraction that means something for this kernel: fp64 issue slots of the busiest SIMD that are used
+            roofline["bound_effective"] = "valu_f64_issue"
+            roofline["frac_valu_issue"] = roofline["not_hbm_bound"]["issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] / us_sub
     config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
               "subcycles_per_step": ndte,
               "decomposition": f"1x{world} j-slabs, one block per GPU" + (
