@@ -80,6 +80,10 @@ struct cice_ctx {
   // staging of the host-pointer entries (thermo_vertical is called ncat x nblocks times per step with
   // the same block size: allocated once, grown only when a larger block comes along)
   DevBuf<double> tv_stage, fz_stage, halo_stage;
+  // page-locked gather buffer and cell offsets of the compact thermo_vertical path
+  void* tv_host = nullptr;
+  size_t tv_host_bytes = 0;
+  std::vector<size_t> tv_cells;
   // frame of the rank's blocks (cells a halo update can read or write), for host-array halo updates
   std::vector<int32_t> frame;
   DevBuf<int32_t> frame_dev;
@@ -372,6 +376,7 @@ int cice_host_unregister_all(cice_ctx* ctx) {
 int cice_destroy(cice_ctx* ctx) {
   if (!ctx) return CICE_EINVAL;
   if (ctx->frame_host) (void)hipHostFree(ctx->frame_host);
+  if (ctx->tv_host) (void)hipHostFree(ctx->tv_host);
   ctx->unpin_all();
   ctx->evp.reset();
   ctx->transport.reset();
@@ -827,8 +832,102 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
          A_FSWINT, A_FSWTHRU, A_SSW, A_ISW = A_SSW + NSLYR, A_OUT = A_ISW + NILYR, A_MLT = A_OUT + 15,
          A_FRZ, A_END };
   DevBuf<double>& d = c_->tv_stage;
-  if (d.n < (size_t)A_END * np) d.alloc((size_t)A_END * np);
   DevBuf<int32_t>& li = c_->tv_list;
+  if ((size_t)icells * 2 <= np) {
+    // Few of the block's cells carry ice of this category (the rule on a real grid: the reference compresses to a
+    // list for that reason): only the listed cells travel.  The host gathers them plane by plane into a page-locked
+    // buffer, ONE copy takes all planes to the device, the list kernel runs on that compact "1 x icells block", ONE
+    // copy brings everything back, the host zeroes the output planes (:299-329) and scatters the listed cells.
+    // 54 copies of whole planes become 2 of icells elements per plane.
+    const size_t m = (size_t)icells;
+    double* houts[15] = {fsurfn, fcondtopn, fsensn, flatn, fswabsn, flwoutn, evapn, freshn, fsaltn,
+                         fhocnn, meltt, melts, meltb, congel, snoice};
+    auto zero_out = [&]() {
+      for (int k = 0; k < 15; ++k)
+        if (c_->tp.calc_Tsfc || !(k == 0 || k == 1 || k == 3)) std::memset(houts[k], 0, np * 8);
+    };
+    if (m == 0) {
+      zero_out();
+      *l_stop = 0; *istop = 0; *jstop = 0;
+      return CICE_OK;
+    }
+    const size_t bytes = ((size_t)A_END * m) * 8 + 2 * m * 4;
+    if (c_->tv_host_bytes < bytes) {
+      if (c_->tv_host) (void)hipHostFree(c_->tv_host);
+      c_->tv_host = nullptr;
+      c_->tv_host_bytes = 0;
+      CICE_HIP(hipHostMalloc(&c_->tv_host, bytes + bytes / 2, hipHostMallocDefault));
+      c_->tv_host_bytes = bytes + bytes / 2;
+    }
+    if (d.n < (size_t)A_END * m) d.alloc((size_t)A_END * std::max(m, np / 8));
+    if (li.n < 2 * m) li.alloc(2 * std::max(m, np / 8));
+    double* hp = static_cast<double*>(c_->tv_host);
+    int32_t* hl = reinterpret_cast<int32_t*>(hp + (size_t)A_END * m);
+    std::vector<size_t>& cq = c_->tv_cells;
+    cq.resize(m);
+    for (size_t e = 0; e < m; ++e) {
+      cq[e] = (size_t)(indxj[e] - 1) * nx + (indxi[e] - 1);
+      hl[e] = (int32_t)e + 1;      // the compact block is one row of m cells
+      hl[m + e] = 1;
+    }
+    auto gather = [&](int plane, const double* h, int planes = 1) {
+      for (int k = 0; k < planes; ++k) {
+        double* o = hp + (size_t)(plane + k) * m;
+        const double* src = h + (size_t)k * np;
+        for (size_t e = 0; e < m; ++e) o[e] = src[cq[e]];
+      }
+    };
+    const int it_T = c_->tp.nt_Tsfc - 1;
+    gather(A_AICEN, aicen); gather(A_TRCRN + it_T, trcrn + (size_t)it_T * np); gather(A_VICEN, vicen);
+    gather(A_VSNON, vsnon); gather(A_EICEN, eicen, NILYR); gather(A_ESNON, esnon, NSLYR);
+    gather(A_FLW, flw); gather(A_POTT, potT); gather(A_QA, Qa); gather(A_RHOA, rhoa); gather(A_FSNOW, fsnow);
+    gather(A_FBOT, fbot); gather(A_TBOT, Tbot); gather(A_LH, lhcoef); gather(A_SH, shcoef);
+    gather(A_FSWSFC, fswsfc); gather(A_FSWINT, fswint); gather(A_FSWTHRU, fswthrun);
+    gather(A_SSW, Sswabs, NSLYR); gather(A_ISW, Iswabs, NILYR);
+    gather(A_MLT, mlt_onset); gather(A_FRZ, frz_onset);
+    if (!c_->tp.calc_Tsfc) { gather(A_OUT + 0, fsurfn); gather(A_OUT + 1, fcondtopn); gather(A_OUT + 3, flatn); }
+    CICE_HIP(hipMemcpyAsync(d.p, hp, (size_t)A_END * m * 8, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p, hl, 2 * m * 4, hipMemcpyHostToDevice, s));
+    c_->tkey.alloc(2);
+    CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
+    CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+    ThermoArgs a{};
+    a.p = c_->tp; a.nx = (int)m; a.ny = 1; a.ncat = 1; a.nblocks = 1; a.dt = dt; a.yday = yday;
+    a.icells = icells; a.indxi = li.p; a.indxj = li.p + m; a.blk = nullptr;
+    auto P = [&](int plane) { return d.p + (size_t)plane * m; };
+    a.aicen = P(A_AICEN); a.trcrn = P(A_TRCRN); a.vicen = P(A_VICEN); a.vsnon = P(A_VSNON);
+    a.eicen = P(A_EICEN); a.esnon = P(A_ESNON); a.flw = P(A_FLW); a.potT = P(A_POTT); a.Qa = P(A_QA);
+    a.rhoa = P(A_RHOA); a.fsnow = P(A_FSNOW); a.fbot = P(A_FBOT); a.Tbot = P(A_TBOT);
+    a.lhcoef = P(A_LH); a.shcoef = P(A_SH); a.fswsfc = P(A_FSWSFC); a.fswint = P(A_FSWINT);
+    a.fswthrun = P(A_FSWTHRU); a.Sswabs = P(A_SSW); a.Iswabs = P(A_ISW);
+    double** outs[15] = {&a.fsurfn, &a.fcondtopn, &a.fsensn, &a.flatn, &a.fswabsn, &a.flwoutn, &a.evapn,
+                         &a.freshn, &a.fsaltn, &a.fhocnn, &a.meltt, &a.melts, &a.meltb, &a.congel,
+                         &a.snoice};
+    for (int k = 0; k < 15; ++k) *outs[k] = P(A_OUT + k);
+    a.mlt_onset = P(A_MLT); a.frz_onset = P(A_FRZ);
+    a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+    thermo_launch_list(a, s);
+    CICE_HIP(hipMemcpyAsync(hp, d.p, (size_t)A_END * m * 8, hipMemcpyDeviceToHost, s));
+    unsigned long long key = 0;
+    CICE_HIP(hipMemcpyAsync(&key, c_->tkey.p, 8, hipMemcpyDeviceToHost, s));
+    CICE_HIP(hipStreamSynchronize(s));
+    zero_out();
+    auto scatter = [&](int plane, double* h, int planes = 1) {
+      for (int k = 0; k < planes; ++k) {
+        const double* in = hp + (size_t)(plane + k) * m;
+        double* dst = h + (size_t)k * np;
+        for (size_t e = 0; e < m; ++e) dst[cq[e]] = in[e];
+      }
+    };
+    scatter(A_AICEN, aicen); scatter(A_TRCRN + it_T, trcrn + (size_t)it_T * np); scatter(A_VICEN, vicen);
+    scatter(A_VSNON, vsnon); scatter(A_EICEN, eicen, NILYR); scatter(A_ESNON, esnon, NSLYR);
+    scatter(A_FSWSFC, fswsfc); scatter(A_FSWINT, fswint); scatter(A_SSW, Sswabs, NSLYR); scatter(A_ISW, Iswabs, NILYR);
+    for (int k = 0; k < 15; ++k) scatter(A_OUT + k, houts[k]);
+    scatter(A_MLT, mlt_onset); scatter(A_FRZ, frz_onset);
+    decode_err(key, nx, 1, indxi, indxj, l_stop, istop, jstop, nullptr, nullptr);
+    return CICE_OK;
+  }
+  if (d.n < (size_t)A_END * np) d.alloc((size_t)A_END * np);
   if (li.n < 2 * np) li.alloc(2 * np);
   auto up = [&](int plane, const double* h, int planes = 1) {
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");

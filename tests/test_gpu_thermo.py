@@ -123,6 +123,42 @@ def test_known_Tsfc_batched(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
 
 
+@pytest.mark.parametrize("calc_Tsfc", [True, False])
+def test_sparse_list_travels_compact(ctx, orc, calc_Tsfc):
+    """Fewer than half of the block's cells listed (the rule on a real grid): cice_thermo_vertical gathers the listed
+    cells on the host, moves them in one copy each way and runs the list kernel on the compact block.  Same bits as
+    the checker, cells outside the list untouched, outputs zero there, the first failing column reported with its
+    (i, j) of the full block."""
+    ctx.thermo_init(calc_Tsfc=calc_Tsfc); orc.init_thermo(calc_Tsfc=calc_Tsfc)
+    for n, frac in ((0, 0.3), (3, 0.05)):
+        a, icells, ii, jj = synth.thermo_columns(37, 70, n, regime="mixed", seed=19 + n, ice_frac=frac)
+        assert 0 < icells * 2 <= 37 * 70
+        if not calc_Tsfc:
+            orc.init_thermo(); t = {k: v.copy() for k, v in a.items()}
+            assert orc.thermo_vertical(DT, icells, ii, jj, t, yday=120.0)[0] == 0
+            a = synth.known_tsfc_inputs(a, t, seed=4)
+            orc.init_thermo(calc_Tsfc=False)
+        ag = {k: v.copy() for k, v in a.items()}; ac = {k: v.copy() for k, v in a.items()}
+        lg = ctx.thermo_vertical(DT, icells, ii, jj, ag, yday=120.0)
+        lc = orc.thermo_vertical(DT, icells, ii, jj, ac, yday=120.0)
+        assert lg == lc == (0, 0, 0)
+        for k in CHECK:
+            assert np.array_equal(ag[k], ac[k]) or frel(k, ag[k], ac[k]) <= TOL, (n, k)
+        outside = np.ones_like(a["aicen"], bool)
+        outside[jj[:icells] - 1, ii[:icells] - 1] = False
+        for k in ("aicen", "vicen", "vsnon", "fswsfc", "mlt_onset"):
+            assert np.array_equal(ag[k][outside], a[k][outside]), k
+        assert np.all(ag["fsensn"][outside] == 0.0) and np.all(ag["meltb"][outside] == 0.0)
+    # error order in the compact form
+    a, icells, ii, jj = synth.thermo_columns(20, 30, 2, regime="winter", seed=5, ice_frac=0.3)
+    for e in (icells - 2, icells // 2):
+        a["eicen"][2, jj[e] - 1, ii[e] - 1] *= 1e-3          # layer-3 enthalpy far too warm
+    ag = {k: v.copy() for k, v in a.items()}; ac = {k: v.copy() for k, v in a.items()}
+    ctx.thermo_init(); orc.init_thermo()
+    lg = ctx.thermo_vertical(DT, icells, ii, jj, ag); lc = orc.thermo_vertical(DT, icells, ii, jj, ac)
+    assert lg == lc and lg[0] == 1 and (lg[1], lg[2]) == (ii[icells // 2], jj[icells // 2])
+
+
 def test_empty_list_and_all_melt(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
     a, icells, ii, jj = synth.thermo_columns(12, 20, 0, regime="summer", seed=3)
