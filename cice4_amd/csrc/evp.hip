@@ -1355,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_count_active(const PrepArgs a) {
   int b, i, j;
   unsigned long long nt = 0, nu = 0;
   if (cell_of(a, t, b, i, j)) {
-    const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
+    const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jhi = a.blk[6 * b + 3];
     // rows this block owns (a wide-halo domain recomputes its overlap rows; they are not counted)
     const int ojlo = a.blk[6 * b + 4], ojhi = a.blk[6 * b + 5];
     const int tjhi = ojhi + (ojhi == jhi ? 1 : 0);
