@@ -86,7 +86,8 @@ struct cice_ctx {
   std::vector<size_t> tv_cells;
   // frame of the rank's blocks (cells a halo update can read or write), for host-array halo updates
   std::vector<int32_t> frame;
-  DevBuf<int32_t> frame_dev;
+  std::vector<size_t> frame_at;
+  std::unique_ptr<Halo> frame_halo;   // the domain's lists re-addressed to positions in the gathered frame
   DevBuf<double> frame_pack;
   void* frame_host = nullptr;
   size_t frame_host_bytes = 0;
@@ -131,6 +132,7 @@ struct cice_ctx {
       CICE_REQUIRE(have_domain, "cice_domain_create has not been called");
       halo.reset(new Halo());
       frame_gen = -1;
+      frame_halo.reset();
       halo->init(dom, stream);
       if (comm) halo->set_comm((ncclComm*)comm, comm_rank, comm_nranks);
     }
@@ -209,27 +211,10 @@ static void halo_host(cice_ctx* c, T* field, int nlev, int loc = LOC_CENTER, int
 // Only the cells a halo update can read or write travel: the FRAME of the rank's blocks (physical edge cells and ghost
 // cells: every address that occurs in a copy, fill, message or fold list of the domain; ~4 (nx + ny) of the nx * ny
 // cells of a block).  The host gathers the frame into a page-locked buffer (a few thousand elements per level), one
-// copy takes it to the device, a kernel spreads it into the level-major staging field, the update runs as for a
-// resident field, and the way back mirrors this.  At gx1 a 2-D update moves 22 KB each way instead of 1 MB, a 25-level
+// copy takes it to the device, the update runs ON THE GATHERED BUFFER (a second Halo whose lists address positions
+// in the frame instead of cells of the field), one copy brings it back and the host scatters it.  At gx1 a 2-D update moves 22 KB each way instead of 1 MB, a 25-level
 // one 0.6 MB instead of 25 -- the reference's own timer of ice_HaloUpdate (timer_bound) in the whole model fell
 // accordingly.
-template <class T>
-__global__ __launch_bounds__(256) void k_frame_spread(T* __restrict__ d, const T* __restrict__ pack,
-                                                      const int32_t* __restrict__ cell, int ncell, size_t n, int nz) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)ncell * nz) return;
-  const int z = (int)(t / ncell), k = (int)(t - (size_t)z * ncell);
-  d[(size_t)z * n + cell[k]] = pack[t];
-}
-template <class T>
-__global__ __launch_bounds__(256) void k_frame_collect(const T* __restrict__ d, T* __restrict__ pack,
-                                                       const int32_t* __restrict__ cell, int ncell, size_t n, int nz) {
-  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= (size_t)ncell * nz) return;
-  const int z = (int)(t / ncell), k = (int)(t - (size_t)z * ncell);
-  pack[t] = d[(size_t)z * n + cell[k]];
-}
-
 static void frame_build(cice_ctx* c) {
   const Domain& dm = c->dom;
   const size_t n = (size_t)dm.nblocks() * dm.nx_block * dm.ny_block;
@@ -244,12 +229,36 @@ static void frame_build(cice_ctx* c) {
   for (const HaloMsg& m : dm.fold_send) add(m.addr);
   for (int l = 0; l < 4; ++l) add(dm.fold_out[l].dst);
   c->frame.clear();
+  std::vector<int32_t> pos(n, -1);
   for (size_t a = 0; a < n; ++a)
-    if (mark[a]) c->frame.push_back((int32_t)a);
-  c->frame_dev.alloc(std::max<size_t>(c->frame.size(), 1));
-  if (!c->frame.empty()) c->frame_dev.upload(c->frame.data(), c->stream);
+    if (mark[a]) {
+      pos[a] = (int32_t)c->frame.size();
+      c->frame.push_back((int32_t)a);
+    }
+  // the same lists with every field address replaced by its position in the gathered frame: the update then runs on
+  // the gathered buffer itself (level stride = frame size), copies, fills, messages and folds alike
+  Domain fd = dm;
+  auto remap = [&](std::vector<int32_t>& v) {
+    for (int32_t& a : v)
+      if (a >= 0 && (size_t)a < n) a = pos[a];
+  };
+  remap(fd.hsrc); remap(fd.hdst); remap(fd.hfill); remap(fd.rsrc); remap(fd.rdst); remap(fd.fold_lsrc);
+  for (HaloMsg& m : fd.send) remap(m.addr);
+  for (HaloMsg& m : fd.recv) remap(m.addr);
+  for (HaloMsg& m : fd.fold_send) remap(m.addr);
+  for (int l = 0; l < 4; ++l) remap(fd.fold_out[l].dst);
+  c->frame_halo.reset(new Halo());
+  c->frame_halo->init(fd, c->stream);
+  if (c->comm) c->frame_halo->set_comm((ncclComm*)c->comm, c->comm_rank, c->comm_nranks);
   CICE_HIP(hipStreamSynchronize(c->stream));
   c->frame_gen = c->halo->generation();
+}
+
+template <class T>
+static void halo_apply_on(Halo& h, T* d, int nlev, size_t n, int loc, int kind, double fill) {
+  if (std::is_same<T, double>::value) h.update_r8(reinterpret_cast<double*>(d), nlev, n, true, loc, kind, fill);
+  else if (std::is_same<T, float>::value) h.update_r4(reinterpret_cast<float*>(d), nlev, n, loc, kind, (float)fill);
+  else h.update_i4(reinterpret_cast<int32_t*>(d), nlev, n, loc, kind, (int32_t)fill);
 }
 
 template <class T>
@@ -258,9 +267,6 @@ static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, 
   CICE_REQUIRE(field && nz >= 1, "bad argument");
   const int nb = c->dom.nblocks();
   const size_t np = (size_t)c->dom.nx_block * c->dom.ny_block, n = np * nb;
-  const size_t words = (n * nz * sizeof(T) + 7) / 8;
-  if (c->halo_stage.n < words) c->halo_stage.alloc(words);
-  T* d = reinterpret_cast<T*>(c->halo_stage.p);
   if (c->frame_gen != c->halo->generation()) frame_build(c);
   const size_t nc = c->frame.size();
   if (nc > 0 && nc * 4 <= n) {   // the frame is a small part of the field: move only the frame
@@ -276,30 +282,32 @@ static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, 
     T* hp = static_cast<T*>(c->frame_host);
     T* dp = reinterpret_cast<T*>(c->frame_pack.p);
     const int32_t* cell = c->frame.data();
+    std::vector<size_t>& at = c->frame_at;     // element (level 0) of every frame cell in the caller's layout
+    at.resize(nc);
+    for (size_t k = 0; k < nc; ++k) {
+      const size_t b = (size_t)cell[k] / np, q = (size_t)cell[k] - b * np;
+      at[k] = b * nz * np + q;
+    }
     for (int z = 0; z < nz; ++z) {
       T* out = hp + (size_t)z * nc;
-      for (size_t k = 0; k < nc; ++k) {
-        const size_t b = (size_t)cell[k] / np, q = (size_t)cell[k] - b * np;
-        out[k] = field[(b * nz + z) * np + q];
-      }
+      const T* src = field + (size_t)z * np;
+      for (size_t k = 0; k < nc; ++k) out[k] = src[at[k]];
     }
     CICE_HIP(hipMemcpyAsync(dp, hp, bytes, hipMemcpyHostToDevice, c->stream));
-    const dim3 g((unsigned)((cnt + 255) / 256)), blk(256);
-    hipLaunchKernelGGL((k_frame_spread<T>), g, blk, 0, c->stream, d, (const T*)dp, c->frame_dev.p, (int)nc, n, nz);
-    halo_apply<T>(c, d, nz, n, loc, kind, fill);
-    hipLaunchKernelGGL((k_frame_collect<T>), g, blk, 0, c->stream, (const T*)d, dp, c->frame_dev.p, (int)nc, n, nz);
+    halo_apply_on<T>(*c->frame_halo, dp, nz, nc, loc, kind, fill);
     CICE_HIP(hipGetLastError());
     CICE_HIP(hipMemcpyAsync(hp, dp, bytes, hipMemcpyDeviceToHost, c->stream));
     CICE_HIP(hipStreamSynchronize(c->stream));
     for (int z = 0; z < nz; ++z) {
       const T* in = hp + (size_t)z * nc;
-      for (size_t k = 0; k < nc; ++k) {
-        const size_t b = (size_t)cell[k] / np, q = (size_t)cell[k] - b * np;
-        field[(b * nz + z) * np + q] = in[k];
-      }
+      T* dst = field + (size_t)z * np;
+      for (size_t k = 0; k < nc; ++k) dst[at[k]] = in[k];
     }
     return;
   }
+  const size_t words = (n * nz * sizeof(T) + 7) / 8;
+  if (c->halo_stage.n < words) c->halo_stage.alloc(words);
+  T* d = reinterpret_cast<T*>(c->halo_stage.p);
   if (nz == 1 || nb == 1) {
     CICE_HIP(hipMemcpyAsync(d, field, n * nz * sizeof(T), hipMemcpyHostToDevice, c->stream));
   } else {
@@ -380,6 +388,7 @@ int cice_destroy(cice_ctx* ctx) {
   ctx->unpin_all();
   ctx->evp.reset();
   ctx->transport.reset();
+  ctx->frame_halo.reset();
   ctx->halo.reset();
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -439,6 +448,7 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   c_->transport.reset();
   c_->halo.reset();
   c_->frame_gen = -1;   // the frame belongs to the domain
+  c_->frame_halo.reset();
   CICE_CATCH
 }
 
@@ -455,6 +465,7 @@ int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, in
   c_->transport.reset();
   c_->halo.reset();
   c_->frame_gen = -1;   // the frame belongs to the domain
+  c_->frame_halo.reset();
   CICE_CATCH
 }
 
@@ -491,6 +502,7 @@ int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int
   c_->transport.reset();
   c_->halo.reset();
   c_->frame_gen = -1;   // the frame belongs to the domain
+  c_->frame_halo.reset();
   CICE_CATCH
 }
 
@@ -587,6 +599,7 @@ int cice_comm_init(cice_ctx* ctx, const char uid[128], int rank, int nranks) {
                  "cice_comm_init: this context already has a communicator with another rank / size");
   }
   c_->halo->set_comm((ncclComm*)c_->comm, c_->comm_rank, c_->comm_nranks);
+  if (c_->frame_halo) c_->frame_halo->set_comm((ncclComm*)c_->comm, c_->comm_rank, c_->comm_nranks);
   CICE_CATCH
 }
 
