@@ -269,7 +269,7 @@ static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, 
   const size_t np = (size_t)c->dom.nx_block * c->dom.ny_block, n = np * nb;
   if (c->frame_gen != c->halo->generation()) frame_build(c);
   const size_t nc = c->frame.size();
-  if (nc > 0 && nc * 4 <= n) {   // the frame is a small part of the field: move only the frame
+  if (nc > 0 && nc * 2 <= n) {   // the frame is the smaller part of the field: move only the frame
     const size_t cnt = nc * nz, bytes = cnt * sizeof(T);
     if (c->frame_host_bytes < bytes) {
       if (c->frame_host) (void)hipHostFree(c->frame_host);

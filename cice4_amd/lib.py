@@ -385,6 +385,20 @@ class Context:
             assert field.dtype == np.int32
             self._ck(self.lib.cice_halo_update_ex_i4(self.h, p, nlev, loc, kind, C.c_int32(int(fill))))
 
+    def halo_update_blocked(self, field, loc=1, kind=1, fill=0):
+        """The same for a field in the reference's own array layout (nblocks, nz, ny, nx) -- block outermost, what the
+        Fortran boundary module hands over (cice_halo_update_blocked_*): only the frame of each block travels."""
+        nz = field.size // (self.nblocks * self.ny * self.nx)
+        assert field.flags["C_CONTIGUOUS"] and field.shape[0] == self.nblocks
+        p = field.ctypes.data_as(C.c_void_p)
+        if field.dtype == np.float64:
+            self._ck(self.lib.cice_halo_update_blocked_r8(self.h, p, nz, loc, kind, C.c_double(fill)))
+        elif field.dtype == np.float32:
+            self._ck(self.lib.cice_halo_update_blocked_r4(self.h, p, nz, loc, kind, C.c_float(fill)))
+        else:
+            assert field.dtype == np.int32
+            self._ck(self.lib.cice_halo_update_blocked_i4(self.h, p, nz, loc, kind, C.c_int32(int(fill))))
+
     def halo_update_resident(self, field):
         """The same on a field kept in device memory: upload once, update through cice_halo_update_dev_r8/_i4
         (all levels in one message per neighbour, no staging, no allocation per call), download."""

@@ -446,11 +446,21 @@ def test_multi_level_halo_resident_on_device(monkeypatch, selfcomm):
     for nlev, dt in ((65, np.float64), (3, np.float64), (2, np.int32), (65, np.float64)):
         a = (rng.uniform(0, 1, (nlev, dom["nblocks"], dom["ny"], dom["nx"])) * 1000).astype(dt)
         want = a.copy().reshape(nlev, -1); want[:, plain["hdst"]] = want[:, plain["hsrc"]]
-        b = a.copy()
+        b = a.copy(); a0 = a.copy()
         c.halo_update_resident(a)
         assert np.array_equal(a.reshape(nlev, -1), want), (nlev, dt)
         c.halo_update(b)                                  # host form: one update for all levels as well
         assert np.array_equal(b.reshape(nlev, -1), want), (nlev, dt)
+        # the reference's array layout (block outermost): only the frame of each block crosses PCIe, the update runs
+        # on the gathered frame (a second set of lists, addressed by frame position) -- messages included
+        nb = dom["nblocks"]
+        blk = np.ascontiguousarray(a0.reshape(nlev, nb, dom["ny"], dom["nx"]).transpose(1, 0, 2, 3))
+        inside = blk.copy()
+        c.halo_update_blocked(blk)
+        got = np.ascontiguousarray(blk.transpose(1, 0, 2, 3)).reshape(nlev, -1)
+        assert np.array_equal(got, want), ("blocked", nlev, dt)
+        untouched = np.ones(got.shape[1], bool); untouched[plain["hdst"]] = False
+        assert np.array_equal(got[:, untouched], np.ascontiguousarray(inside.transpose(1, 0, 2, 3)).reshape(nlev, -1)[:, untouched])
 
 
 def _owned(dom, f):
