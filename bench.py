@@ -488,6 +488,10 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     value = nsub_total / t_evp
     # dominant kernel: the subcycle kernel; HIP-event time of the launches on the library's stream / launches
     resident = resident and bool(ctx.evp_get_info("resident"))    # 0 if a launch timed out and the library fell back
+    if resident and ctx.evp_get_info("resident_waves") != rw:     # dense shape gave way to one workgroup per CU
+        rw = ctx.evp_get_info("resident_waves")
+        tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
+                f"(owns {rw - 1} rows x 63 columns), one workgroup per CU (the dense shape timed out on this box)")
     n_launch = steps if resident else launches_per_step(ndte, fused, dom.get("overlap", 0)) * steps
     us_per_launch = dev_ms * 1e3 / n_launch
     sub_per_launch = nsub_total / n_launch
