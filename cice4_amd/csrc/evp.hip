@@ -1900,7 +1900,14 @@ static void launch_res(const ResArgs& r, bool damp, dim3 g, hipStream_t s) {
 // subcycles ksub0 .. ksub0+nsub-1 in one launch; false: not done (time-out), the state is as it was
 bool Evp::run_resident(int ksub0, int nsub) {
   const int W = resident_waves();
-  if (W != res_w || res_deps.n == 0) build_resident(W);
+  if (W != res_w || res_deps.n == 0) {
+    try {
+      build_resident(W);
+    } catch (const Error&) {   // e.g. a tile with more producers than RES_MAXDEP: not a domain for this loop
+      resident_failed = true;
+      return false;
+    }
+  }
   if (res_epoch > 0x70000000u) {   // progress words are compared modulo 2^32 over at most 2^31
     res_prog.zero(stream);
     res_epoch = 0;
