@@ -1,6 +1,6 @@
-"""Randomised check of k_subcycle2 (two subcycles per launch) against k_subcycle (one per launch):
-random grid sizes, E-W boundary types, subcycle counts, damping, workgroup heights, ice cover.
-Bit-for-bit on every output field.  usage: python scripts/fuzz_pairing.py [ncases] [seed]"""
+"""Randomised check of k_subcycle2 (two subcycles per launch) and of k_evp_resident (the whole loop in one launch)
+against k_subcycle (one subcycle per launch): random grid sizes, boundary types, subcycle counts, damping, workgroup
+heights and shapes, ice cover.  Bit-for-bit on every output field.  usage: python scripts/fuzz_pairing.py [ncases] [seed]"""
 import os
 import sys
 
@@ -34,11 +34,14 @@ def main():
         nxg = int(rng.choice([rng.integers(5, 70), rng.integers(55, 65), rng.integers(110, 125), rng.integers(170, 260)]))
         nyg = int(rng.choice([rng.integers(5, 12), rng.integers(12, 40), rng.integers(40, 90)]))
         ew = int(rng.choice([1, 1, 1, 0, 2]))
+        ns = int(rng.choice([0, 0, 1, 2]))
         ndte = int(rng.choice([1, 2, 3, 8, 11, 24]))
         damping = bool(rng.integers(0, 2))
         cover = str(rng.choice(["full", "patchy"]))
         fw = int(rng.choice([0, 8, 12, 13, 14, 16]))
-        dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=0)
+        rw = int(rng.choice([0, 4, 6, 8, 11, 12]))
+        dense = int(rng.integers(0, 2))
+        dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=ns)
         gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=100 + case)
         grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
         s = synth.evp_state(grid, dom, seed=case, cover=cover)
@@ -47,15 +50,22 @@ def main():
             s[k][:, 0, :] += rng.uniform(-0.01, 0.01, s[k][:, 0, :].shape)
             s[k][:, -1, :] += rng.uniform(-0.01, 0.01, s[k][:, -1, :].shape)
             s[k][:, :, -1] += rng.uniform(-0.01, 0.01, s[k][:, :, -1].shape)
-        ref, f0 = run(ctx, grid, s, ndte, damping, fuse=0)
-        got, f1 = run(ctx, grid, s, ndte, damping, fuse=1, fused_waves=fw)
-        assert (f0, f1) == (0, 1)
-        for k in OUT:
-            if not np.array_equal(got[k], ref[k]):
-                bad = np.argwhere(got[k] != ref[k])
-                raise SystemExit(f"MISMATCH case {case}: nxg={nxg} nyg={nyg} ew={ew} ndte={ndte} damping={damping} "
-                                 f"cover={cover} W={fw} field={k} first={bad[0].tolist()} n={len(bad)}")
-        print(f"case {case}: {nxg}x{nyg} ew={ew} ndte={ndte} damp={int(damping)} {cover} W={fw} ok", flush=True)
+        ref, f0 = run(ctx, grid, s, ndte, damping, fuse=0, resident=0)
+        variants = []
+        if ns != 1:     # (a cyclic N-S edge rewrites ghost rows every subcycle: no pairing there)
+            got, f1 = run(ctx, grid, s, ndte, damping, fuse=1, fused_waves=fw, resident=0)
+            assert (f0, f1) == (0, 1)
+            variants.append((f"pairs W={fw}", got))
+        got, _ = run(ctx, grid, s, ndte, damping, fuse=1, resident=2, resident_waves=rw, resident_dense=dense)
+        assert ndte < 2 or ctx.evp_get_info("resident") == 1, "the resident loop fell back"
+        variants.append((f"one launch W={rw} dense={dense}", got))
+        for name, got in variants:
+            for k in OUT:
+                if not np.array_equal(got[k], ref[k]):
+                    bad = np.argwhere(got[k] != ref[k])
+                    raise SystemExit(f"MISMATCH case {case} ({name}): nxg={nxg} nyg={nyg} ew={ew} ns={ns} ndte={ndte} "
+                                     f"damping={damping} cover={cover} field={k} first={bad[0].tolist()} n={len(bad)}")
+        print(f"case {case}: {nxg}x{nyg} ew={ew} ns={ns} ndte={ndte} damp={int(damping)} {cover} W={fw} rw={rw} dense={dense} ok", flush=True)
     print("FUZZ-OK", ncases)
 
 

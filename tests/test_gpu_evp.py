@@ -136,6 +136,7 @@ def test_whole_evp_bit_exact_without_transcendentals(ctx, orc, bs, shape):
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
     ctx.evp_set_option("waves", shape[0]); ctx.evp_set_option("rows_per_wave", shape[1])
+    ctx.evp_set_option("fuse", 0); ctx.evp_set_option("resident", 0)     # this test is about k_subcycle's tile shapes
     ctx.evp(DT, sg)
     orc.set_strength_parameters()
     for k in EVP_OUT_FIELDS + ("iceumask",):
@@ -690,9 +691,9 @@ def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
 
 
 def test_pairing_fuzz():
-    """scripts/fuzz_pairing.py: 30 random grids / boundary types / subcycle counts / workgroup heights,
-    with the never-written ghost cells made different from the cells they would mirror: two subcycles per
-    launch == one per launch, bit for bit."""
+    """scripts/fuzz_pairing.py: 30 random grids / boundary types (E-W and N-S) / subcycle counts / workgroup
+    heights and shapes, with the never-written ghost cells made different from the cells they would mirror: two
+    subcycles per launch == the whole loop in one launch == one subcycle per launch, bit for bit."""
     import subprocess
     import sys
     import os

@@ -73,13 +73,16 @@ def test_evp_gx3_real_grid_golden(ctx):
     assert (d["nx"], d["ny"], d["nblocks"]) == (dom["nx"], dom["ny"], 1)
     g = {k: np.ascontiguousarray(v) for k, v in grid.items()}
     first = None
-    for opts in (dict(), dict(fuse=0), dict(derive_metrics=0), dict(fuse=0, derive_metrics=0, use_graph=0)):
+    # default = the whole loop in one launch (k_evp_resident); then two subcycles per launch, one per launch, ...
+    for opts in (dict(), dict(resident=0), dict(fuse=0, resident=0), dict(derive_metrics=0, resident=0),
+                 dict(fuse=0, derive_metrics=0, use_graph=0, resident=0)):
         s = {k: v.copy() for k, v in s0.items()}
         ctx.evp_init(g, ndte=NDTE)
         for k, v in opts.items():
             ctx.evp_set_option(k, v)
         if not opts:
             assert ctx.evp_get_info("derive_metrics") == 1 and ctx.evp_get_info("fused") == 1
+            assert ctx.evp_get_info("resident") == 1
         ctx.evp(DT, s)
         if first is None:
             first = s
