@@ -9,8 +9,15 @@ device-resident state.  `value` = EVP subcycles per second for the whole job.  T
 JSON line carries the column-thermodynamics rate ((cell,category) updates per second),
 the HBM roofline of the dominant kernel and a CPU baseline timed on this host.
 
-N > 1: launched by torch.distributed.run, one rank per GPU; the grid is cut into N
-j-slabs (strong scaling) and ghost rows travel by RCCL point-to-point inside the library.
+N > 1: one rank per GPU; the grid is cut into N j-slabs (strong scaling) and ghost rows travel by RCCL
+point-to-point inside the library.  Either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment), or -- a plain `python bench.py --gpus N` -- this process starts the N ranks
+itself as fresh children BEFORE anything touches a GPU (launch_ranks) and passes rank 0's JSON line through.
+Every wait of a rank on its peers (rendezvous, communicator creation, first exchange) is bounded: a rank that
+cannot proceed exits non-zero with a message, and the launcher then stops the others.
+
+  --host-only: no GPU.  The same launcher, rendezvous (gloo) and slab decomposition; the ranks exchange a test
+  field through the library's message lists over gloo and check every ghost / overlap row (tests/test_bench_launcher.py).
 """
 import argparse
 import json
@@ -95,25 +102,199 @@ def parse():
     p.add_argument("--no-dropin-timing", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     p.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
+    p.add_argument("--host-only", action="store_true",
+                   help="no GPU: launcher + rendezvous + slab decomposition + one ghost exchange over gloo, checked")
+    p.add_argument("--comm-timeout", type=float, default=120.0,
+                   help="N > 1: seconds a rank may wait for its peers in the rendezvous, in the creation of the RCCL "
+                        "communicator and in the first exchange before it gives up (exit code 14)")
+    p.add_argument("--launch-timeout", type=float, default=2400.0,
+                   help="N > 1 without torchrun: seconds the self-started ranks may run before the launcher stops them")
     return p.parse_args()
 
 
-def init_dist(n_gpus):
+class bounded:
+    """`with bounded(seconds, what):` -- a wait on other ranks that must not hang.  If the block has not finished
+    after `seconds`, the process says what it was waiting for and leaves with exit code 14 (the native call it sits
+    in -- ncclCommInitRank, a stream synchronise behind an ncclRecv -- cannot be interrupted any other way; the
+    launcher, or torchrun, then stops the other ranks)."""
+
+    def __init__(self, seconds, what):
+        self.seconds, self.what, self.timer = seconds, what, None
+
+    def _fire(self):
+        rank = os.environ.get("RANK", "0")
+        sys.stderr.write(f"[bench] rank {rank}: {self.what} did not complete within {self.seconds:.0f} s "
+                         f"(a peer is missing, has failed, or shares this rank's device) -- giving up\n")
+        sys.stderr.flush()
+        os._exit(14)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self.timer = threading.Timer(self.seconds, self._fire)
+            self.timer.daemon = True
+            self.timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self.timer is not None:
+            self.timer.cancel()
+        return False
+
+
+def visible_gpus():
+    """Number of GPUs this host shows, counted in a CHILD process: the launcher itself must never touch a GPU
+    (its children are started afterwards), and the count needs the HIP runtime."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); from cice4_amd import lib; "
+            "print(lib.load().cice_device_count())" % ROOT)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        return int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else 0
+    except (subprocess.SubprocessError, ValueError, IndexError, OSError):
+        return 0
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without torchrun: start the N ranks as fresh child processes -- before this process
+    has made any GPU call, and it never makes one -- with the environment torch.distributed.run would give them,
+    pass rank 0's stdout (the one JSON line) through, and return the first non-zero exit code.  A rank that fails
+    takes the others with it (each child is its own process group; exactly those groups are signalled)."""
+    import signal
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.host_only and os.environ.get("CICE4_AMD_BENCH_DEVICE") is None:
+        have = visible_gpus()
+        if have < n:
+            sys.stderr.write(f"[bench] --gpus {n}: this host shows {have} GPU(s).  One rank needs one GPU of its own "
+                             f"(RCCL refuses two ranks on one device); nothing was started.\n")
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), CICE4_AMD_BENCH_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL, start_new_session=True))
+    deadline = time.time() + args.launch_timeout
+    rc, why = 0, ""
+    while True:
+        codes = [p.poll() for p in procs]
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            rc, why = bad[0][1], f"rank {bad[0][0]} exited with code {bad[0][1]}"
+            break
+        if all(c == 0 for c in codes):
+            return 0
+        if time.time() > deadline:
+            rc, why = 15, f"the ranks did not finish within --launch-timeout {args.launch_timeout:.0f} s"
+            break
+        time.sleep(0.2)
+    sys.stderr.write(f"[bench] {why}; stopping the other ranks\n")
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)          # the rank and the CPU-baseline child it may have started
+                except (ProcessLookupError, PermissionError):
+                    pass
+        t_end = time.time() + 5.0
+        while time.time() < t_end and any(p.poll() is None for p in procs):
+            time.sleep(0.1)
+    return rc if rc > 0 else 1
+
+
+def init_dist(n_gpus, comm_timeout=120.0):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != n_gpus:
         raise SystemExit(f"--gpus {n_gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {n_gpus}")
+                         f"--nproc-per-node {n_gpus}, or without RANK / WORLD_SIZE in the environment")
     dist = None
+    hook = os.environ.get("CICE4_AMD_BENCH_TEST_HOOK", "")      # tests/test_bench_launcher.py: "die:R" / "hang:R"
+    if hook and world > 1 and hook.split(":")[1] == str(rank):
+        if hook.startswith("die"):
+            raise SystemExit(7)
+        time.sleep(3600)
     if world > 1:
+        import datetime
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barriers, the ncclUniqueId, max-over-ranks) on gloo; the data path
         # (ghost rows) is RCCL inside libcice4_amd.so
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        with bounded(comm_timeout + 10.0, "rendezvous of the ranks (gloo)"):
+            dist.init_process_group("gloo", rank=rank, world_size=world,
+                                    timeout=datetime.timedelta(seconds=max(5.0, comm_timeout)))
     return rank, world, local, dist
+
+
+def host_only(args):
+    """--host-only: what a multi-rank run does before and around the device work, without a device: rendezvous, the
+    slab decomposition bench.py --gpus N uses, and ONE ghost exchange of a test field (value = global cell number)
+    through the library's own send / receive lists over gloo, in the order Halo::update works (wrap list, pack,
+    messages, on-rank refresh, unpack).  Every cell of every rank's slab -- owned rows, overlap rows, ghost rows and
+    columns -- must then hold the number of the global cell it mirrors."""
+    rank, world, local, dist = init_dist(args.gpus, args.comm_timeout)
+    import torch
+    ctx = lib.Context()                       # host-side domain logic only
+    nxg, nyg, ndte, _ = workload(args.workload)
+    rows = nyg // world
+    overlap = args.overlap if args.overlap >= 0 else auto_overlap(nxg, rows)
+    dom = ctx.domain_create_slabs(nxg, nyg, world, ew=1, ns=0, rank=rank, nranks=world, overlap=overlap)
+    ny, nx = dom["ny"], dom["nx"]
+    jlo, jhi, j0 = int(dom["jlo"][0]), int(dom["jhi"][0]), int(dom["j0"][0])
+    own_lo, own_hi = int(dom["own_jlo"][0]), int(dom["own_jhi"][0])
+    jg = j0 + (np.arange(ny) + 1 - jlo)                         # global row of local row j (1-based j = index + 1)
+    ig = (np.arange(nx) - 1) % nxg                              # cyclic east-west
+    want = (jg[:, None] * nxg + ig[None, :]).astype(np.float64)
+    f = np.full((ny, nx), -1.0)
+    f[own_lo - 1:own_hi, 1:nx - 1] = want[own_lo - 1:own_hi, 1:nx - 1]   # only what this rank owns
+    flat = f.reshape(-1)
+    sends, recvs = ctx.halo_msgs(0), ctx.halo_msgs(1)
+    with bounded(args.comm_timeout, "first ghost exchange (gloo)"):
+        flat[dom["hdst"]] = flat[dom["hsrc"]]
+        reqs, bufs = [], []
+        for peer, addr in recvs:
+            b = torch.empty(len(addr), dtype=torch.float64)
+            bufs.append((addr, b))
+            reqs.append(dist.irecv(b, src=peer))
+        for peer, addr in sends:
+            reqs.append(dist.isend(torch.from_numpy(flat[addr].copy()), dst=peer))
+        for r in reqs:
+            r.wait()
+        if len(dom["rsrc"]):
+            flat[dom["rdst"]] = flat[dom["rsrc"]]
+        for addr, b in bufs:
+            flat[addr] = b.numpy()
+    # rows inside the global grid (the outermost ranks' rows beyond an open edge are never written)
+    inside = (jg >= 0) & (jg < nyg)
+    inside[:max(0, jlo - 2)] = False                            # padding below the extended slab, if any
+    inside[jhi + 1:] = False
+    ok = bool(np.array_equal(f[inside], want[inside]))
+    res = [ok]
+    if dist is not None:
+        t = torch.tensor([1 if ok else 0, 1], dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        res = [int(t[0]) == world]
+        seen = int(t[1])
+    else:
+        seen = 1
+    if rank == 0:
+        print(json.dumps({"host_only": True, "n_gpus": world, "ranks_seen": seen, "exchange_ok": res[0],
+                          "config": {"workload": workload(args.workload)[3],
+                                     "decomposition": f"1x{world} j-slabs, {overlap} overlap rows",
+                                     "messages_per_rank": {"send": len(sends), "recv": len(recvs)}}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if res[0] else 1
 
 
 def auto_overlap(nxg, rows):
@@ -408,9 +589,10 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         # the communicator is created once per context and handed to every decomposition built afterwards
         # (the uid is only used by the first call)
         uid = [ctx.comm_unique_id() if rank == 0 and not getattr(ctx, "_comm_ready", False) else None]
-        if not getattr(ctx, "_comm_ready", False):
-            dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0] if uid[0] is not None else bytes(128), rank, world)
+        with bounded(args.comm_timeout, "creation of the RCCL communicator (ncclCommInitRank)"):
+            if not getattr(ctx, "_comm_ready", False):
+                dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0] if uid[0] is not None else bytes(128), rank, world)
         ctx._comm_ready = True
     ctx.evp_init(grid, ndte=ndte)
     if tune and args.waves:
@@ -441,7 +623,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                 f"(owns {rw - 1} rows x 63 columns), " + ("three workgroups per CU (every slot of the chip)" if dense
                                                           else "one workgroup per CU"))
     ctx.evp_upload(state)
-    ctx.evp_prepare(DT)
+    with bounded(args.comm_timeout if world > 1 else 0, "first ghost exchange (evp_prepare: RCCL send / receive)"):
+        ctx.evp_prepare(DT)
+        ctx.sync()
     nt, nu = ctx.evp_active_cells()
 
     def sync_all():
@@ -454,8 +638,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     # bring the device to its sustained clocks first (a few ms of work right after start-up still run at
     # ramping clocks: 91 k instead of 112 k subcycles/s observed once), then the W warm-up steps
     # (a fixed number of steps, agreed by all ranks: every step of a multi-rank run exchanges ghost rows)
-    ctx.evp_subcycles(1, ndte)          # builds the graph
-    sync_all()
+    with bounded(args.comm_timeout if world > 1 else 0, "first subcycle loop across the ranks"):
+        ctx.evp_subcycles(1, ndte)          # builds the graph
+        sync_all()
     t_ramp = time.perf_counter()
     ctx.evp_subcycles(1, ndte)
     sync_all()
@@ -600,6 +785,11 @@ def main():
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python bench.py --gpus N`: this process has not touched a GPU and never will
+        raise SystemExit(launch_ranks(args))
+    if args.host_only:
+        raise SystemExit(host_only(args))
     # NOTE on load order: torch is imported before the product library touches the device.  Both bring a
     # HIP runtime and a librccl.so.1; whichever is loaded first serves the whole process, and loading the
     # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With
@@ -610,7 +800,7 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    rank, world, local, dist = init_dist(args.gpus)
+    rank, world, local, dist = init_dist(args.gpus, args.comm_timeout)
     try:
         import torch
         have_torch_gpu = torch.cuda.is_available()
@@ -754,6 +944,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "EVP subcycles/sec", "value": m["value"], "unit": "subcycles/s", "n_gpus": world,
+            "ranks_seen": ctx.comm_count() if world > 1 else 1,     # ncclCommCount: what RCCL itself says
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * m["t_evp"] / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "config": m["config"], "roofline": m["roofline"],

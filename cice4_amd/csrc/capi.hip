@@ -603,6 +603,18 @@ int cice_comm_init(cice_ctx* ctx, const char uid[128], int rank, int nranks) {
   CICE_CATCH
 }
 
+// Ranks of this context's communicator as RCCL itself counts them (ncclCommCount); 0 before cice_comm_init.
+int cice_comm_count(cice_ctx* ctx, int* nranks) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(nranks != nullptr, "NULL argument");
+  *nranks = 0;
+  if (c_->comm) {
+    const ncclResult_t r = ncclCommCount(c_->comm, nranks);
+    if (r != ncclSuccess) throw Error{CICE_ECOMM, std::string("ncclCommCount: ") + ncclGetErrorString(r)};
+  }
+  CICE_CATCH
+}
+
 // ---- EVP -------------------------------------------------------------------------------------
 int cice_evp_init(cice_ctx* ctx, const cice_evp_config* cfg, const cice_evp_grid* grid) {
   CICE_TRY(ctx)

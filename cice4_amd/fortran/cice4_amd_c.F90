@@ -257,6 +257,11 @@ module cice4_amd_c
          character(kind=c_char), intent(in) :: uid(128)
          integer(c_int), value :: rank, nranks
       end function
+      integer(c_int) function cice_comm_count(ctx, nranks) bind(C, name='cice_comm_count')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), intent(out) :: nranks
+      end function
       integer(c_int) function cice_evp_init(ctx, cfg, grid) bind(C, name='cice_evp_init')
          import
          type(c_ptr), value :: ctx

@@ -261,17 +261,29 @@ class Context:
 
     def halo_msgs(self, direction):
         """direction 0 / 1: ghost-cell messages sent / received; 2 / 3: tripole top rows sent / received (receive
-        addresses are indices into the global fold buffer)."""
+        addresses are indices into the global fold buffer).  The list ends at the first CICE_EINVAL for a message
+        index; a context without a domain or a bad direction is an error, not an empty list, and for directions
+        0 / 1 the count is checked against cice_domain_info."""
+        if direction not in (0, 1, 2, 3):
+            raise CiceError(f"halo_msgs: direction {direction} not in 0..3")
+        if not getattr(self, "dinfo", None):
+            raise CiceError("halo_msgs: no domain (call domain_create* first)")
         out = []
         m = -1
         while True:
             m += 1
             peer = C.c_int(); cnt = C.c_int()
-            if self.lib.cice_domain_halo_msg(self.h, direction, m, C.byref(peer), C.byref(cnt), None) != 0:
+            rc = self.lib.cice_domain_halo_msg(self.h, direction, m, C.byref(peer), C.byref(cnt), None)
+            if rc == -1:        # CICE_EINVAL: past the last message (context and direction were checked above)
                 break
+            self._ck(rc)
             addr = np.zeros(cnt.value, np.int32)
             self._ck(self.lib.cice_domain_halo_msg(self.h, direction, m, None, None, _i4(addr)))
             out.append((peer.value, addr))
+        if direction in (0, 1):
+            want = self.dinfo["nsend" if direction == 0 else "nrecv"]
+            if len(out) != want:
+                raise CiceError(f"halo_msgs({direction}): {len(out)} messages listed, cice_domain_info says {want}")
         return out
 
     # ---- communication --------------------------------------------------
@@ -284,6 +296,12 @@ class Context:
 
     def comm_init(self, uid, rank, nranks):
         self._ck(self.lib.cice_comm_init(self.h, C.c_char_p(uid), rank, nranks))
+
+    def comm_count(self):
+        """ranks of this context's communicator as RCCL counts them (0 before comm_init)"""
+        n = C.c_int(0)
+        self._ck(self.lib.cice_comm_count(self.h, C.byref(n)))
+        return n.value
 
     # ---- EVP -----------------------------------------------------------------
     def evp_init(self, grid, ndte=120, evp_damping=False, kstrength=1, krdg_partic=1, krdg_redist=1,

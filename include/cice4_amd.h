@@ -114,6 +114,9 @@ int cice_domain_halo_msg(const cice_ctx *ctx, int dir, int msg, int *peer, int *
  * distributed by the caller (MPI_Bcast in a Fortran driver, torch.distributed here). */
 int cice_comm_unique_id(char uid[128]);
 int cice_comm_init(cice_ctx *ctx, const char uid[128], int rank, int nranks);
+/* ranks of the communicator as RCCL counts them (ncclCommCount; = MPI_COMM_SIZE of mpi/ice_communicate.F90:109-136);
+ * 0 before cice_comm_init */
+int cice_comm_count(cice_ctx *ctx, int *nranks);
 
 /* ---- EVP dynamics (source/ice_dyn_evp.F90) ----------------------------- */
 typedef struct { /* source/ice_grid.F90:58-133; each (nx_block,ny_block,nblocks) */
