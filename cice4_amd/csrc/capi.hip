@@ -2,6 +2,7 @@
 // boundary: every entry returns a status code and records the message.
 #include <rccl/rccl.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -91,7 +92,6 @@ struct cice_ctx {
   DevBuf<double> frame_pack;
   void* frame_host = nullptr;
   size_t frame_host_bytes = 0;
-  int frame_gen = -1;
   DevBuf<int32_t> tv_list;
   // thermo
   ThermoParams tp{};
@@ -131,7 +131,6 @@ struct cice_ctx {
     if (!halo) {
       CICE_REQUIRE(have_domain, "cice_domain_create has not been called");
       halo.reset(new Halo());
-      frame_gen = -1;
       frame_halo.reset();
       halo->init(dom, stream);
       if (comm) halo->set_comm((ncclComm*)comm, comm_rank, comm_nranks);
@@ -251,7 +250,6 @@ static void frame_build(cice_ctx* c) {
   c->frame_halo->init(fd, c->stream);
   if (c->comm) c->frame_halo->set_comm((ncclComm*)c->comm, c->comm_rank, c->comm_nranks);
   CICE_HIP(hipStreamSynchronize(c->stream));
-  c->frame_gen = c->halo->generation();
 }
 
 template <class T>
@@ -261,13 +259,68 @@ static void halo_apply_on(Halo& h, T* d, int nlev, size_t n, int loc, int kind, 
   else h.update_i4(reinterpret_cast<int32_t*>(d), nlev, n, loc, kind, (int32_t)fill);
 }
 
+// A HOST array on a domain without messages (one rank: every ghost cell mirrors a cell of the same array, takes the
+// fill value or comes out of the tripole fold): the update is a few thousand element copies inside the caller's own
+// array, done right here on the host from the domain's lists -- what serial/ice_boundary.F90:591-873 does, in the
+// order Halo::update works (copy list, fill list, refresh list, fold).  No device round trip: the whole model's Bound
+// timer is back at the reference's.  Device-resident fields (cice_halo_update_dev_*) and
+// domains with off-rank neighbours keep the device path.
+template <class T>
+static T fold_avg_host(T x1, T x2, int sgn) {
+  if (std::is_same<T, int32_t>::value) return (T)std::round(0.5 * (double)(x1 + sgn * x2));   // nint()
+  return (T)0.5 * (x1 + (T)sgn * x2);
+}
+
+template <class T>
+static void halo_host_lists(const Domain& dm, T* field, int nz, int loc, int kind, T fill) {
+  const size_t np = (size_t)dm.nx_block * dm.ny_block;
+  // list address (level-major numbering: block * np + cell) -> element of level 0 in the caller's layout
+  auto at = [&](int32_t a) { const size_t b = (size_t)a / np; return b * (size_t)nz * np + ((size_t)a - b * np); };
+  const bool fold = dm.fold;
+  if (fold) {
+    CICE_REQUIRE(loc >= LOC_CENTER && loc <= LOC_EFACE, "halo: field location unknown on a tripole grid");
+    CICE_REQUIRE(kind >= KIND_SCALAR && kind <= KIND_ANGLE, "halo: field kind unknown on a tripole grid");
+  }
+  const int sgn = kind == KIND_SCALAR ? 1 : -1;
+  std::vector<T> buf(fold ? 2 * (size_t)dm.nxg : 0);
+  for (int z = 0; z < nz; ++z) {
+    T* f = field + (size_t)z * np;
+    for (size_t e = 0; e < dm.hsrc.size(); ++e) f[at(dm.hdst[e])] = f[at(dm.hsrc[e])];
+    for (int32_t a : dm.hfill) f[at(a)] = fill;
+    for (size_t e = 0; e < dm.rsrc.size(); ++e) f[at(dm.rdst[e])] = f[at(dm.rsrc[e])];
+    if (fold) {
+      const int l = loc - 1;
+      std::fill(buf.begin(), buf.end(), fill);
+      for (size_t e = 0; e < dm.fold_lsrc.size(); ++e) buf[dm.fold_bidx[e]] = f[at(dm.fold_lsrc[e])];
+      for (size_t e = 0; e < dm.fold_lo[l].size(); ++e) {
+        const int32_t lo = dm.fold_lo[l][e], hi = dm.fold_hi[l][e];
+        const T x = fold_avg_host<T>(buf[lo], buf[hi], sgn);
+        buf[lo] = x;
+        buf[hi] = (T)sgn * x;
+      }
+      const Domain::FoldOut& fo = dm.fold_out[l];
+      for (size_t e = 0; e < fo.dst.size(); ++e) f[at(fo.dst[e])] = (T)sgn * buf[fo.src[e]];
+    }
+  }
+}
+
+static bool domain_has_messages(const Domain& dm) {
+  return !dm.send.empty() || !dm.recv.empty() || !dm.fold_send.empty() || !dm.fold_recv.empty();
+}
+
 template <class T>
 static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, double fill) {
-  c->need_halo();
   CICE_REQUIRE(field && nz >= 1, "bad argument");
+  CICE_REQUIRE(c->have_domain, "cice_domain_create has not been called");
+  static const bool force_dev = std::getenv("CICE4_AMD_HALO_HOST_ON_DEVICE") != nullptr;   // test aid: the frame path
+  if (!domain_has_messages(c->dom) && !force_dev) {
+    halo_host_lists<T>(c->dom, field, nz, loc, kind, (T)fill);
+    return;
+  }
+  c->need_halo();
   const int nb = c->dom.nblocks();
   const size_t np = (size_t)c->dom.nx_block * c->dom.ny_block, n = np * nb;
-  if (c->frame_gen != c->halo->generation()) frame_build(c);
+  if (!c->frame_halo) frame_build(c);   // the frame belongs to the domain: dropped by cice_domain_create*
   const size_t nc = c->frame.size();
   if (nc > 0 && nc * 2 <= n) {   // the frame is the smaller part of the field: move only the frame
     const size_t cnt = nc * nz, bytes = cnt * sizeof(T);
@@ -396,6 +449,20 @@ int cice_destroy(cice_ctx* ctx) {
   return CICE_OK;
 }
 
+// The library is compiled for one set of ice_domain_size parameters (CICE_NCAT, ...): every stride of the
+// category / layer / tracer dimensions of the caller's module arrays is derived from them.  A host model built
+// with other sizes must not get past its init calls.
+int cice_check_sizes(cice_ctx* ctx, int ncat, int nilyr, int nslyr, int max_ntrcr) {
+  CICE_TRY(ctx)
+  if (ncat != NCAT || nilyr != NILYR || nslyr != NSLYR || max_ntrcr != NTRCR)
+    throw Error{CICE_EINVAL, "libcice4_amd is built for ncat=" + std::to_string(NCAT) + " nilyr=" + std::to_string(NILYR) +
+                                 " nslyr=" + std::to_string(NSLYR) + " max_ntrcr=" + std::to_string(NTRCR) +
+                                 "; the host model has ncat=" + std::to_string(ncat) + " nilyr=" + std::to_string(nilyr) +
+                                 " nslyr=" + std::to_string(nslyr) + " max_ntrcr=" + std::to_string(max_ntrcr) +
+                                 " (rebuild the library with matching CICE_NCAT / CICE_NILYR / CICE_NSLYR / CICE_MAX_NTRCR)"};
+  CICE_CATCH
+}
+
 const char* cice_last_error(const cice_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
 int cice_diag_stream_copy(cice_ctx* ctx, long long n_doubles, float* elapsed_ms) {
@@ -447,7 +514,6 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   c_->evp.reset();
   c_->transport.reset();
   c_->halo.reset();
-  c_->frame_gen = -1;   // the frame belongs to the domain
   c_->frame_halo.reset();
   CICE_CATCH
 }
@@ -464,7 +530,6 @@ int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, in
   c_->evp.reset();
   c_->transport.reset();
   c_->halo.reset();
-  c_->frame_gen = -1;   // the frame belongs to the domain
   c_->frame_halo.reset();
   CICE_CATCH
 }
@@ -501,7 +566,6 @@ int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int
   c_->evp.reset();
   c_->transport.reset();
   c_->halo.reset();
-  c_->frame_gen = -1;   // the frame belongs to the domain
   c_->frame_halo.reset();
   CICE_CATCH
 }

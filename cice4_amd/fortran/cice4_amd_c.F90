@@ -257,6 +257,11 @@ module cice4_amd_c
          character(kind=c_char), intent(in) :: uid(128)
          integer(c_int), value :: rank, nranks
       end function
+      integer(c_int) function cice_check_sizes(ctx, ncat, nilyr, nslyr, max_ntrcr) bind(C, name='cice_check_sizes')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: ncat, nilyr, nslyr, max_ntrcr
+      end function
       integer(c_int) function cice_comm_count(ctx, nranks) bind(C, name='cice_comm_count')
          import
          type(c_ptr), value :: ctx

@@ -134,6 +134,8 @@
       integer (c_int) :: info(9)
 
       call cice_gpu_ensure()
+      ! ice_strength reads aicen, vicen with the library's category stride
+      call cice_gpu_check(cice_check_sizes(cice_gpu_ctx, ncat, nilyr, nslyr, max_ntrcr), 'init_evp')
       ! with rccl/ice_boundary.F90 in the build the device topology (and, under MPI, the RCCL
       ! communicator) already exists for the model's block distribution; with the reference's own
       ! boundary module (serial build) it is created here

@@ -49,6 +49,7 @@
       cfg%nt_Tsfc = nt_Tsfc
       cfg%nt_iage = nt_iage
       call cice_gpu_ensure()
+      call cice_gpu_check(cice_check_sizes(cice_gpu_ctx, ncat, nilyr, nslyr, max_ntrcr), 'init_thermo_vertical')
       ! the device side computes the salinity / melting-temperature profile and hands it back,
       ! so that the host copies used by ice_init / ice_history stay consistent with it
       call cice_gpu_check(cice_thermo_init(cice_gpu_ctx, cfg, salin, Tmlt), 'init_thermo_vertical')

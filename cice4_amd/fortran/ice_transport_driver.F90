@@ -40,6 +40,10 @@
       if (trim(advection) == 'remap') then
          if (.not. cice_gpu_domain_ready) &
             call abort_ice('init_transport: the device block topology does not exist yet (init_evp or ice_HaloCreate first)')
+         ! the library's strides of the category / layer / tracer dimensions are compile-time sizes
+         call cice_gpu_check(cice_check_sizes(cice_gpu_ctx, ncat, nilyr, nslyr, max_ntrcr), 'init_transport')
+         if (ntrcr > size(cfg%trcr_depend)) &
+            call abort_ice('init_transport: more tracers than the GPU transport module is built for')
          cfg%ntrcr = ntrcr
          cfg%trcr_depend = 0
          cfg%trcr_depend(1:ntrcr) = trcr_depend(1:ntrcr)

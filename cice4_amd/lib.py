@@ -297,6 +297,10 @@ class Context:
     def comm_init(self, uid, rank, nranks):
         self._ck(self.lib.cice_comm_init(self.h, C.c_char_p(uid), rank, nranks))
 
+    def check_sizes(self, ncat, nilyr, nslyr, max_ntrcr):
+        """CiceError unless the host model's ice_domain_size parameters are the library's compile-time sizes"""
+        self._ck(self.lib.cice_check_sizes(self.h, ncat, nilyr, nslyr, max_ntrcr))
+
     def comm_count(self):
         """ranks of this context's communicator as RCCL counts them (0 before comm_init)"""
         n = C.c_int(0)

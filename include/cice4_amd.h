@@ -56,6 +56,10 @@ int cice_host_register(cice_ctx *ctx, void *host, size_t bytes);
  * BEFORE the host frees or re-allocates such an array. */
 int cice_host_unregister_all(cice_ctx *ctx);
 int cice_destroy(cice_ctx *ctx);
+/* The category / layer / tracer strides of every module array are the compile-time sizes above
+ * (source/ice_domain_size.F90:37-70).  A host model calls this from its init routines with ITS ncat, nilyr, nslyr,
+ * max_ntrcr: CICE_EINVAL (and a message naming both sets) unless they are the library's. */
+int cice_check_sizes(cice_ctx *ctx, int ncat, int nilyr, int nslyr, int max_ntrcr);
 const char *cice_last_error(const cice_ctx *ctx); /* ctx may be NULL: last create error */
 int cice_device_sync(cice_ctx *ctx);
 /* Diagnostics: streams n_doubles 8-byte loads + stores through HBM twice (kernel

@@ -84,6 +84,16 @@ def main():
                     assert np.array_equal(got, want), (dtype, ew, ns, loc, kind, np.argwhere(got != want)[:8])
                     assert not np.array_equal(want, a)
                     nchk += 1
+                    # the C-ABI entry the boundary module calls with a HOST array (cice_halo_update_blocked_*): on a
+                    # one-rank domain the lists are applied on the host inside the caller's array (no device), in the
+                    # reference's layout (block outermost, levels inside) -- 1 and 3 levels
+                    for shape in ((nb, ny, nx), (nb, 3, ny, nx)):
+                        a = rand(rng, shape, dtype)
+                        want = a.copy(); ref.halo_nd(want, loc, kind)
+                        got = a.copy()
+                        c.halo_update_blocked(got[:dom["nblocks"]].reshape(dom["nblocks"], -1, ny, nx), loc, kind, fill=0)
+                        assert np.array_equal(got, want), ("blocked", dtype, shape, ew, ns, loc, kind)
+                        nchk += 1
         print("BOUNDARY-OK", nchk)
         return
 

@@ -62,3 +62,21 @@ def test_argument_errors_return_codes():
         c.domain_create(10, 10, 5, 5, rank=4, npx=2, npy=2)
     with pytest.raises(lib.CiceError):
         c.thermo_init(heat_capacity=False)      # zero-layer thermodynamics: not implemented, says so
+
+
+def test_host_model_sizes_are_checked():
+    """A model built with another ncat / nilyr / nslyr / max_ntrcr must not get past its init calls: the library's
+    strides of those dimensions are compile-time sizes (the drop-in modules call this from init_evp,
+    init_thermo_vertical and init_transport)."""
+    c = lib.Context()
+    c.check_sizes(5, 4, 1, 5)
+    for bad in ((6, 4, 1, 5), (5, 7, 1, 5), (5, 4, 3, 5), (5, 4, 1, 6)):
+        with pytest.raises(lib.CiceError) as e:
+            c.check_sizes(*bad)
+        assert "ncat=5" in str(e.value) and f"ncat={bad[0]}" in str(e.value)
+    assert c.comm_count() == 0          # no communicator yet
+    with pytest.raises(lib.CiceError):
+        c.halo_msgs(0)                  # no domain: an error, not an empty list
+    c.domain_create(16, 12, 8, 6)
+    with pytest.raises(lib.CiceError):
+        c.halo_msgs(7)
