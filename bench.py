@@ -86,6 +86,9 @@ def parse():
     p.add_argument("--no-resident", action="store_true", help="do not run the whole subcycle loop in one launch (k_evp_resident)")
     p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
     p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/13/14/16); 0 = auto")
+    p.add_argument("--no-skew", action="store_true", help="no K-subcycle sweeps (k_subcycle_skew) on large grids")
+    p.add_argument("--skew-levels", type=int, default=0, help="K of k_subcycle_skew (2, 3, 4, 5, 6, 8); 0 = library's choice")
+    p.add_argument("--skew-seg-rows", type=int, default=0, help="rows a workgroup of k_subcycle_skew owns; 0 = auto")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -312,15 +315,25 @@ def auto_overlap(nxg, rows):
     return h + (h & 1) if h + (h & 1) <= rows else max(2, h - (h & 1))
 
 
-def launches_per_step(ndte, fused, overlap):
-    """Kernel launches of one step's subcycle loop (Evp::launch_range): pairs of subcycles where the
-    domain allows, never across a wide-halo refresh."""
-    n, k = 0, 1
+def launches_per_step(ndte, fused, overlap, skew_k=0):
+    """Kernel launches of one step's subcycle loop and the subcycles the most common launch runs
+    (Evp::launch_range): K subcycles per sweep or pairs where the domain allows, never across a wide-halo refresh."""
+    n, k, sizes = 0, 1, {}
+    def clear(length):
+        if k + length - 1 > ndte:
+            return False
+        return not (overlap > 0 and any(q % overlap == 0 for q in range(k, k + length - 1)))
     while k <= ndte:
-        pair = fused and k + 1 <= ndte and not (overlap > 0 and k % overlap == 0)
-        k += 2 if pair else 1
+        if skew_k and clear(skew_k):
+            step = skew_k
+        elif fused and clear(2):
+            step = 2
+        else:
+            step = 1
+        sizes[step] = sizes.get(step, 0) + 1
+        k += step
         n += 1
-    return n
+    return n, max(sizes, key=lambda z: sizes[z] * z)
 
 
 def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
@@ -612,6 +625,15 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     fw = ctx.evp_get_info("fused_waves") if fused else 0
     if fused:
         tile = f"two subcycles per launch; workgroup {fw} wavefronts x 64 lanes owns {fw - 3} rows x 59 columns"
+    ctx.evp_set_option("skew", 0 if args.no_skew else 1)
+    if args.skew_levels:
+        ctx.evp_set_option("skew_levels", args.skew_levels)
+    if args.skew_seg_rows:
+        ctx.evp_set_option("skew_seg_rows", args.skew_seg_rows)
+    skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") else 0
+    if skew_k:
+        tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
+                f"lanes, owns {62 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
     ctx.evp_set_option("resident", 0 if args.no_resident else 1)
     if tune and args.resident_waves:
         ctx.evp_set_option("resident_waves", args.resident_waves)
@@ -677,7 +699,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         rw = ctx.evp_get_info("resident_waves")
         tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
                 f"(owns {rw - 1} rows x 63 columns), one workgroup per CU (the dense shape timed out on this box)")
-    n_launch = steps if resident else launches_per_step(ndte, fused, dom.get("overlap", 0)) * steps
+    n_step, main_sub = launches_per_step(ndte, fused, dom.get("overlap", 0), 0 if resident else skew_k)
+    n_launch = steps if resident else n_step * steps
     us_per_launch = dev_ms * 1e3 / n_launch
     sub_per_launch = nsub_total / n_launch
     cells_rank = nt_all / world
@@ -690,9 +713,12 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
     kname = ("k_evp_resident (all ndte subcycles in one launch: stresses, metrics, forcing resident in registers / LDS; "
              "tile-edge velocities through agent-scope stores, progress words and agent-scope loads)" if resident else
+             f"k_subcycle_skew ({skew_k} subcycles per sweep: a pipeline of {skew_k} time levels, rows handed on through LDS; "
+             f"stress + stepu + on-rank halo per level)" if skew_k else
              "k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
              else "k_subcycle (fused stress + stepu + on-rank halo)")
     ksub = (f"k_evp_resident<{rw}, false>" if resident else
+            f"k_subcycle_skew<{skew_k}, false>" if skew_k else
             f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
             else f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>")
     traffic, traffic_src = pmc_traffic(wl, ksub) if world == 1 else (None, None)

@@ -58,14 +58,22 @@ template <class T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  bool owned = true;   // false: a view into another buffer's allocation
   DevBuf() = default;
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
   ~DevBuf() { release(); }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && owned) (void)hipFree(p);
     p = nullptr;
     n = 0;
+    owned = true;
+  }
+  void view(T* ptr, size_t count) {   // alloc(count) afterwards is a no-op
+    release();
+    p = ptr;
+    n = count;
+    owned = false;
   }
   void alloc(size_t count) {
     if (count == n && p) return;

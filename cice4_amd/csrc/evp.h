@@ -39,6 +39,11 @@ class Evp {
   bool can_reside() const;   // the whole subcycle loop in one launch, state in registers (k_evp_resident)
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
+  bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
+  int skew_levels() const;   // its K
+  int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
+  int skew_blocks(int K) const;    // workgroups per CU it is built for
+  int skew_waves_per_simd(int K) const;
   bool can_fuse() const;     // two subcycles per launch on this domain
   int fused_waves() const;   // wavefronts per workgroup of the fused kernel
 
@@ -63,6 +68,10 @@ class Evp {
   bool use_graph = true;
   bool comm_graph = false;   // multi-rank loops: capture the RCCL calls too (opt-in)
   bool fuse_on = true;
+  bool skew_on = true;       // K subcycles per sweep where the domain allows and the grid is large enough
+  int skew_blocks_opt = 0;
+  int skew_k_opt = 0, skew_seg_opt = 0;   // forced K / rows per workgroup (tests, tuning), 0 = auto
+  long long skew_min_cells = 1000000;     // smaller grids keep k_subcycle2 (or the resident loop)
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
   mutable int waves2_auto = 0;  // the automatic choice, once made
   // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
@@ -87,6 +96,7 @@ class Evp {
   DevBuf<double> dxt, dyt, dxhy, dyhx, cxp, cyp, cxm, cym, tarea, uarea, tarear, uarear, tinyarea,
       fcor, HTN, HTE;
   DevBuf<int32_t> tmask, umask, blk;  // blk: ilo,ihi,jlo,jhi per block
+  DevBuf<double> uarena;   // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear live here (views below)
   // in
   DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,
       ss_tlty;
@@ -110,6 +120,7 @@ class Evp {
 
   void launch_subcycle(int ksub);
   void launch_subcycle_pair(int ksub);
+  void launch_subcycle_skew(int ksub, int K);
   void launch_range(int ksub0, int nsub);
   void after_subcycle(int ksub);
   SubArgs make_args() const;

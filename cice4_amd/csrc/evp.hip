@@ -767,6 +767,288 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
   }
 }
 
+// ---- K EVP subcycles in one sweep: time-skewed streaming (grids that do not fit the chip) ------------------------
+//
+// k_subcycle2 sends sigma, u, v and the inputs across HBM once per PAIR of subcycles and pays a redundant rim of
+// 1.34 x for it ((16 x 64) / (13 x 59)); at 0.1 degree its memory phase and its arithmetic add up.
+// Here a workgroup is a PIPELINE OF K TIME LEVELS, one wavefront per level, that sweeps a strip of 64 columns upward
+// row by row, once: wavefront k turns state k into state k+1.  It marches like k_subcycle -- per step the stresses of
+// one T-row, then the momentum equation of the U-row below it, `str` of the previous row carried in registers, the
+// eastern neighbour by wave shift -- but only level 0 reads sigma, u, v from memory and only level K-1 writes them;
+// in between a row travels from level k to level k+1 through LDS (12 + 2 doubles per lane, two slots each).
+// Level k+1 needs u_k of rows r and r-1 for T-row r, and u_k(r) exists once level k has finished T-row r+1: the
+// levels run TWO ROWS apart, one workgroup barrier per step.  HBM sees sigma, u, v once per K subcycles; there is no
+// redundant row (only 2(K-1) steps to fill the pipeline and K rim rows at the ends of a row segment) and K+1 / K
+// redundant columns at the west / east end of the 64 lanes (each level loses one lane per side; the ring's (G, ilo)
+// pair costs one more, as in k_subcycle2): a strip owns 63 - 2K columns.  Loads run one step ahead of their use
+// (level 0: from memory; the others: the stresses from LDS), so a wavefront's memory latency overlaps its own
+// arithmetic, and the three workgroups of a CU drift apart by themselves.  The read-only inputs (HTN, HTE, strength,
+// the eight momentum inputs: 88 B per cell) are fetched by every level, two steps after the level before it: L2 /
+// Infinity-Cache hits.
+// Same arithmetic, same order, same bits as k_subcycle; columns walk the block as a ring exactly as in k_subcycle2.
+// Used where k_subcycle2 can be used (can_fuse) and the metrics derive from HTN / HTE.
+struct SkewArgs {
+  SubArgs a;               // only what the kernel names is fetched from the argument block
+  const double* st_in;     // u, v, 12 stresses of the current state: 14 planes of a.n doubles
+  double* st_out;          // the other copy
+  const double* uar;       // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear: 8 planes of a.n doubles
+  int seg_rows;            // U-rows a workgroup owns
+};
+
+// WS: wavefronts per SIMD the kernel is built for (bounds the registers)
+//
+// Addressing: every array of the launch is (one uniform base) + (one 32-bit byte offset per lane); the 14 planes of
+// the state and the 8 planes of the momentum inputs are reached by adding plane * n * 8 to the lane offset
+// (Evp::can_skew checks that 14 planes stay below 4 GB), so the kernel holds a handful of base pointers, not forty.
+template <int K, bool LAST, bool DAMP, int WS>
+__global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa) {
+  const SubArgs& a = sa.a;
+  constexpr int OWN0 = K + 1, OWNL = 62 - 2 * K;   // lanes OWN0 .. OWN0+OWNL-1 own their column
+  __shared__ double s_sig[K - 1][2][12][TX];
+  __shared__ double s_uv[K - 1][2][2][TX];
+  const int per_blk = a.tiles_x * a.tiles_y;
+  const int nt = per_blk * a.nblocks;
+  const int chunk = (nt + 7) >> 3;
+  const int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (tile_lin >= nt) return;  // whole workgroup
+  const int b = tile_lin / per_blk;
+  const int rem = tile_lin - b * per_blk;
+  const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
+  const int ilo = a.blk[6 * b + 0], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
+  const int lx = threadIdx.x & 63;
+  // time level of this wavefront (uniform); dealt differently from workgroup to workgroup, so that the wavefronts
+  // a SIMD holds are at different levels (level 0 waits for memory, level K-1 stores)
+  const int k = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + tile_lin) % K;
+  const int nx = a.nx;
+  const unsigned n8 = (unsigned)(a.n * 8);                  // bytes between two planes
+  const size_t base = (size_t)b * nx * a.ny;
+  const double* const u_in = sa.st_in + base;               // block planes: u, v at +n, stress c at +(2+c) n
+  double* const s_out = sa.st_out + base;
+  const double* const uar = sa.uar + base;
+  const double* const htn = a.HTN + base;
+  const double* const hte = a.HTE + base;
+  const double* const stren = a.strength + base;
+  const int32_t* const tmk = a.icetmask + base;
+  const int32_t* const umk = a.iceumask + base;
+  const bool cyc = a.ew_cyclic != 0;
+  // column: ring position (0 = ilo, ncol = G) -> memory column, as in k_subcycle2
+  const int ncol = ihi - ilo + 1;
+  const int kraw = txi * OWNL + lx - OWN0;
+  int col = -1;
+  if (cyc) {
+    int kk = kraw % (ncol + 1);
+    if (kk < 0) kk += ncol + 1;
+    col = ilo + kk;
+  } else if (kraw >= -1 && kraw <= ncol) {
+    col = ilo + kraw;
+  }
+  const bool col_ok = col >= 1;
+  const bool isG = cyc && col == ihi + 1;
+  const bool at_ilo = cyc && col == ilo;
+  const bool own_col = lx >= OWN0 && lx < OWN0 + OWNL && kraw >= 0 && kraw <= ncol;
+  const bool tcol = col_ok && col >= ilo;                 // (col <= ihi + 1 holds)
+  const bool ucol = col_ok && col >= ilo && col <= ihi;
+  const unsigned co = (unsigned)(col_ok ? col - 1 : 0) * 8u;
+  const unsigned nx8 = (unsigned)nx * 8u;
+  const bool has_ilo = __any(at_ilo), has_G = __any(isG);   // most strips hold neither end of the ring
+  // rows: this workgroup owns U-rows ja..jb (and T-rows ja..jb, the last segment T-row jhi+1 as well); every level
+  // walks T-rows jt0..jt1, level k two rows behind level k-1
+  const int ja = jlo + tyi * sa.seg_rows, jb = min(ja + sa.seg_rows - 1, jhi);
+  const int jt0 = max(jlo, ja - (K - 1)), jt1 = min(jhi + 1, jb + K);
+  const int nsteps = (jt1 - jt0 + 1) + 2 * (K - 1);
+  const bool lastlev = k == K - 1;
+
+  // row below the first T-row: unchanged during the sweep where it matters (a ghost row), harmless elsewhere
+  double us = c0, vs = c0, usw = c0, vsw = c0, hn_s = c0;
+  if (col_ok) {
+    const unsigned q = (unsigned)(jt0 - 2) * nx8 + co;
+    us = ld8(u_in, q);
+    vs = ld8(u_in, q + n8);
+    hn_s = ld8(htn, q);
+    if (col >= 2) {
+      usw = ld8(u_in, q - 8u);
+      vsw = ld8(u_in, q + n8 - 8u);
+    }
+  }
+  double p0 = c0, pe1 = c0, p4 = c0, pe6 = c0;   // str of the previous T-row: (i,j,1) (i+1,j,2) (i,j,5) (i+1,j,7)
+  // what the NEXT step works on, fetched one step ahead (the stresses are not: they are wanted halfway through
+  // `stress` only, level 0 fetches them at the top of the step itself and the others find them in LDS)
+  double nun = c0, nvn = c0, nhn = c0, nhe = c0, nhew = c0, nst = c0;
+  int ntm = 0, num = 0, um_prev = 0;   // icetmask / iceumask of the next row (as loaded); iceumask of the row below
+  double s[12];                        // stresses of this step's row; handed on at the top of the NEXT step
+#pragma unroll
+  for (int c = 0; c < 12; ++c) s[c] = c0;
+
+#pragma clang loop unroll(disable)
+  for (int t = -1; t < nsteps; ++t) {
+    const int r = jt0 + t - 2 * k;                 // T-row of this step (uniform)
+    const bool act = r >= jt0 && r <= jt1;
+    const unsigned q = (unsigned)(r - 1) * nx8 + co;   // T-cell (col, r); the U-cell of this step is (col, r-1) = q - nx8
+    const bool urow = act && r > jt0;                  // (jlo <= r-1 <= jhi holds then)
+    // ---- the stresses of the previous row go to the next level now, not when they were formed: the slot they go
+    // into was read by that level during the previous step (two slots, one barrier per step)
+    if (!lastlev && r - 1 >= jt0 && r - 1 <= jt1) {
+#pragma unroll
+      for (int c = 0; c < 12; ++c) s_sig[k][(r - 1) & 1][c][lx] = s[c];
+    }
+    // ---- take over what was fetched for this row.  The empty asm is a use of those registers placed BEFORE this
+    // step's loads are issued: the wait for them that the compiler needs (it cannot count loads across the back edge
+    // and waits for everything) then falls here, where only loads of the previous step are in flight
+    asm volatile("" : "+v"(nun), "+v"(nvn), "+v"(nhn), "+v"(nhe), "+v"(nhew), "+v"(nst), "+v"(ntm), "+v"(num));
+    double un = nun, vn = nvn;
+    const double hn = nhn, he = nhe, St = nst;
+    double hew = nhew;
+    const int tm_cur = ntm, um_cur = num;
+    // ---- loads, oldest first: the momentum inputs of the U-row below (read-only: L2 hits for the levels behind
+    // level 0; fetched whatever the mask says so that they do not wait for it) ...
+    double xa, xuo, xvo, xfx, xfy, xum, xfm, xur;
+    if (urow && ucol) {
+      const unsigned qu = q - nx8;
+      xa = ld8(uar, qu); xuo = ld8(uar, qu + n8); xvo = ld8(uar, qu + 2u * n8); xfx = ld8(uar, qu + 3u * n8);
+      xfy = ld8(uar, qu + 4u * n8); xum = ld8(uar, qu + 5u * n8); xfm = ld8(uar, qu + 6u * n8);
+      xur = ld8(uar, qu + 7u * n8);
+    }
+    // ... what the next step starts with (straight-line code: a row index clamped into the sweep instead of a branch,
+    // so that the number of loads in flight is the same on every path) ...
+    {
+      const int rn = min(max(r + 1, jt0), jt1);
+      const unsigned qn = (unsigned)(rn - 1) * nx8 + co;
+      if (k == 0) {
+        nun = ld8(u_in, qn);
+        nvn = ld8(u_in, qn + n8);
+      }
+      nhn = ld8(htn, qn);
+      nhe = ld8(hte, qn);
+      nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));   // only the lane at ilo uses it
+      nst = ld8(stren, qn);
+      ntm = ld4(tmk, qn >> 1);
+      num = ld4(umk, qn >> 1);
+    }
+    // ... and, youngest, the stresses of this row: whoever waits for them waits for everything, which has arrived by then
+    if (act) {
+      if (k == 0) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s[c] = ld8(u_in, q + (unsigned)(2 + c) * n8);
+      } else {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s[c] = s_sig[k - 1][r & 1][c][lx];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (act) {
+      const bool tact = tcol && tm_cur == 1;
+      // the rows of the level below (a ghost row never changes: it is read where it lives)
+      if (k > 0) {
+        if (r > jhi) {
+          if (col_ok) {
+            un = ld8(u_in, q);
+            vn = ld8(u_in, q + n8);
+          }
+        } else {
+          un = s_uv[k - 1][r & 1][0][lx];
+          vn = s_uv[k - 1][r & 1][1][lx];
+        }
+      }
+      double uw, vw;
+      {
+        // wave shifts are taken by every lane, the choice between them is per lane.  West of ilo sits G in the ring:
+        // ilo's western neighbour ihi is two lanes away where the ghost columns mirror (rows jlo..jhi, every
+        // level: the ghost columns of the state a launch starts from are current); on a ghost row it is the ghost
+        // column's own, unchanged value
+        uw = up1(un);
+        vw = up1(vn);
+        if (has_ilo) {
+          const double uw2 = up1(uw), vw2 = up1(vw);
+          if (r >= jlo && r <= jhi) {
+            if (at_ilo) {
+              uw = uw2;
+              vw = vw2;
+            }
+          } else if (at_ilo) {
+            uw = ld8(u_in, q - 8u);
+            vw = ld8(u_in, q + n8 - 8u);
+          }
+        }
+      }
+      {
+        const double hs = up1(he);
+        if (!at_ilo) hew = hs;
+      }
+      const bool uact = urow && ucol && um_prev != 0;
+      // ---- stress (ice_dyn_evp.F90:1065-1289)
+      StressOut o;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) o.str[c] = c0;
+      if (tact) {
+        const double Dxt = p5 * (hn + hn_s);                 // ice_grid.F90:1184 (dxt)
+        const double Dyt = p5 * (he + hew);                  // :1271 (dyt)
+        const double Dxhy = p5 * (he - hew);                 // :347
+        const double Dyhx = p5 * (hn - hn_s);                // :348
+        const double Cyp = 1.5 * he - p5 * hew;              // :354
+        const double Cxp = 1.5 * hn - p5 * hn_s;             // :355
+        const double Cym = -(1.5 * hew - p5 * he);           // :357
+        const double Cxm = -(1.5 * hn_s - p5 * hn);          // :358
+        const double Tiny = puny * (Dxt * Dyt);              // :334, :346
+        const bool diag = LAST && lastlev;
+        stress_cell<LAST, DAMP>(a.sc, un, uw, usw, us, vn, vw, vsw, vs, Dxt, Dyt, Dxhy, Dyhx, Cxp, Cyp, Cxm, Cym,
+                                diag ? ld8(a.tarear + base, q) : c0, Tiny, St, s, o, diag);
+        const bool own_t = own_col && ((r >= ja && r <= jb) || (r == jhi + 1 && jb == jhi));
+        if (lastlev && own_t) {
+#pragma unroll
+          for (int c = 0; c < 12; ++c) st8(s_out, q + (unsigned)(2 + c) * n8, s[c]);
+          if (LAST) {
+            st8(a.divu + base, q, o.divu);
+            st8(a.rdg_conv + base, q, o.rdg_conv);
+            st8(a.rdg_shear + base, q, o.rdg_shear);
+            st8(a.shear + base, q, o.shear);
+            st8(a.prs_sig + base, q, o.prs_sig);
+          }
+        }
+      }
+      // ---- momentum of U-row r-1 (:1390-1435): str of (i,j) carried, of (i+1, .) by wave shift
+      const double e1 = down1(o.str[1]), e3 = down1(o.str[3]), e6 = down1(o.str[6]), e7 = down1(o.str[7]);
+      double u1 = us, v1 = vs;   // velocity of row r-1 after this level
+      if (uact) {
+        const double sx = p0 + pe1 + o.str[2] + e3;      // :1415-1416 order
+        const double sy = p4 + o.str[5] + pe6 + e7;      // :1417-1418 order
+        const int ru = r - 1;
+        UIn x;
+        x.aiu = xa; x.uocn = xuo; x.vocn = xvo; x.forcex = xfx; x.forcey = xfy; x.umassdtei = xum; x.fm = xfm;
+        x.uarear = xur;
+        x.waterx = xuo * cosw - xvo * sinw;   // evp_prep2's own expressions (ice_dyn_evp.F90:915-916)
+        x.watery = xvo * cosw + xuo * sinw;
+        if (lastlev) {
+          if (own_col && ru >= ja && ru <= jb)
+            stepu_store_o<LAST>(a, x, base, q - nx8, col, ru, ilo, ihi, jlo, jhi, us, vs, sx, sy);
+        } else {
+          StepuOut ro;
+          stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
+                     x.uarear, sx, sy, ro);
+          u1 = ro.u;
+          v1 = ro.v;
+        }
+      }
+      if (!lastlev && urow) {
+        // the east ghost column G mirrors column ilo = the next lane (rows whose velocity is updated, :397-402)
+        if (has_G) {
+          const double gu = down1(u1), gv = down1(v1);
+          if (isG) {
+            u1 = gu;
+            v1 = gv;
+          }
+        }
+        s_uv[k][(r - 1) & 1][0][lx] = u1;
+        s_uv[k][(r - 1) & 1][1][lx] = v1;
+      }
+      p0 = o.str[0]; pe1 = e1; p4 = o.str[4]; pe6 = e6;
+      us = un; vs = vn; usw = uw; vsw = vw;
+      hn_s = hn;
+      um_prev = um_cur;
+    }
+    __syncthreads();
+  }
+}
+
 // ---- list-driven, unfused forms with the reference's argument lists (tests) --------------
 // ---- the WHOLE subcycle loop in one launch, state resident in registers (grids of at most one tile per CU) --------
 //
@@ -1415,6 +1697,21 @@ void Evp::set_option(const char* key, int value) {
     CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
                  "resident_waves must be 0, 4, 6, 8, 11 or 12");
     res_w_opt = value;
+  } else if (!std::strcmp(key, "skew")) {          // K subcycles per sweep (k_subcycle_skew) where the domain allows
+    skew_on = value != 0;
+  } else if (!std::strcmp(key, "skew_levels")) {   // 0 = auto
+    CICE_REQUIRE(value == 0 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 8,
+                 "skew_levels must be 0, 2, 3, 4, 5, 6 or 8");
+    skew_k_opt = value;
+  } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
+    CICE_REQUIRE(value >= 0, "skew_blocks must be >= 0");
+    skew_blocks_opt = value;
+  } else if (!std::strcmp(key, "skew_seg_rows")) { // 0 = auto: rows a workgroup owns
+    CICE_REQUIRE(value >= 0, "skew_seg_rows must be >= 0");
+    skew_seg_opt = value;
+  } else if (!std::strcmp(key, "skew_min_cells")) { // grids below this size keep k_subcycle2
+    CICE_REQUIRE(value >= 0, "skew_min_cells must be >= 0");
+    skew_min_cells = value;
   } else if (!std::strcmp(key, "fused_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 8 || value == 12 || value == 13 || value == 14 || value == 16,
                  "fused_waves must be 0, 8, 12, 13, 14 or 16");
@@ -1439,6 +1736,12 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   }
   blk.alloc(hb.size());
   blk.upload(hb.data(), stream);
+  // the eight read-only inputs of the momentum equation share one allocation (k_subcycle_skew: one base pointer)
+  uarena.alloc(8 * n);
+  {
+    DevBuf<double>* us8[8] = {&aiu, &uocn, &vocn, &forcex, &forcey, &umassdtei, &fm, &uarear};
+    for (int k = 0; k < 8; ++k) us8[k]->view(uarena.p + (size_t)k * n, n);
+  }
   struct G { DevBuf<double>* d; const double* h; };
   G gs[] = {{&dxt, g.dxt}, {&dyt, g.dyt}, {&dxhy, g.dxhy}, {&dyhx, g.dyhx}, {&cxp, g.cxp},
             {&cyp, g.cyp}, {&cxm, g.cxm}, {&cym, g.cym}, {&tarea, g.tarea}, {&uarea, g.uarea},
@@ -1791,6 +2094,89 @@ void Evp::launch_subcycle_pair(int ksub) {
   after_subcycle(ksub + 1);
 }
 
+// ---- K subcycles per sweep (k_subcycle_skew) ---------------------------------------------------------------------
+// Where two subcycles per launch are possible, K are: the same condition (no ghost row of a local block changes
+// during the launch) over K subcycles; and the metrics have to derive from HTN / HTE (the kernel has no other form).
+// Small grids keep k_subcycle2 / the resident loop: a sweep needs rows to amortise its 2(K-1) + 2K - 1 extra steps.
+bool Evp::can_skew() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW"); return e && e[0] == '0'; }();
+  if (!skew_on || env_off || !can_fuse() || !(derive_ok && derive_on)) return false;
+  if (n * 8 * 14 >= (1ull << 32)) return false;   // the kernel reaches the 14 planes of the state by 32-bit offsets
+  const long long cells = (long long)dom.nblocks() * (dom.nx_block - 2) * (dom.ny_block - 2);
+  return cells >= skew_min_cells;
+}
+
+int Evp::skew_levels() const { return skew_k_opt ? skew_k_opt : 4; }
+
+// wavefronts per SIMD the kernel is built for (registers), and the workgroups per CU that follow from it and from
+// the LDS a workgroup takes ((K-1) x 14 KB of 160 KB)
+int Evp::skew_waves_per_simd(int K) const {
+  if (K == 4 && skew_blocks_opt == 2) return 2;
+  return K <= 6 ? 3 : 2;
+}
+int Evp::skew_blocks(int K) const {
+  const int by_regs = skew_waves_per_simd(K) * 4 / K;
+  const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * 14336) : 16;
+  return std::max(1, std::min(by_regs, by_lds));
+}
+
+// rows a workgroup owns: as many workgroups as the chip holds at once (one round), segments not shorter than 4K rows
+int Evp::skew_seg_rows(int K) const {
+  const int rows = dom.ny_block - 2;
+  if (skew_seg_opt) return std::min(skew_seg_opt, rows);
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  const int ownl = 62 - 2 * K;
+  const long long strips = (long long)(((dom.nx_block - 2) + 1 + ownl - 1) / ownl) * dom.nblocks();
+  long long nseg = (long long)ncu * skew_blocks(K) / std::max(1LL, strips);
+  nseg = std::max(1LL, std::min(nseg, (long long)std::max(1, rows / (4 * K))));
+  return (int)((rows + nseg - 1) / nseg);
+}
+
+template <int K, int WS>
+static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s) {
+  const dim3 blk(64 * K);
+  if (last) {
+    if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, true, true, WS>), g, blk, 0, s, sa);
+    else hipLaunchKernelGGL((k_subcycle_skew<K, true, false, WS>), g, blk, 0, s, sa);
+  } else {
+    if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, false, true, WS>), g, blk, 0, s, sa);
+    else hipLaunchKernelGGL((k_subcycle_skew<K, false, false, WS>), g, blk, 0, s, sa);
+  }
+}
+
+// subcycles ksub .. ksub+K-1
+void Evp::launch_subcycle_skew(int ksub, int K) {
+  SkewArgs sa{};
+  sa.a = make_args();
+  const int ownl = 62 - 2 * K;
+  sa.seg_rows = skew_seg_rows(K);
+  sa.a.tiles_x = ((dom.nx_block - 2) + 1 + ownl - 1) / ownl;
+  sa.a.tiles_y = ((dom.ny_block - 2) + sa.seg_rows - 1) / sa.seg_rows;
+  sa.st_in = st[cur].p;
+  sa.st_out = st[1 - cur].p;
+  sa.uar = uarena.p;
+  const bool last = ksub + K - 1 == sc.ndte;
+  const int nt = sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks;
+  const dim3 g(8 * ((nt + 7) / 8));
+  const bool damp = sc.evp_damping != 0;
+  const int WS = skew_waves_per_simd(K);
+  switch (K * 10 + WS) {
+    case 23: launch_skew_kb<2, 3>(sa, last, damp, g, stream); break;
+    case 33: launch_skew_kb<3, 3>(sa, last, damp, g, stream); break;
+    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, stream); break;
+    case 42: launch_skew_kb<4, 2>(sa, last, damp, g, stream); break;
+    case 53: launch_skew_kb<5, 3>(sa, last, damp, g, stream); break;
+    case 63: launch_skew_kb<6, 3>(sa, last, damp, g, stream); break;
+    case 82: launch_skew_kb<8, 2>(sa, last, damp, g, stream); break;
+    default: throw Error{CICE_EINVAL, "unsupported (skew_levels, skew_blocks) combination"};
+  }
+  after_subcycle(ksub + K - 1);
+}
+
 // ---- resident loop ------------------------------------------------------------------------------------------------
 // One block on this rank, nothing to exchange with other ranks or across a tripole fold during the subcycling, on-rank
 // ghosts served by forwarding, and at most one tile per CU (the hand-off form used is the one measured for one
@@ -1958,15 +2344,26 @@ bool Evp::run_resident(int ksub0, int nsub) {
   return true;
 }
 
-// subcycles ksub0 .. ksub0+nsub-1: pairs where possible
+// subcycles ksub0 .. ksub0+nsub-1: K per sweep where possible, else pairs, else one by one
 void Evp::launch_range(int ksub0, int nsub) {
   const bool fuse = can_fuse();
+  const bool skew = can_skew();
+  const int K = skew_levels();
   const int end = ksub0 + nsub - 1;
   for (int k = ksub0; k <= end;) {
-    // a wide-halo refresh falls after subcycles that are multiples of `overlap` (even): a pair must
-    // not straddle one, i.e. it has to start on an odd subcycle
-    const bool pair = fuse && k + 1 <= end && !(dom.overlap > 0 && k % dom.overlap == 0);
-    if (pair) {
+    // a wide-halo refresh falls after subcycles that are multiples of `overlap`: a launch must not straddle one,
+    // i.e. none of its subcycles but the last may be such a multiple
+    auto clear = [&](int len) {
+      if (k + len - 1 > end) return false;
+      if (dom.overlap > 0)
+        for (int q = k; q < k + len - 1; ++q)
+          if (q % dom.overlap == 0) return false;
+      return true;
+    };
+    if (skew && clear(K)) {
+      launch_subcycle_skew(k, K);
+      k += K;
+    } else if (fuse && clear(2)) {
       launch_subcycle_pair(k);
       k += 2;
     } else {
@@ -1996,8 +2393,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   if (nsub >= 2 && can_reside()) replayed = run_resident(ksub0, nsub);
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
-                        (((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 64 +
-                            (halo.generation() & 63)};
+                        ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +
+                         (can_skew() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();

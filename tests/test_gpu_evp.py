@@ -555,6 +555,44 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
                 assert np.array_equal(got[k], ref[k]), (ndte, damping, opts, k)
 
 
+@pytest.mark.parametrize("nxg,nyg,ew", [(96, 70, 1), (20, 33, 1), (53, 18, 1), (54, 18, 1), (55, 18, 1), (107, 9, 1),
+                                         (109, 41, 1), (119, 5, 1), (200, 50, 1), (96, 70, 0), (130, 27, 2), (7, 6, 1),
+                                         (300, 120, 1)])
+def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
+    """k_subcycle_skew (K subcycles in one sweep: a pipeline of K time levels, one wavefront each, two rows apart,
+    rows handed from level to level through LDS) against one launch per subcycle and the checker: bit for bit.
+    Every K; widths around the strip strides (62 - 2K columns), blocks narrower than a strip (the ring wraps inside
+    one wavefront), open / closed E-W edges; row segments of 1 .. many rows (interior segment ends: K rim rows) and
+    the automatic choice; subcycle counts that are no multiple of K (the rest runs as pairs / single launches);
+    damping; graph replay and eager."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
+    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    big = nxg * nyg > 20000
+    for ndte, damping in (((NDTE, False),) if big else ((NDTE, False), (7, True), (13, False))):
+        ref, _ = _evp_with(ctx, grid, s, ndte, damping, fuse=0, resident=0, skew=0)
+        if (ndte, damping) == (NDTE, False):
+            orc.set_evp_parameters(DT, ndte, damping); orc.set_strength_parameters(1, 0, 0, 4.0)
+            so = {k: v.copy() for k, v in s.items()}
+            orc.evp(orc.make_domain(dom, grid), so)
+            orc.set_strength_parameters()
+            for k in keys:
+                assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
+        for K, seg, graph in ((4, 0, 1), (2, 0, 1), (3, 5, 1), (4, 1, 1), (4, 7, 0), (5, 3, 1), (6, 11, 1), (8, 4, 1),
+                              (8, 0, 1)):
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+            for key, v in (("resident", 0), ("skew", 1), ("skew_min_cells", 0), ("skew_levels", K),
+                           ("skew_seg_rows", seg), ("use_graph", graph)):
+                ctx.evp_set_option(key, v)
+            assert ctx.evp_get_info("skew") == 1 and ctx.evp_get_info("skew_levels") == K
+            ctx.evp(DT, sg)
+            for k in keys:
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, k)
+
+
 @pytest.mark.parametrize("nxg,nyg,ew,ns", [(96, 70, 1, 0), (20, 33, 1, 0), (62, 18, 1, 0), (63, 18, 1, 0), (64, 18, 1, 0),
                                             (125, 9, 1, 0), (126, 41, 1, 0), (127, 5, 1, 0), (200, 50, 1, 0),
                                             (96, 70, 0, 0), (130, 27, 2, 2), (7, 6, 1, 0), (96, 40, 1, 1), (320, 384, 1, 0),
