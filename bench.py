@@ -89,6 +89,9 @@ def parse():
     p.add_argument("--no-skew", action="store_true", help="no K-subcycle sweeps (k_subcycle_skew) on large grids")
     p.add_argument("--skew-levels", type=int, default=0, help="K of k_subcycle_skew (2, 3, 4, 5, 6, 8); 0 = library's choice")
     p.add_argument("--skew-seg-rows", type=int, default=0, help="rows a workgroup of k_subcycle_skew owns; 0 = auto")
+    p.add_argument("--skew-gen-pct", type=int, default=-1, help="longer row segments for the workgroups dispatched first; -1 = library's choice")
+    p.add_argument("--skew-prio", type=int, default=-1, help="rotate issue priorities among workgroups of a CU; -1 = library's choice")
+    p.add_argument("--skew-stagger-ns", type=int, default=-1, help="start delay between workgroups sharing a CU; -1 = library's choice")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -630,6 +633,12 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         ctx.evp_set_option("skew_levels", args.skew_levels)
     if args.skew_seg_rows:
         ctx.evp_set_option("skew_seg_rows", args.skew_seg_rows)
+    if args.skew_gen_pct >= 0:
+        ctx.evp_set_option("skew_gen_pct", args.skew_gen_pct)
+    if args.skew_prio >= 0:
+        ctx.evp_set_option("skew_prio", args.skew_prio)
+    if args.skew_stagger_ns >= 0:
+        ctx.evp_set_option("skew_stagger_ns", args.skew_stagger_ns)
     skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") else 0
     if skew_k:
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "

@@ -751,6 +751,13 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
   CICE_CATCH
 }
+int cice_evp_debug(cice_ctx* ctx, const char* what, long long* out, long long* count) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(what && count, "NULL argument");
+  *count = c_->evp->debug_read(what, out, *count);
+  CICE_CATCH
+}
 int cice_evp_active_cells(cice_ctx* ctx, long long* nt, long long* nu) {
   CICE_TRY(ctx) NEED_EVP; c_->evp->active_cells(nt, nu); CICE_CATCH
 }

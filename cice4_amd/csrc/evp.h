@@ -33,6 +33,7 @@ class Evp {
   }
   void set_option(const char* key, int value);
   void active_cells(long long* nt, long long* nu);
+  long long debug_read(const char* what, long long* out, long long cap);
   bool derives_metrics() const;
   int tile_waves() const { return waves; }
   int tile_rows() const { return rows_per_wave; }
@@ -70,6 +71,15 @@ class Evp {
   bool fuse_on = true;
   bool skew_on = true;       // K subcycles per sweep where the domain allows and the grid is large enough
   int skew_blocks_opt = 0;
+  bool fwd_is_ew_wrap = false;   // the on-rank ghost list is the east-west wrap of full-width blocks and nothing else
+  int skew_gen_pct = 0;          // see build_skew_rows
+  DevBuf<int32_t> skew_rows;
+  int skew_rows_key[5] = {0, 0, 0, 0, 0};
+  void build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_rows);
+  int skew_prio = 1;             // rotate the issue priority among the workgroups sharing a CU
+  bool skew_debug = false;
+  DevBuf<long long> skew_dbg;
+  int skew_stagger_ns = 0;   // start delay per workgroup sharing a CU (k_subcycle_skew), 0 = none
   int skew_k_opt = 0, skew_seg_opt = 0;   // forced K / rows per workgroup (tests, tuning), 0 = auto
   long long skew_min_cells = 1000000;     // smaller grids keep k_subcycle2 (or the resident loop)
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto

@@ -229,6 +229,28 @@ __device__ __forceinline__ double down1(double x) {
   return __hiloint2double(hi, lo);
 }
 
+#ifndef SKEW_FAKE_SIGMA_LOAD
+#define SKEW_FAKE_SIGMA_LOAD 0
+#endif
+#ifndef SKEW_OPAQUE_STRIDE
+#define SKEW_OPAQUE_STRIDE 1
+#endif
+// The same shifts with bound_ctrl: the lane without a source (lane 0 / lane 63) reads zero instead of keeping its own
+// value, which frees the compiler from copying the operand first (one instruction per half instead of two).  For
+// kernels in which that lane's result is never used (k_subcycle_skew: lanes 0 and 63 own nothing).
+__device__ __forceinline__ double up1z(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);  // wave_shr:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double down1z(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);  // wave_shl:1
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 constexpr int TX = 64;  // T-cells per tile row = one wavefront
 
 // Momentum update of one U-cell inside the fused kernel + forwarding of the new velocity to
@@ -792,7 +814,13 @@ struct SkewArgs {
   const double* st_in;     // u, v, 12 stresses of the current state: 14 planes of a.n doubles
   double* st_out;          // the other copy
   const double* uar;       // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear: 8 planes of a.n doubles
-  int seg_rows;            // U-rows a workgroup owns
+  int seg_rows;            // U-rows a workgroup owns (when there is no table)
+  const int32_t* rows;     // [tiles][2]: first and last U-row (relative to jlo) a workgroup owns, or NULL
+  int stagger_ticks;       // start delay per workgroup "generation", in 10 ns ticks (see the kernel)
+  int stagger_mod;         // generations
+  int prio_rotate;         // rotate the issue priority among the workgroups sharing a CU (see the kernel)
+  int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
+  long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
 };
 
 // WS: wavefronts per SIMD the kernel is built for (bounds the registers)
@@ -853,7 +881,11 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const bool has_ilo = __any(at_ilo), has_G = __any(isG);   // most strips hold neither end of the ring
   // rows: this workgroup owns U-rows ja..jb (and T-rows ja..jb, the last segment T-row jhi+1 as well); every level
   // walks T-rows jt0..jt1, level k two rows behind level k-1
-  const int ja = jlo + tyi * sa.seg_rows, jb = min(ja + sa.seg_rows - 1, jhi);
+  int ja = jlo + tyi * sa.seg_rows, jb = min(ja + sa.seg_rows - 1, jhi);
+  if (sa.rows) {   // segments of unequal length (Evp::build_skew_rows): per tile of a block
+    ja = jlo + sa.rows[2 * rem];
+    jb = jlo + sa.rows[2 * rem + 1];
+  }
   const int jt0 = max(jlo, ja - (K - 1)), jt1 = min(jhi + 1, jb + K);
   const int nsteps = (jt1 - jt0 + 1) + 2 * (K - 1);
   const bool lastlev = k == K - 1;
@@ -879,8 +911,29 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
 #pragma unroll
   for (int c = 0; c < 12; ++c) s[c] = c0;
 
+  // The workgroups a CU holds are copies of one program started at the same moment: left alone they stay IN PHASE --
+  // all compute together (sharing the SIMDs), then all wait together (barrier, LDS, memory) -- and the waiting of one
+  // hides behind nothing.  Workgroups are dealt to the CUs of an XCD in turn, so consecutive ones (blockIdx / 8) that
+  // share a CU are stagger_mod apart in that count: each starts a fraction of a step later than the one before.
+  if (sa.stagger_ticks > 0) {
+    const long long wait = (long long)((blockIdx.x >> 3) % (unsigned)sa.stagger_mod) * sa.stagger_ticks;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(2);
+  }
+  if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x] = wall_clock64();
+  // generation of this workgroup: workgroups are dispatched in blockIdx order, one per CU first
+  const int gen = (int)(blockIdx.x / (gridDim.x / (unsigned)sa.stagger_mod + 1u));
 #pragma clang loop unroll(disable)
   for (int t = -1; t < nsteps; ++t) {
+    // The SIMD issues from its OLDEST ready wavefront first: of the workgroups sharing a CU the first one dispatched
+    // runs at its own pace, the last one gets what is left and finishes long after -- alone on the CU, bound by
+    // latency.  Rotating the priority from step to step lets them advance together.
+    if (sa.prio_rotate) {
+      const int p = (t + 1 + gen) % sa.stagger_mod;
+      if (p == 0) __builtin_amdgcn_s_setprio(3);
+      else if (p == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
     const int r = jt0 + t - 2 * k;                 // T-row of this step (uniform)
     const bool act = r >= jt0 && r <= jt1;
     const unsigned q = (unsigned)(r - 1) * nx8 + co;   // T-cell (col, r); the U-cell of this step is (col, r-1) = q - nx8
@@ -895,6 +948,13 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     // step's loads are issued: the wait for them that the compiler needs (it cannot count loads across the back edge
     // and waits for everything) then falls here, where only loads of the previous step are in flight
     asm volatile("" : "+v"(nun), "+v"(nvn), "+v"(nhn), "+v"(nhe), "+v"(nhew), "+v"(nst), "+v"(ntm), "+v"(num));
+    // the planes of an array are walked with a scalar pointer (base += plane stride: scalar adds, no vector
+    // arithmetic per access); the stride is made opaque once per step, or the compiler would form all the plane bases
+    // before the loop and keep them in (spilled) scalar registers
+    size_t pstride = n8;
+#if SKEW_OPAQUE_STRIDE
+    asm volatile("" : "+s"(pstride));
+#endif
     double un = nun, vn = nvn;
     const double hn = nhn, he = nhe, St = nst;
     double hew = nhew;
@@ -904,9 +964,15 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     double xa, xuo, xvo, xfx, xfy, xum, xfm, xur;
     if (urow && ucol) {
       const unsigned qu = q - nx8;
-      xa = ld8(uar, qu); xuo = ld8(uar, qu + n8); xvo = ld8(uar, qu + 2u * n8); xfx = ld8(uar, qu + 3u * n8);
-      xfy = ld8(uar, qu + 4u * n8); xum = ld8(uar, qu + 5u * n8); xfm = ld8(uar, qu + 6u * n8);
-      xur = ld8(uar, qu + 7u * n8);
+      const char* pu = (const char*)uar;
+      xa = ld8((const double*)pu, qu); pu += pstride;
+      xuo = ld8((const double*)pu, qu); pu += pstride;
+      xvo = ld8((const double*)pu, qu); pu += pstride;
+      xfx = ld8((const double*)pu, qu); pu += pstride;
+      xfy = ld8((const double*)pu, qu); pu += pstride;
+      xum = ld8((const double*)pu, qu); pu += pstride;
+      xfm = ld8((const double*)pu, qu); pu += pstride;
+      xur = ld8((const double*)pu, qu);
     }
     // ... what the next step starts with (straight-line code: a row index clamped into the sweep instead of a branch,
     // so that the number of loads in flight is the same on every path) ...
@@ -915,7 +981,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       const unsigned qn = (unsigned)(rn - 1) * nx8 + co;
       if (k == 0) {
         nun = ld8(u_in, qn);
-        nvn = ld8(u_in, qn + n8);
+        nvn = ld8((const double*)((const char*)u_in + pstride), qn);
       }
       nhn = ld8(htn, qn);
       nhe = ld8(hte, qn);
@@ -926,10 +992,21 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     }
     // ... and, youngest, the stresses of this row: whoever waits for them waits for everything, which has arrived by then
     if (act) {
+#if SKEW_FAKE_SIGMA_LOAD   // timing experiment only (wrong results): what the sweep costs if level 0 never waits for memory
       if (k == 0) {
 #pragma unroll
-        for (int c = 0; c < 12; ++c) s[c] = ld8(u_in, q + (unsigned)(2 + c) * n8);
+        for (int c = 0; c < 12; ++c) s[c] = s_sig[0][r & 1][c][lx];
       } else {
+#else
+      if (k == 0) {
+        const char* ps = (const char*)u_in + 2 * pstride;
+#pragma unroll
+        for (int c = 0; c < 12; ++c) {
+          s[c] = ld8((const double*)ps, q);
+          ps += pstride;
+        }
+      } else {
+#endif
 #pragma unroll
         for (int c = 0; c < 12; ++c) s[c] = s_sig[k - 1][r & 1][c][lx];
       }
@@ -955,10 +1032,10 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         // ilo's western neighbour ihi is two lanes away where the ghost columns mirror (rows jlo..jhi, every
         // level: the ghost columns of the state a launch starts from are current); on a ghost row it is the ghost
         // column's own, unchanged value
-        uw = up1(un);
-        vw = up1(vn);
+        uw = up1z(un);
+        vw = up1z(vn);
         if (has_ilo) {
-          const double uw2 = up1(uw), vw2 = up1(vw);
+          const double uw2 = up1z(uw), vw2 = up1z(vw);
           if (r >= jlo && r <= jhi) {
             if (at_ilo) {
               uw = uw2;
@@ -971,7 +1048,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         }
       }
       {
-        const double hs = up1(he);
+        const double hs = up1z(he);
         if (!at_ilo) hew = hs;
       }
       const bool uact = urow && ucol && um_prev != 0;
@@ -994,8 +1071,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
                                 diag ? ld8(a.tarear + base, q) : c0, Tiny, St, s, o, diag);
         const bool own_t = own_col && ((r >= ja && r <= jb) || (r == jhi + 1 && jb == jhi));
         if (lastlev && own_t) {
+          char* po = (char*)s_out + 2 * pstride;
 #pragma unroll
-          for (int c = 0; c < 12; ++c) st8(s_out, q + (unsigned)(2 + c) * n8, s[c]);
+          for (int c = 0; c < 12; ++c) {
+            st8((double*)po, q, s[c]);
+            po += pstride;
+          }
           if (LAST) {
             st8(a.divu + base, q, o.divu);
             st8(a.rdg_conv + base, q, o.rdg_conv);
@@ -1006,7 +1087,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         }
       }
       // ---- momentum of U-row r-1 (:1390-1435): str of (i,j) carried, of (i+1, .) by wave shift
-      const double e1 = down1(o.str[1]), e3 = down1(o.str[3]), e6 = down1(o.str[6]), e7 = down1(o.str[7]);
+      const double e1 = down1z(o.str[1]), e3 = down1z(o.str[3]), e6 = down1z(o.str[6]), e7 = down1z(o.str[7]);
       double u1 = us, v1 = vs;   // velocity of row r-1 after this level
       if (uact) {
         const double sx = p0 + pe1 + o.str[2] + e3;      // :1415-1416 order
@@ -1018,8 +1099,32 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         x.waterx = xuo * cosw - xvo * sinw;   // evp_prep2's own expressions (ice_dyn_evp.F90:915-916)
         x.watery = xvo * cosw + xuo * sinw;
         if (lastlev) {
-          if (own_col && ru >= ja && ru <= jb)
-            stepu_store_o<LAST>(a, x, base, q - nx8, col, ru, ilo, ihi, jlo, jhi, us, vs, sx, sy);
+          if (own_col && ru >= ja && ru <= jb) {
+            if (sa.fwd_rule) {
+              // the ghost cells that mirror this cell on this rank are known without the table: column ilo is
+              // mirrored by ihi+1, column ihi by ilo-1, same row (the table look-up costs the two strips at the ends
+              // of the ring four dependent memory round trips per row)
+              StepuOut ro;
+              stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
+                         x.uarear, sx, sy, ro);
+              const unsigned qu = q - nx8;
+              st8(s_out, qu, ro.u);
+              st8(s_out, qu + n8, ro.v);
+              if (LAST) {
+                st8(a.strintx + base, qu, ro.strintx);
+                st8(a.strinty + base, qu, ro.strinty);
+                st8(a.strocnx + base, qu, ro.taux);
+                st8(a.strocny + base, qu, ro.tauy);
+              }
+              if (cyc && (col == ilo || col == ihi)) {
+                const unsigned qg = (unsigned)(ru - 1) * nx8 + (unsigned)(col == ilo ? ihi : ilo - 2) * 8u;
+                st8(s_out, qg, ro.u);
+                st8(s_out, qg + n8, ro.v);
+              }
+            } else {
+              stepu_store_o<LAST>(a, x, base, q - nx8, col, ru, ilo, ihi, jlo, jhi, us, vs, sx, sy);
+            }
+          }
         } else {
           StepuOut ro;
           stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
@@ -1031,7 +1136,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       if (!lastlev && urow) {
         // the east ghost column G mirrors column ilo = the next lane (rows whose velocity is updated, :397-402)
         if (has_G) {
-          const double gu = down1(u1), gv = down1(v1);
+          const double gu = down1z(u1), gv = down1z(v1);
           if (isG) {
             u1 = gu;
             v1 = gv;
@@ -1047,6 +1152,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     }
     __syncthreads();
   }
+  if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x + 1] = wall_clock64();
 }
 
 // ---- list-driven, unfused forms with the reference's argument lists (tests) --------------
@@ -1703,6 +1809,16 @@ void Evp::set_option(const char* key, int value) {
     CICE_REQUIRE(value == 0 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 8,
                  "skew_levels must be 0, 2, 3, 4, 5, 6 or 8");
     skew_k_opt = value;
+  } else if (!std::strcmp(key, "skew_stagger_ns")) {   // start delay between the workgroups that share a CU
+    CICE_REQUIRE(value >= 0 && value <= 100000, "skew_stagger_ns must be 0 .. 100000");
+    skew_stagger_ns = value;
+  } else if (!std::strcmp(key, "skew_gen_pct")) {   // segments of the workgroup dispatched first on a CU this much longer
+    CICE_REQUIRE(value >= 0 && value <= 60, "skew_gen_pct must be 0 .. 60");
+    skew_gen_pct = value;
+  } else if (!std::strcmp(key, "skew_debug")) {  // record start / end ticks of every workgroup of the sweep kernel
+    skew_debug = value != 0;
+  } else if (!std::strcmp(key, "skew_prio")) {   // rotate issue priorities among the workgroups of a CU
+    skew_prio = value;
   } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
     CICE_REQUIRE(value >= 0, "skew_blocks must be >= 0");
     skew_blocks_opt = value;
@@ -1736,6 +1852,29 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
   }
   blk.alloc(hb.size());
   blk.upload(hb.data(), stream);
+  {
+    // Are the on-rank ghost copies exactly the east-west wrap of full-width blocks -- every cell (ilo, j) mirrored by
+    // (ihi+1, j), every (ihi, j) by (ilo-1, j), j = jlo..jhi, and nothing else?  Then a kernel can forward a new
+    // velocity to its ghost cells without the table.
+    const int nx = dom.nx_block, ny = dom.ny_block;
+    const size_t np = (size_t)nx * ny;
+    bool ok = dom.ew == BND_CYCLIC && dom.nbx == 1;
+    size_t expect = 0;
+    for (int lb = 0; lb < dom.nblocks() && ok; ++lb) {
+      const Block& b = dom.all[dom.local[lb]];
+      expect += 2 * (size_t)(b.jhi - b.jlo + 1);
+    }
+    ok = ok && dom.hsrc.size() == expect;
+    for (size_t e = 0; e < dom.hsrc.size() && ok; ++e) {
+      const size_t sb = (size_t)dom.hsrc[e] / np, db = (size_t)dom.hdst[e] / np;
+      const int sq = (int)((size_t)dom.hsrc[e] - sb * np), dq = (int)((size_t)dom.hdst[e] - db * np);
+      const int si = sq % nx + 1, sj = sq / nx + 1, di = dq % nx + 1, dj = dq / nx + 1;
+      const Block& b = dom.all[dom.local[sb]];
+      ok = sb == db && sj == dj && sj >= b.jlo && sj <= b.jhi &&
+           ((si == b.ilo && di == b.ihi + 1) || (si == b.ihi && di == b.ilo - 1));
+    }
+    fwd_is_ew_wrap = ok;
+  }
   // the eight read-only inputs of the momentum equation share one allocation (k_subcycle_skew: one base pointer)
   uarena.alloc(8 * n);
   {
@@ -1907,6 +2046,15 @@ void Evp::prepare(double dt) {
   CICE_HIP(hipGetLastError());
   prepared = true;
   counted = false;   // the diagnostic counts are formed when somebody asks (active_cells)
+}
+
+// test aid: start / end wall-clock ticks (10 ns) of the workgroups of the last k_subcycle_skew launch
+long long Evp::debug_read(const char* what, long long* out, long long cap) {
+  CICE_REQUIRE(!std::strcmp(what, "skew_times"), "unknown debug array");
+  CICE_HIP(hipStreamSynchronize(stream));
+  const long long nn = (long long)skew_dbg.n;
+  if (out && nn) CICE_HIP(hipMemcpy(out, skew_dbg.p, (size_t)std::min(nn, cap) * 8, hipMemcpyDeviceToHost));
+  return nn;
 }
 
 bool Evp::derives_metrics() const { return derive_ok && derive_on; }
@@ -2136,6 +2284,49 @@ int Evp::skew_seg_rows(int K) const {
   return (int)((rows + nseg - 1) / nseg);
 }
 
+// Rows per workgroup when the workgroups of a launch are not treated alike: the SIMD issues from its oldest wavefront
+// first, so of the workgroups sharing a CU the one dispatched first finishes first and the last one late.  Workgroups
+// are dispatched in blockIdx order, one per CU before any CU gets its second; blockIdx -> tile is the XCD remap of the
+// kernel.  The "generation" g of a tile (0: first on its CU) gets a segment of weight 1 + (1 - g) * pct / 100 (two
+// generations: +- pct / 2 ...), normalised per column strip so that the strip's segments still cover its rows exactly.
+void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_rows) {
+  const int key[5] = {K, tiles_x, tiles_y, skew_gen_pct, seg_rows};
+  if (skew_rows.n && !std::memcmp(key, skew_rows_key, sizeof(key))) return;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  const int per_blk = tiles_x * tiles_y, nt = per_blk * nblocks, chunk = (nt + 7) >> 3, per_xcd = std::max(1, ncu / 8);
+  const int rows = dom.ny_block - 2, gens = std::max(1, skew_blocks(K));
+  std::vector<int32_t> tab((size_t)2 * per_blk);
+  // one table for all blocks (they have the same shape): generation from the tile's place in block 0's dispatch order
+  for (int tx = 0; tx < tiles_x; ++tx) {
+    std::vector<double> w(tiles_y);
+    double sum = 0;
+    for (int ty = 0; ty < tiles_y; ++ty) {
+      const int tile_lin = ty * tiles_x + tx;
+      const int g = std::min(gens - 1, (tile_lin % chunk) / per_xcd);
+      w[ty] = 1.0 + (0.5 * (gens - 1) - g) * skew_gen_pct / 100.0;
+      sum += w[ty];
+    }
+    double acc = 0;
+    int prev = 0;
+    for (int ty = 0; ty < tiles_y; ++ty) {
+      acc += w[ty];
+      int end = ty == tiles_y - 1 ? rows : (int)std::lround(rows * acc / sum);
+      end = std::max(end, std::min(rows, prev + 1));       // at least one row each while rows last
+      tab[2 * (size_t)(ty * tiles_x + tx)] = prev;
+      tab[2 * (size_t)(ty * tiles_x + tx) + 1] = std::max(prev, end) - 1;   // empty segment: last < first
+      prev = std::max(prev, end);
+    }
+  }
+  skew_rows.alloc(tab.size());
+  skew_rows.upload(tab.data(), stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+  std::memcpy(skew_rows_key, key, sizeof(key));
+}
+
 template <int K, int WS>
 static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s) {
   const dim3 blk(64 * K);
@@ -2156,6 +2347,21 @@ void Evp::launch_subcycle_skew(int ksub, int K) {
   sa.seg_rows = skew_seg_rows(K);
   sa.a.tiles_x = ((dom.nx_block - 2) + 1 + ownl - 1) / ownl;
   sa.a.tiles_y = ((dom.ny_block - 2) + sa.seg_rows - 1) / sa.seg_rows;
+  sa.prio_rotate = skew_prio;
+  sa.rows = nullptr;
+  if (skew_gen_pct > 0 && skew_seg_opt == 0) {   // (built by subcycles() before any capture: it uploads a table)
+    build_skew_rows(K, sa.a.tiles_x, sa.a.tiles_y, sa.a.nblocks, sa.seg_rows);
+    sa.rows = skew_rows.p;
+  }
+  sa.fwd_rule = fwd_is_ew_wrap ? 1 : 0;
+  sa.dbg = nullptr;
+  if (skew_debug) {
+    const size_t want = 2 * (size_t)(8 * ((sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks + 7) / 8));
+    if (skew_dbg.n < want) skew_dbg.alloc(want);
+    sa.dbg = skew_dbg.p;
+  }
+  sa.stagger_ticks = skew_stagger_ns / 10;
+  sa.stagger_mod = std::max(1, skew_blocks(K));
   sa.st_in = st[cur].p;
   sa.st_out = st[1 - cur].p;
   sa.uar = uarena.p;
@@ -2389,12 +2595,16 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   // CICE4_AMD_COMM_GRAPH=1 once a multi-GPU parity run has passed.
   static const bool env_comm_graph = std::getenv("CICE4_AMD_COMM_GRAPH") != nullptr;
   const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
+  if (can_skew() && skew_gen_pct > 0 && skew_seg_opt == 0) {   // the segment table of the sweep kernel, outside any capture
+    const int K = skew_levels(), ownl = 62 - 2 * K, seg = skew_seg_rows(K);
+    build_skew_rows(K, ((dom.nx_block - 2) + 1 + ownl - 1) / ownl, ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
+  }
   bool replayed = false;
   if (nsub >= 2 && can_reside()) replayed = run_resident(ksub0, nsub);
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +
-                         (can_skew() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};
+                         (can_skew() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};   // (set_option drops the graph anyway)
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();

@@ -368,6 +368,14 @@ class Context:
         self._ck(self.lib.cice_evp_get_info(self.h, key.encode(), C.byref(v)))
         return v.value
 
+    def evp_debug(self, what):
+        n = C.c_longlong(0)
+        self._ck(self.lib.cice_evp_debug(self.h, what.encode(), None, C.byref(n)))
+        out = np.zeros(n.value, np.int64)
+        if n.value:
+            self._ck(self.lib.cice_evp_debug(self.h, what.encode(), out.ctypes.data_as(C.c_void_p), C.byref(n)))
+        return out
+
     def evp_active_cells(self):
         nt = C.c_longlong(); nu = C.c_longlong()
         self._ck(self.lib.cice_evp_active_cells(self.h, C.byref(nt), C.byref(nu)))

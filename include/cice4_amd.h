@@ -202,6 +202,10 @@ int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
  * (= sum of icellt / icellu, ice_dyn_evp.F90:160-162) */
 int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucells);
+/* Test / tuning aid: `what` = "skew_times" (after cice_evp_set_option("skew_debug", 1)): start and end wall-clock ticks
+ * (10 ns) of every workgroup of the last K-subcycle sweep launch.  *count: in = capacity of out (out may be NULL),
+ * out = entries available. */
+int cice_evp_debug(cice_ctx *ctx, const char *what, long long *out, long long *count);
 
 /* Per-routine entries with the reference's own argument lists (host pointers, one
  * (nx_block,ny_block) block), for parity tests: stress ice_dyn_evp.F90:947-966,

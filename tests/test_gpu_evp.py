@@ -563,7 +563,8 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
     rows handed from level to level through LDS) against one launch per subcycle and the checker: bit for bit.
     Every K; widths around the strip strides (62 - 2K columns), blocks narrower than a strip (the ring wraps inside
     one wavefront), open / closed E-W edges; row segments of 1 .. many rows (interior segment ends: K rim rows) and
-    the automatic choice; subcycle counts that are no multiple of K (the rest runs as pairs / single launches);
+    the automatic choice, segments of unequal length (longer ones for the workgroups dispatched first) and the rotation
+    of issue priorities; subcycle counts that are no multiple of K (the rest runs as pairs / single launches);
     damping; graph replay and eager."""
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=0)
     gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
@@ -580,17 +581,19 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
             orc.set_strength_parameters()
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
-        for K, seg, graph in ((4, 0, 1), (2, 0, 1), (3, 5, 1), (4, 1, 1), (4, 7, 0), (5, 3, 1), (6, 11, 1), (8, 4, 1),
-                              (8, 0, 1)):
+        # (K, rows per workgroup (0: automatic), graph, unequal segments in %, priority rotation)
+        for K, seg, graph, pct, prio in ((4, 0, 1, 0, 0), (2, 0, 1, 30, 1), (3, 5, 1, 0, 1), (4, 1, 1, 0, 0), (4, 7, 0, 0, 1),
+                                         (5, 3, 1, 0, 0), (6, 11, 1, 0, 0), (8, 4, 1, 0, 1), (8, 0, 1, 10, 0),
+                                         (4, 0, 1, 25, 1), (3, 0, 1, 60, 1)):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             for key, v in (("resident", 0), ("skew", 1), ("skew_min_cells", 0), ("skew_levels", K),
-                           ("skew_seg_rows", seg), ("use_graph", graph)):
+                           ("skew_seg_rows", seg), ("use_graph", graph), ("skew_gen_pct", pct), ("skew_prio", prio)):
                 ctx.evp_set_option(key, v)
             assert ctx.evp_get_info("skew") == 1 and ctx.evp_get_info("skew_levels") == K
             ctx.evp(DT, sg)
             for k in keys:
-                assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, k)
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, pct, prio, k)
 
 
 @pytest.mark.parametrize("nxg,nyg,ew,ns", [(96, 70, 1, 0), (20, 33, 1, 0), (62, 18, 1, 0), (63, 18, 1, 0), (64, 18, 1, 0),
