@@ -104,6 +104,9 @@ struct cice_ctx {
     DevBuf<double> aicen, trcrn, vicen, vsnon, eicen, esnon, flw, potT, Qa, rhoa, fsnow, fbot, Tbot,
         lhcoef, shcoef, fswsfc, fswint, fswthrun, Sswabs, Iswabs, out15, mlt_onset, frz_onset;
     DevBuf<double> mrg_in, mrg_acc, fz_in;   // merge_fluxes inputs / accumulators, frzmlt inputs + rside
+    DevBuf<int32_t> perm;                    // columns of every chunk sorted by expected work (k_thermo_sort)
+    int sort_chunk = 0, sort_group = 8;      // chunk 0: no sorting (k_thermo_dense) -- the default: DESIGN.md 3.3
+    DevBuf<unsigned char> niter;             // solver iterations of every (cell, category) in the last step
     DevBuf<double> atm_in;                   // uatm, vatm, wind, zlvl, strax, stray (cice_step_therm1_abl)
     std::vector<int32_t> hblk;               // ilo, ihi, jlo, jhi per block (host copy of blk)
   } tb;
@@ -753,8 +756,28 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
 }
 int cice_evp_debug(cice_ctx* ctx, const char* what, long long* out, long long* count) {
   CICE_TRY(ctx)
-  NEED_EVP;
   CICE_REQUIRE(what && count, "NULL argument");
+  if (!std::strcmp(what, "thermo_niter")) {   // one byte per (cell, category) of the batched thermo state, packed in the words
+    const long long nbytes = (long long)c_->tb.niter.n, nw = (nbytes + 7) / 8;
+    if (out && nbytes) {
+      CICE_REQUIRE(*count >= nw, "cice_evp_debug: buffer too small");
+      CICE_HIP(hipStreamSynchronize(c_->stream));
+      CICE_HIP(hipMemcpy(out, c_->tb.niter.p, (size_t)nbytes, hipMemcpyDeviceToHost));
+    }
+    *count = nw;
+    return CICE_OK;
+  }
+  if (!std::strcmp(what, "thermo_perm")) {    // the permutation of the last sorted thermo step, two int32 per word
+    const long long nbytes = (long long)c_->tb.perm.n * 4, nw = (nbytes + 7) / 8;
+    if (out && nbytes) {
+      CICE_REQUIRE(*count >= nw, "cice_evp_debug: buffer too small");
+      CICE_HIP(hipStreamSynchronize(c_->stream));
+      CICE_HIP(hipMemcpy(out, c_->tb.perm.p, (size_t)nbytes, hipMemcpyDeviceToHost));
+    }
+    *count = nw;
+    return CICE_OK;
+  }
+  NEED_EVP;
   *count = c_->evp->debug_read(what, out, *count);
   CICE_CATCH
 }
@@ -1178,14 +1201,47 @@ static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long 
   for (int k = 0; k < 15; ++k) *outs[k] = t.out15.p + (size_t)k * nc;
   a.mlt_onset = t.mlt_onset.p; a.frz_onset = t.frz_onset.p;
   a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+  if (t.niter.n != nc) {
+    t.niter.alloc(nc);
+    t.niter.zero(s);
+  }
+  a.niter = t.niter.p;
   if (elapsed_ms) {
     CICE_HIP(hipEventCreate(&ev[0]));
     CICE_HIP(hipEventCreate(&ev[1]));
     CICE_HIP(hipEventRecord(ev[0], s));
   }
-  thermo_launch_dense(a, s);
+  static const int env_chunk = [] { const char* e = std::getenv("CICE4_AMD_THERMO_SORT"); return e ? std::atoi(e) : -1; }();
+  const int chunk = env_chunk >= 0 ? env_chunk : t.sort_chunk;
+  static const int env_group = [] { const char* e = std::getenv("CICE4_AMD_THERMO_GROUP"); return e ? std::atoi(e) : -1; }();
+  const int group = env_group > 0 ? env_group : t.sort_group;
+  if (chunk >= 256 && chunk <= 2048 && chunk % 256 == 0 && (group == 1 || group == 2 || group == 4 || group == 8 ||
+                                                            group == 16 || group == 32)) {
+    const size_t np = (size_t)t.nx * t.ny;
+    const size_t want = thermo_sorted_plane(np, chunk) * t.nb * NCAT;
+    if (t.perm.n != want) t.perm.alloc(want);
+    // the Tsfc tracer plane of (category, block) cb: trcrn is (nx, ny, max_ntrcr, ncat, nb)
+    thermo_launch_sorted(a, chunk, group, t.perm.p, t.trcrn.p + (size_t)(c_->tp.nt_Tsfc - 1) * np, (size_t)NTRCR * np, s);
+  } else {
+    thermo_launch_dense(a, s);
+  }
   if (elapsed_ms) CICE_HIP(hipEventRecord(ev[1], s));
   CICE_HIP(hipMemcpyAsync(status, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
+}
+
+int cice_thermo_set_option(cice_ctx* ctx, const char* key, int value) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(key, "NULL key");
+  if (!std::strcmp(key, "sort_chunk")) {
+    CICE_REQUIRE(value == 0 || (value >= 256 && value <= 2048 && value % 256 == 0), "sort_chunk must be 0 or 256 .. 2048 in steps of 256");
+    c_->tb.sort_chunk = value;
+  } else if (!std::strcmp(key, "sort_group")) {
+    CICE_REQUIRE(value == 1 || value == 2 || value == 4 || value == 8 || value == 16 || value == 32, "sort_group must be 1, 2, 4, 8, 16 or 32");
+    c_->tb.sort_group = value;
+  } else {
+    throw Error{CICE_EINVAL, std::string("unknown option ") + key};
+  }
+  CICE_CATCH
 }
 
 int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_updates,

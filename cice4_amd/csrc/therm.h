@@ -34,10 +34,14 @@ struct ThermoArgs {
       *meltt, *melts, *meltb, *congel, *snoice, *mlt_onset, *frz_onset;
   unsigned long long* errkey;   // atomicMin target, initialised to ~0
   unsigned long long* nupdates; // dense mode: number of columns updated
+  unsigned char* niter;         // dense mode (may be NULL): iterations the implicit solve of every column took
 };
 
 void thermo_launch_list(const ThermoArgs& a, hipStream_t s);
 void thermo_launch_dense(const ThermoArgs& a, hipStream_t s);
+size_t thermo_sorted_plane(size_t np, int chunk);   // entries of the permutation per (category, block) plane
+void thermo_launch_sorted(const ThermoArgs& a, int chunk, int group, int32_t* perm, const double* tsfc, size_t tstride,
+                          hipStream_t s);
 
 struct MergeArgs {  // merge_fluxes, ice_flux.F90:613-762
   int nx, ny, ncat, nblocks;

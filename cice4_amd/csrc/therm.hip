@@ -135,7 +135,7 @@ __device__ __forceinline__ unsigned init_profile(const ThermoParams& P, double a
 // are the caller's, Tsf is not solved for), get_matrix_elements_know_Tsfc :2777;
 // tridiag_solver :3069)
 template <bool CALC>
-__device__ __forceinline__ bool temperature_changes(const ThermoParams& P, double dt, Col& c, Flx& f) {
+__device__ __forceinline__ bool temperature_changes(const ThermoParams& P, double dt, Col& c, Flx& f, int& iters) {
   constexpr int nitermax = 100;
   constexpr double Tsf_errmax = 5.0e-4;
   const double hilyr = c.hilyr, hslyr = c.hslyr;
@@ -212,6 +212,7 @@ __device__ __forceinline__ bool temperature_changes(const ThermoParams& P, doubl
 
 #pragma unroll 1
   for (int niter = 1; niter <= nitermax && !converged; ++niter) {
+    iters = niter;
     double etai[NI], sb[NMAT], dg[NMAT], sp[NMAT], rh[NMAT], Tm[NMAT];
     double dfsurf_dT = c0, avg_Tsi = c0, enew = c0, Tsf_start = c0, dTsf = c0, avg_Tsf = c0;
     double dqmat[NI];
@@ -674,7 +675,9 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   if (!CALC) {  // intent(in) when calc_Tsfc = F (:213-217)
     f.fsurfn = a.fsurfn[c2d]; f.fcondtopn = a.fcondtopn[c2d]; f.flatn = a.flatn[c2d];
   }
-  const bool conv = temperature_changes<CALC>(P, a.dt, c, f);
+  int iters = 0;
+  const bool conv = temperature_changes<CALC>(P, a.dt, c, f, iters);
+  if (a.niter) a.niter[c2d] = (unsigned char)min(iters, 255);   // solver iterations of this column: next step's sort key
   a.fswsfc[c2d] = f.fswsfc; a.fswint[c2d] = f.fswint;
 #pragma unroll
   for (int k = 0; k < NS; ++k) a.Sswabs[ssq + (size_t)k * np] = f.Sswabs[k];
@@ -777,6 +780,117 @@ __global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_dense(co
   if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
 }
 
+// ---- homogeneous wavefronts: columns sorted by the work they are expected to take ---------------------------------
+//
+// A column takes 1 to ~16 iterations of the implicit solve (3.4 on average in the bench workload) and one of four
+// branch patterns (snow-covered or bare, cold or melting surface); a wavefront lasts as long as its slowest lane:
+// with 64 consecutive cells per wavefront a third of the lane-iterations is idle (profiles/r02_sq_counters_gx1.csv:
+// 47 of 64 lanes active).  Which column sits in which lane changes no column's bits, so: k_thermo_sort orders the
+// columns of every chunk of SORT_CHUNK consecutive cells of a (category, block) plane by a key -- the iterations the
+// column took in the PREVIOUS step (the state of a column changes slowly from step to step; in the first step the
+// count is unknown = 0), then snow / no snow and cold / melting surface -- with a counting sort in LDS, and writes the
+// permutation; k_thermo_perm is k_thermo_dense with lane l of wavefront w working on column perm[64 w + l].
+// The chunk bounds the scatter of a wavefront's memory accesses (512 cells = 32 cache lines of 128 B per field).
+struct SortArgs {
+  int nx, ny, ncat, nblocks, chunk, group;
+  size_t np_pad;                        // cells per plane rounded up to whole chunks
+  const int32_t* blk;
+  const double *aicen, *vsnon, *tsfc;   // tsfc: the Tsfc tracer plane of (category, block) cb at tsfc + cb * tstride
+  size_t tstride;
+  const unsigned char* niter;
+  int32_t* perm;                        // [ncat * nblocks][np_pad]: cell index q, bit 31 set: not an active column; -1: no cell
+};
+
+constexpr int SORT_BINS = 128;          // key = min(iterations, 31) * 4 + snow * 2 + cold; 127 = nothing active
+
+// What is sorted are GROUPS of `group` adjacent cells (1, 8, 16: a power of two), by the largest key among their
+// active columns: a wavefront then works on 64 / group runs of adjacent cells and its loads stay (nearly) coalesced --
+// with single columns as the unit (group = 1) the scattered accesses cost more than the idle lanes did (measured).
+__global__ __launch_bounds__(256) void k_thermo_sort(const SortArgs a) {
+  __shared__ int s_cnt[SORT_BINS];
+  const size_t np = (size_t)a.nx * a.ny;
+  const int n = blockIdx.y, b = blockIdx.z;
+  const size_t cb = (size_t)b * a.ncat + n;
+  const size_t q0 = (size_t)blockIdx.x * a.chunk;
+  const int ilo = a.blk[4 * b], ihi = a.blk[4 * b + 1], jlo = a.blk[4 * b + 2], jhi = a.blk[4 * b + 3];
+  const int G = a.group, lane = threadIdx.x & 63;
+  if (threadIdx.x < SORT_BINS) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  constexpr int MAXPER = 8;             // chunk <= 2048
+  int gkey[MAXPER], rank[MAXPER];
+  bool act[MAXPER];
+  const int per = a.chunk / 256;        // the chunk is a multiple of 256
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    gkey[e] = -1;
+    act[e] = false;
+    if (e >= per) continue;
+    const size_t q = q0 + (size_t)e * 256 + threadIdx.x;     // consecutive threads, consecutive cells
+    int k = -1;
+    if (q < np) {
+      const size_t c2d = cb * np + q;
+      const int j = (int)(q / a.nx) + 1, i = (int)(q - (size_t)(j - 1) * a.nx) + 1;
+      const double ai = a.aicen[c2d];
+      if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && ai > puny) {
+        const bool snow = a.vsnon[c2d] / ai > hs_min;
+        const bool cold = a.tsfc[cb * a.tstride + q] <= -puny;
+        // heaviest first: bin 0 = most iterations (the wavefronts that run longest start first, see k_thermo_perm)
+        k = SORT_BINS - 2 - min(min((int)a.niter[c2d], 31) * 4 + (snow ? 2 : 0) + (cold ? 1 : 0), SORT_BINS - 2);
+        act[e] = true;
+      }
+    }
+    int gk = k < 0 ? SORT_BINS - 1 : k;  // heaviest column of the group = smallest bin (SORT_BINS - 1: nothing active in it)
+    for (int d = 1; d < G; d <<= 1) gk = min(gk, __shfl_xor(gk, d));
+    int r = 0;
+    if ((lane & (G - 1)) == 0) r = atomicAdd(&s_cnt[gk], 1);
+    rank[e] = __shfl(r, lane & ~(G - 1));
+    gkey[e] = gk;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {   // exclusive prefix sum over the bins: one wavefront, two bins per lane
+    const int c0_ = s_cnt[2 * threadIdx.x], c1_ = s_cnt[2 * threadIdx.x + 1];
+    int v = c0_ + c1_;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int u = __shfl_up(v, d);
+      if ((int)threadIdx.x >= d) v += u;
+    }
+    const int excl = v - (c0_ + c1_);
+    s_cnt[2 * threadIdx.x] = excl;
+    s_cnt[2 * threadIdx.x + 1] = excl + c0_;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < MAXPER; ++e) {
+    if (gkey[e] < 0) continue;
+    const size_t q = q0 + (size_t)e * 256 + threadIdx.x;
+    const int pos = (s_cnt[gkey[e]] + rank[e]) * G + (lane & (G - 1));
+    a.perm[cb * a.np_pad + q0 + pos] = q < np ? ((int32_t)q | (act[e] ? 0 : (int32_t)0x80000000)) : -1;
+  }
+}
+
+template <bool CALC>
+__global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_perm(const ThermoArgs a, const int32_t* perm,
+                                                                             size_t np_pad, int chunk) {
+  const size_t np = (size_t)a.nx * a.ny;
+  // workgroup (= wavefront) w of a plane takes the (w / nchunks)-th wavefront of chunk w % nchunks: the heaviest
+  // wavefronts of all chunks are dispatched first, the lightest last (a short tail)
+  const unsigned wpc = (unsigned)chunk / blockDim.x, nchunks = (unsigned)(np_pad / (size_t)chunk);
+  const size_t slot = ((size_t)(blockIdx.x % nchunks) * wpc + blockIdx.x / nchunks) * blockDim.x + threadIdx.x;
+  const int n = blockIdx.y, b = blockIdx.z;
+  if (slot >= np_pad) return;
+  const size_t cb = (size_t)b * a.ncat + n;
+  const int32_t e = perm[cb * np_pad + slot];
+  if (e == -1) return;                       // padding behind the last cell of the plane
+  const size_t q = (size_t)(e & 0x7fffffff);
+  const bool active = e >= 0;
+  // every point's 15 output planes are written exactly once: by its column, or zeroed here
+  if (active) column<CALC, true>(a, q, n, b, (unsigned long long)q);
+  else zero_outputs<CALC>(a, cb * np + q);
+  unsigned long long cnt = __popcll(__ballot(active));
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
+}
+
 // merge_fluxes (ice_flux.F90:730-760): one lane per cell accumulates the categories in order
 __global__ __launch_bounds__(256) void k_merge(const MergeArgs a) {
   const size_t np = (size_t)a.nx * a.ny;
@@ -872,6 +986,27 @@ void thermo_launch_dense(const ThermoArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(k_thermo_dense<true>, g, dim3(bs), 0, s, a);
   else
     hipLaunchKernelGGL(k_thermo_dense<false>, g, dim3(bs), 0, s, a);
+  CICE_HIP(hipGetLastError());
+}
+
+size_t thermo_sorted_plane(size_t np, int chunk) { return (np + chunk - 1) / chunk * chunk; }
+
+// dense step with the columns of every chunk of `chunk` cells sorted by expected work (see k_thermo_sort); tsfc / tstride:
+// the Tsfc tracer plane of (category, block) cb starts at tsfc + cb * tstride
+void thermo_launch_sorted(const ThermoArgs& a, int chunk, int group, int32_t* perm, const double* tsfc, size_t tstride,
+                          hipStream_t s) {
+  const size_t np = (size_t)a.nx * a.ny;
+  SortArgs sa{};
+  sa.nx = a.nx; sa.ny = a.ny; sa.ncat = a.ncat; sa.nblocks = a.nblocks; sa.chunk = chunk; sa.group = group; sa.blk = a.blk;
+  sa.np_pad = thermo_sorted_plane(np, chunk);
+  sa.aicen = a.aicen; sa.vsnon = a.vsnon; sa.tsfc = tsfc; sa.tstride = tstride; sa.niter = a.niter; sa.perm = perm;
+  hipLaunchKernelGGL(k_thermo_sort, dim3((unsigned)((np + chunk - 1) / chunk), a.ncat, a.nblocks), dim3(256), 0, s, sa);
+  constexpr unsigned bs = 64;
+  const dim3 g((unsigned)((sa.np_pad + bs - 1) / bs), a.ncat, a.nblocks);
+  if (a.p.calc_Tsfc)
+    hipLaunchKernelGGL(k_thermo_perm<true>, g, dim3(bs), 0, s, a, (const int32_t*)perm, sa.np_pad, chunk);
+  else
+    hipLaunchKernelGGL(k_thermo_perm<false>, g, dim3(bs), 0, s, a, (const int32_t*)perm, sa.np_pad, chunk);
   CICE_HIP(hipGetLastError());
 }
 

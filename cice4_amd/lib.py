@@ -462,6 +462,9 @@ class Context:
             C.byref(jstop)))
         return ls.value, istop.value, jstop.value
 
+    def thermo_set_option(self, key, value):
+        self._ck(self.lib.cice_thermo_set_option(self.h, key.encode(), int(value)))
+
     def thermo_batch_alloc(self, nx, ny, nblocks):
         self._ck(self.lib.cice_thermo_batch_alloc(self.h, nx, ny, nblocks))
 

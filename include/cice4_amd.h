@@ -305,6 +305,12 @@ int cice_thermo_batch_alloc(cice_ctx *ctx, int nx_block, int ny_block, int nbloc
 int cice_thermo_batch_upload(cice_ctx *ctx, const cice_thermo_fields *host);
 /* One pass over all (cell,category) columns.  n_updates: number of columns updated;
  * l_stop/istop/jstop/nstop/bstop: first failing column in (block, category, list) order. */
+/* Tuning switches of the batched step; results never depend on them.  "sort_chunk" (0 = off, the default; 256 .. 2048):
+ * the columns of every chunk of that many consecutive cells of a (category, block) plane are ordered by the work they
+ * are expected to take (the solver iterations of the previous step, snow / no snow, cold / melting surface) before
+ * wavefronts are formed, "sort_group" (1, 2, 4, 8, 16, 32) adjacent cells staying together (built,
+ * bit-exact, measured slower than the unsorted kernel at every setting, hence off). */
+int cice_thermo_set_option(cice_ctx *ctx, const char *key, int value);
 int cice_thermo_batch_step(cice_ctx *ctx, double dt, double yday, long long *n_updates,
                            int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop,
                            int32_t *bstop, float *elapsed_ms);

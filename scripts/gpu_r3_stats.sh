@@ -1,0 +1,14 @@
+#!/bin/bash
+# rocprofv3 kernel stats of a bench command: args = env assignments and bench options
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+O=gpurun_out/r03stats
+rm -rf $O; mkdir -p $O
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O -- python bench.py "$@" > $O/run.log 2>&1
+f=$(find $O -name "*kernel_stats.csv" | head -1)
+python - "$f" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:14]:
+    print(f"{r['Name'][:90]:90s} calls {r['Calls']:>6s} avg_us {float(r['AverageNs'])/1e3:10.2f} total_ms {float(r['TotalDurationNs'])/1e6:9.2f} {r['Percentage']}%")
+PY
+find $O -name "*kernel_trace.csv" -size +20M -delete

@@ -260,6 +260,38 @@ def test_batched_step_equals_per_category_calls(ctx, orc):
     assert st["n_updates"] == nupd
 
 
+@pytest.mark.parametrize("chunk,group", [(256, 1), (512, 8), (2048, 16), (256, 32)])
+def test_sorted_columns_give_the_same_bits(ctx, chunk, group):
+    """cice_thermo_set_option("sort_chunk", C): the columns of every chunk are dealt to the lanes in the order of the
+    work they are expected to take (previous step's solver iterations, snow, cold / melting).  Which lane a column sits
+    in changes nothing in its arithmetic: every field equals the unsorted step bit for bit, in the first step (no
+    iteration counts yet) and in a second one (sorted by the first step's counts); planes that are no multiple of the
+    chunk, two blocks, ice-free and ghost cells inside the chunks."""
+    ctx.thermo_init()
+    ny, nx, nb = 29, 43, 2
+    batch, _ = _batch_inputs(ny, nx, nb, seed=33)
+    keys = ("aicen", "vicen", "vsnon", "trcrn", "eicen", "esnon", "fswsfc", "fswint", "Sswabs", "Iswabs", "mlt_onset",
+            "frz_onset") + lib.THERMO_OUT
+    res = {}
+    for sort in (0, chunk):
+        ctx.thermo_batch_alloc(nx, ny, nb)
+        ctx.thermo_set_option("sort_chunk", sort); ctx.thermo_set_option("sort_group", group)
+        outs = []
+        for step in range(2):
+            b = {k: v.copy() for k, v in batch.items()}
+            ctx.thermo_batch_upload(b)
+            st = ctx.thermo_batch_step(DT, yday=150.0)
+            assert st["l_stop"] == 0
+            ctx.thermo_batch_download(b)
+            outs.append((b, st["n_updates"]))
+        res[sort] = outs
+    ctx.thermo_set_option("sort_chunk", 0)
+    for step in range(2):
+        assert res[0][step][1] == res[chunk][step][1] > 0
+        for k in keys:
+            assert np.array_equal(res[0][step][0][k], res[chunk][step][0][k]), (step, k)
+
+
 def test_batch_merge_equals_merge_fluxes(ctx, orc):
     """cice_thermo_batch_merge = merge_fluxes (ice_flux.F90:613) called once per category with
     that category's list and aicen_init, on the batch's own per-category outputs: bit for bit."""
