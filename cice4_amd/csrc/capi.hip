@@ -34,6 +34,7 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
+  LocalLink* link = nullptr;   // in-process stand-in for the communicator (cice_comm_init_local; tests)
   // Page-locked host ranges of this context: [start, end) in bytes, disjoint.  One manager for the explicit
   // registrations (cice_host_register, cice_evp_pin_fields): a new range that touches registered ones is registered
   // as their union (a whole array after some of its slices), because a copy whose host range is partly registered
@@ -137,6 +138,7 @@ struct cice_ctx {
       frame_halo.reset();
       halo->init(dom, stream);
       if (comm) halo->set_comm((ncclComm*)comm, comm_rank, comm_nranks);
+      if (link) halo->set_link(link, comm_rank, comm_nranks);
     }
   }
 };
@@ -252,6 +254,7 @@ static void frame_build(cice_ctx* c) {
   c->frame_halo.reset(new Halo());
   c->frame_halo->init(fd, c->stream);
   if (c->comm) c->frame_halo->set_comm((ncclComm*)c->comm, c->comm_rank, c->comm_nranks);
+  if (c->link) c->frame_halo->set_link(c->link, c->comm_rank, c->comm_nranks);
   CICE_HIP(hipStreamSynchronize(c->stream));
 }
 
@@ -670,6 +673,20 @@ int cice_comm_init(cice_ctx* ctx, const char uid[128], int rank, int nranks) {
   CICE_CATCH
 }
 
+// In-process link instead of an RCCL communicator (halo.h): the ranks are contexts of this process, one host thread each.
+int cice_comm_init_local(cice_ctx* ctx, int link_id, int rank, int nranks) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "cice_comm_init_local: bad arguments");
+  CICE_REQUIRE(!c_->comm, "cice_comm_init_local: this context already has an RCCL communicator");
+  c_->need_halo();
+  c_->link = local_link_get(link_id, nranks);
+  c_->comm_rank = rank;
+  c_->comm_nranks = nranks;
+  c_->halo->set_link(c_->link, rank, nranks);
+  if (c_->frame_halo) c_->frame_halo->set_link(c_->link, rank, nranks);
+  CICE_CATCH
+}
+
 // Ranks of this context's communicator as RCCL itself counts them (ncclCommCount); 0 before cice_comm_init.
 int cice_comm_count(cice_ctx* ctx, int* nranks) {
   CICE_TRY(ctx)
@@ -748,10 +765,49 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "skew")) *value = c_->evp->can_skew() ? 1 : 0;
   else if (!std::strcmp(key, "skew_levels")) *value = c_->evp->skew_levels();
   else if (!std::strcmp(key, "skew_seg_rows")) *value = c_->evp->skew_seg_rows(c_->evp->skew_levels());
-  else if (!std::strcmp(key, "resident")) *value = c_->evp->can_reside() ? 1 : 0;
+  else if (!std::strcmp(key, "resident")) *value = (c_->evp->can_reside() || c_->evp->can_reside_peer()) ? 1 : 0;
+  else if (!std::strcmp(key, "resident_peer")) *value = c_->evp->can_reside_peer() ? 1 : 0;
   else if (!std::strcmp(key, "resident_waves")) *value = c_->evp->resident_waves();
   else if (!std::strcmp(key, "resident_dense")) *value = c_->evp->can_reside() && c_->evp->resident_dense() ? 1 : 0;
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
+  CICE_CATCH
+}
+int cice_evp_peer_export(cice_ctx* ctx, void* bufs[3], long long* plane) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(bufs && plane, "NULL argument");
+  c_->evp->peer_export(bufs);
+  *plane = (long long)c_->dom.nblocks() * c_->dom.nx_block * c_->dom.ny_block;
+  CICE_CATCH
+}
+int cice_evp_peer_connect(cice_ctx* ctx, int side, void* xu0, void* xu1, void* rprog, long long plane) {
+  CICE_TRY(ctx) NEED_EVP; c_->evp->peer_connect(side, xu0, xu1, rprog, plane); CICE_CATCH
+}
+// The same buffers as IPC handles (3 x 64 bytes) for a neighbour in ANOTHER process, and their opening on the other
+// side.  (Across processes / GPUs; not exercised on the one-GPU test boxes, where two contexts of one process exchange
+// plain pointers.)
+int cice_evp_peer_export_ipc(cice_ctx* ctx, char handles[3][64], long long* plane) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(handles && plane, "NULL argument");
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t size");
+  void* bufs[3];
+  c_->evp->peer_export(bufs);
+  for (int k = 0; k < 3; ++k) CICE_HIP(hipIpcGetMemHandle((hipIpcMemHandle_t*)handles[k], bufs[k]));
+  *plane = (long long)c_->dom.nblocks() * c_->dom.nx_block * c_->dom.ny_block;
+  CICE_CATCH
+}
+int cice_evp_peer_connect_ipc(cice_ctx* ctx, int side, const char handles[3][64], long long plane) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(handles, "NULL argument");
+  void* p[3];
+  for (int k = 0; k < 3; ++k) {
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles[k], 64);
+    CICE_HIP(hipIpcOpenMemHandle(&p[k], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  c_->evp->peer_connect(side, p[0], p[1], p[2], plane);
   CICE_CATCH
 }
 int cice_evp_debug(cice_ctx* ctx, const char* what, long long* out, long long* count) {

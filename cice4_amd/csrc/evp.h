@@ -1,5 +1,6 @@
 // Device-resident EVP dynamics: state, kernels' launch wrappers.
 #pragma once
+#include <map>
 #include <vector>
 
 #include "common.h"
@@ -38,6 +39,9 @@ class Evp {
   int tile_waves() const { return waves; }
   int tile_rows() const { return rows_per_wave; }
   bool can_reside() const;   // the whole subcycle loop in one launch, state in registers (k_evp_resident)
+  bool can_reside_peer() const;  // the same on one slab of a domain cut across ranks, neighbours' buffers mapped (peer_connect)
+  void peer_export(void* out[3]);  // this rank's exchange copies and remote-progress words (device pointers)
+  void peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n);
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
@@ -96,6 +100,13 @@ class Evp {
   DevBuf<unsigned> res_prog;     // [tiles * 32] progress words, then the abort word
   DevBuf<double> res_xu[2];      // exchange copies of (u, v)
   void build_resident(int W);
+  void build_resident_peer(int W);
+  void peer_alloc();
+  struct Peer { double* xu[2] = {nullptr, nullptr}; unsigned* rprog = nullptr; unsigned n = 0; } peers[2];
+  DevBuf<int32_t> res_rslot, res_rfwd, res_pub;
+  DevBuf<unsigned> res_rprog;    // [2 sides][RP_MAX tiles][RES_STRIDE]: progress of the neighbours' tiles, written by them
+  bool res_peer_built = false, res_peer_agree = true;
+  int res_peer_share = 1;
   bool run_resident(int ksub0, int nsub);
   int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop
   bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)

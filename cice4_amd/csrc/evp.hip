@@ -1189,6 +1189,16 @@ struct ResArgs {
   const int32_t* deps;   // [tiles][RES_MAXDEP] producer tiles, -1 padded
   double* xu[2];         // exchange copies: u at 0, v at a.n; subcycle k publishes into xu[k & 1]
   long long spin_ticks;  // wall_clock64() ticks (100 MHz) a poll may take
+  // PEER: the block is one slab of a domain cut across ranks; the tiles on its first / last rows exchange with tiles
+  // of the neighbouring ranks through the SAME protocol, the neighbour's exchange copies and progress words being
+  // mapped into this address space (Evp::peer_connect): side 0 = the rank to the south, 1 = to the north
+  const int32_t* rslot;  // [cells] -1: nothing; -2: a ghost cell whose source lives on another rank; >= 0: slot in rfwd
+  const int32_t* rfwd;   // [slots][4] ghost cells on other ranks that mirror a cell: (side << 30) | address, -1 padded
+  double* pxu[2][2];     // [side][parity]: the neighbour's exchange copies (v at + pn[side])
+  unsigned pn[2];        // the neighbour's plane size
+  unsigned* prp[2];      // [side]: where this rank's tiles publish their progress on the neighbour ([tile * RES_STRIDE])
+  const unsigned* rprog; // progress words the neighbours' tiles publish here: deps <= -2 index it (-2 - dep)
+  const int32_t* pub;    // [tiles] bit 0 / 1: cells of this tile are mirrored on the rank to the south / north
 };
 
 // agent-scope (sc1) access at a uniform base + 32-bit byte offset: SGPR base + VGPR offset addressing, no 64-bit
@@ -1200,7 +1210,20 @@ __device__ __forceinline__ void st_agent(double* base, unsigned off, double v) {
   __hip_atomic_store((double*)((char*)base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int W, bool DAMP>
+// the same across devices (a neighbouring rank's memory over xGMI, or its writes into ours): system scope
+__device__ __forceinline__ double ld_sys(const double* base, unsigned off) {
+  return __hip_atomic_load((double*)((char*)const_cast<double*>(base) + off), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void st_sys(double* base, unsigned off, double v) {
+  __hip_atomic_store((double*)((char*)base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// PEER: see ResArgs.  Differences to the one-rank loop: progress runs epoch0 + 1 ("this launch has begun: its exchange
+// copies are initialised", published before anything else and waited for before the first remote store), epoch0 + 2 + k
+// after subcycle k; the LAST subcycle is exchanged as well, so that every tile ends up holding the final velocity of
+// its halo cells and writes the ghost cells owned by other ranks into the result itself (no halo update afterwards);
+// everything another rank writes or reads is a system-scope access.
+template <int W, bool DAMP, bool PEER>
 __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(const ResArgs r) {
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
@@ -1208,6 +1231,8 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   __shared__ double s_x[W][8][TX];
   __shared__ double s_m[W][10][TX];             // nine metrics + strength
   __shared__ int s_fd[W][3][TX];
+  __shared__ int s_rfd[PEER ? W : 1][4][TX];    // PEER: ghost cells on other ranks mirroring this lane's cell
+  __shared__ int s_pub[2];                      // PEER: this tile publishes to the south / north rank
   __shared__ int s_abort;
   const int nt = a.tiles_x * a.tiles_y;
   const int chunk = (nt + 7) >> 3;
@@ -1234,7 +1259,13 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   const bool south_h = ok && (w == 0 || !(lx < TX - 1 && i <= ihi));
   const bool west_h = lx == 0 && ok;                // column i0-1 (>= 1): west and south-west of lane 0
   // a late workgroup of an aborted launch leaves at once
-  if (threadIdx.x == 0) s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PEER) {   // by geometry, whether or not the cells carry ice: the neighbour's tiles wait for this tile's progress
+      s_pub[0] = r.pub[tile] & 1;
+      s_pub[1] = (r.pub[tile] >> 1) & 1;
+    }
+  }
   __syncthreads();
   if (s_abort) return;
 
@@ -1283,7 +1314,22 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     }
     s_fd[w][0][lx] = fd0; s_fd[w][1][lx] = fd1; s_fd[w][2][lx] = fd2;
     edge = uact && (lx == 0 || lx == TX - 2 || w == 0 || w == W - 2 || i == ihi || j == jhi || fd0 >= 0);
+    if (PEER) {
+      int rf[4] = {-1, -1, -1, -1};
+      if (uact) {
+        const int rs = r.rslot[q];
+        if (rs >= 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rf[c] = r.rfwd[4 * rs + c];
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) s_rfd[w][c][lx] = rf[c];
+      edge = edge || rf[0] >= 0;
+    }
   }
+  // PEER: a ghost cell of this block whose source lives on another rank: some tile has to write its final value
+  const bool rghost = PEER && ok && !uown && r.rslot[q] == -2;
   StressOut o;
   StepuOut ro{};
 
@@ -1292,6 +1338,13 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
   s_uv[w][0][lx] = un;
   s_uv[w][1][lx] = vn;
   __syncthreads();
+  if (PEER) {   // this launch has begun (its exchange copies were initialised before it started)
+    const unsigned begun = r.epoch0 + 1u;
+    if (threadIdx.x == 0)
+      __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 2 && s_pub[threadIdx.x])
+      __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
@@ -1336,12 +1389,42 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
       un = ro.u;
       vn = ro.v;
     }
-    if (k + 1 == r.nsub) break;
+    if (!PEER && k + 1 == r.nsub) break;
     s_uv[w][0][lx] = un;     // read after (E); the reads of the previous values lie before (C)
     s_uv[w][1][lx] = vn;
     // (D) publish the edge velocities of subcycle k, then the progress word
     double* xu = r.xu[k & 1];
     double* xv = xu + a.n;
+    if (PEER && k == 0 && (s_pub[0] | s_pub[1])) {
+      // nothing may be stored into a neighbour's exchange copies before its launch has initialised them
+      if (w == 0) {
+        const int dep = lx < RES_MAXDEP ? r.deps[tile * RES_MAXDEP + lx] : -1;
+        bool have = dep > -2;          // only the tiles of other ranks matter here
+        int bad = 0;
+        const long long t0 = wall_clock64();
+        while (true) {
+          if (!have) {
+            const unsigned v = __hip_atomic_load(r.rprog + (size_t)(-2 - dep) * RES_STRIDE, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_SYSTEM);
+            have = (int)(v - (r.epoch0 + 1u)) >= 0;
+          }
+          if (__all(have)) break;
+          if (lx == 0) {
+            bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!bad && wall_clock64() - t0 > r.spin_ticks) {
+              __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              bad = 1;
+            }
+          }
+          bad = __shfl(bad, 0);
+          if (bad) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (lx == 0) s_abort = bad;
+      }
+      __syncthreads();
+      if (s_abort) return;
+    }
     if (edge) {
       st_agent(xu, qb, un);
       st_agent(xv, qb, vn);
@@ -1353,22 +1436,40 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
           st_agent(xv, (unsigned)fd * 8u, vn);
         }
       }
+      if (PEER) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int rf = s_rfd[w][c][lx];
+          if (rf >= 0) {
+            const int side = (rf >> 30) & 1;
+            const unsigned ro = (unsigned)(rf & 0x3fffffff) * 8u;
+            double* pu = r.pxu[side][k & 1];
+            st_sys(pu, ro, un);
+            st_sys(pu + r.pn[side], ro, vn);
+          }
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const unsigned target = r.epoch0 + (unsigned)k + 1u;
+    const unsigned target = r.epoch0 + (unsigned)k + (PEER ? 2u : 1u);
     if (threadIdx.x == 0)
       __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (PEER && threadIdx.x < 2 && s_pub[threadIdx.x])
+      __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (E) wait until every producer of this tile's halo has published subcycle k
     if (w == 0) {
       const int dep = lx < RES_MAXDEP ? r.deps[tile * RES_MAXDEP + lx] : -1;
-      bool have = dep < 0;
+      bool have = dep == -1;
       int bad = 0;
       const long long t0 = wall_clock64();
       while (true) {
         if (!have) {
-          const unsigned v = __hip_atomic_load(r.prog + (size_t)dep * RES_STRIDE, __ATOMIC_RELAXED,
-                                               __HIP_MEMORY_SCOPE_AGENT);
+          unsigned v;
+          if (PEER && dep <= -2)
+            v = __hip_atomic_load(r.rprog + (size_t)(-2 - dep) * RES_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          else
+            v = __hip_atomic_load(r.prog + (size_t)dep * RES_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           have = (int)(v - target) >= 0;
         }
         if (__all(have)) break;
@@ -1387,20 +1488,20 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
     }
     __syncthreads();
     if (s_abort) return;
-    // every exchanged velocity is an agent-scope load
+    // every exchanged velocity is an agent-scope load (system scope where another rank may have written it)
     if (foreign) {
-      un = ld_agent(xu, qb);
-      vn = ld_agent(xv, qb);
+      un = PEER ? ld_sys(xu, qb) : ld_agent(xu, qb);
+      vn = PEER ? ld_sys(xv, qb) : ld_agent(xv, qb);
     }
     if (south_h) {
-      us = ld_agent(xu, qb - nxb);
-      vs = ld_agent(xv, qb - nxb);
+      us = PEER ? ld_sys(xu, qb - nxb) : ld_agent(xu, qb - nxb);
+      vs = PEER ? ld_sys(xv, qb - nxb) : ld_agent(xv, qb - nxb);
     }
     if (west_h) {
-      uwh = ld_agent(xu, qb - 8u);
-      vwh = ld_agent(xv, qb - 8u);
-      uswh = ld_agent(xu, qb - nxb - 8u);
-      vswh = ld_agent(xv, qb - nxb - 8u);
+      uwh = PEER ? ld_sys(xu, qb - 8u) : ld_agent(xu, qb - 8u);
+      vwh = PEER ? ld_sys(xv, qb - 8u) : ld_agent(xv, qb - 8u);
+      uswh = PEER ? ld_sys(xu, qb - nxb - 8u) : ld_agent(xu, qb - nxb - 8u);
+      vswh = PEER ? ld_sys(xv, qb - nxb - 8u) : ld_agent(xv, qb - nxb - 8u);
     }
   }
 
@@ -1414,6 +1515,26 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
       a.rdg_shear[q] = o.rdg_shear;
       a.shear[q] = o.shear;
       a.prs_sig[q] = o.prs_sig;
+    }
+  }
+  if (PEER) {   // the final velocities of ghost cells another rank owns (after the last exchange the halo registers hold them)
+    if (rghost) {
+      a.u_out[q] = un;
+      a.v_out[q] = vn;
+    }
+    if (south_h && r.rslot[q - nx] == -2) {       // the ghost row below the block is nobody's own position
+      a.u_out[q - nx] = us;
+      a.v_out[q - nx] = vs;
+    }
+    if (west_h) {                                 // nor is the ghost column to the west (its corners)
+      if (r.rslot[q - 1] == -2) {
+        a.u_out[q - 1] = uwh;
+        a.v_out[q - 1] = vwh;
+      }
+      if (r.rslot[q - nx - 1] == -2) {
+        a.u_out[q - nx - 1] = uswh;
+        a.v_out[q - nx - 1] = vswh;
+      }
     }
   }
   if (uact) {
@@ -1794,6 +1915,11 @@ void Evp::set_option(const char* key, int value) {
       resident_failed = false;
       res_level = 0;
     }
+  } else if (!std::strcmp(key, "resident_peer_share")) {   // contexts that share this device in the cross-rank loop (tests: 2)
+    CICE_REQUIRE(value >= 1 && value <= 8, "resident_peer_share must be 1 .. 8");
+    res_peer_share = value;
+  } else if (!std::strcmp(key, "resident_peer_agree")) {   // all-reduce the time-out flag over the ranks (needs cice_comm_init)
+    res_peer_agree = value != 0;
   } else if (!std::strcmp(key, "resident_spin_us")) {   // how long a tile waits for its neighbours before giving up
     CICE_REQUIRE(value >= 0, "resident_spin_us must be >= 0");
     res_spin_us = value;
@@ -2418,19 +2544,195 @@ int Evp::resident_waves() const {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
+  if (halo.multi_rank()) ncu = std::max(1, ncu / std::max(1, res_peer_share));   // contexts sharing this device (tests)
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
   auto tiles = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
-  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu;
-  if (res_w_opt) return tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok) ? res_w_opt : 0;
+  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && !halo.multi_rank();
+  if (res_w_opt) return (tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok)) && !(res_w_opt == 12 && halo.multi_rank()) ? res_w_opt : 0;
   int single = 0;
   for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
-    if (tiles(w) <= ncu) {
+    if (tiles(w) <= ncu && !(w == 12 && halo.multi_rank())) {
       single = w;
       break;
     }
   // wavefronts on the busiest SIMD: dense ceil(tiles / CUs), single ceil(W / 4); a tie goes to dense (hand-offs overlap)
   if (dense_ok && (single == 0 || (tiles(4) + ncu - 1) / ncu <= (single + 3) / 4)) return 4;
   return single;
+}
+
+// ---- the resident loop across ranks (PEER) ----------------------------------------------------------------------
+// One full-width slab per rank (cice_domain_create with npx = 1), ghost rows owned by the ranks to the south and north.
+// The tiles on a slab's first / last rows exchange their edge velocities with the neighbouring rank's tiles exactly as
+// tiles of one rank do -- stores into the reader's exchange copy, a progress word, a poll -- only that the reader's
+// exchange copy and progress words live in another device's memory, mapped into this address space (peer_connect: a
+// plain device pointer for two contexts on one GPU, a pointer obtained from the neighbour's IPC handle across GPUs).
+// No pack kernel, no RCCL call, no unpack kernel inside the subcycling; the host enqueues ONE launch per evp(dt).
+constexpr int RP_MAX = 4096;   // progress words per side a rank keeps for its neighbour's tiles
+
+void Evp::peer_export(void* out[3]) {
+  CICE_REQUIRE(ready, "cice_evp_peer_export before cice_evp_init");
+  peer_alloc();
+  out[0] = res_xu[0].p;
+  out[1] = res_xu[1].p;
+  out[2] = res_rprog.p;
+}
+
+void Evp::peer_alloc() {
+  for (int k = 0; k < 2; ++k)
+    if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
+  if (res_rprog.n == 0) {
+    res_rprog.alloc((size_t)2 * RP_MAX * RES_STRIDE);
+    res_rprog.zero(stream);
+    CICE_HIP(hipStreamSynchronize(stream));
+  }
+}
+
+void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n) {
+  CICE_REQUIRE(ready, "cice_evp_peer_connect before cice_evp_init");
+  CICE_REQUIRE(side == 0 || side == 1, "side must be 0 (south) or 1 (north)");
+  CICE_REQUIRE(xu0 && xu1 && rprog && peer_n > 0 && peer_n < (1ll << 28), "bad peer buffers");
+  peer_alloc();
+  peers[side].xu[0] = (double*)xu0;
+  peers[side].xu[1] = (double*)xu1;
+  peers[side].rprog = (unsigned*)rprog;
+  peers[side].n = (unsigned)peer_n;
+  res_w = 0;   // rebuild the dependency lists
+}
+
+bool Evp::can_reside_peer() const {
+  if (!resident_on || resident_failed || !halo.multi_rank()) return false;
+  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold() || dom.nbx != 1 || dom.npx != 1) return false;
+  if (dom.ns == BND_TRIPOLE) return false;
+  // every neighbour this slab has must be connected
+  const Block& bl = dom.all[dom.local[0]];
+  const bool has_s = bl.jb > 0 || dom.ns == BND_CYCLIC, has_n = bl.jb < dom.nby - 1 || dom.ns == BND_CYCLIC;
+  if ((has_s && !peers[0].rprog) || (has_n && !peers[1].rprog)) return false;
+  return resident_waves() > 0;
+}
+
+void Evp::build_resident_peer(int W) {
+  const int nx = dom.nx_block, ny = dom.ny_block;
+  const Block& bl = dom.all[dom.local[0]];
+  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
+  const int tiles_x = ((nx - 2) + (TX - 1) - 1) / (TX - 1), tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1);
+  const int nt = tiles_x * tiles_y;
+  CICE_REQUIRE(nt <= RP_MAX, "resident EVP loop across ranks: too many tiles");
+  const size_t np = (size_t)nx * ny;
+  // the neighbours' view of the same decomposition (host logic only): their send / receive lists pair up with ours
+  // element by element (Domain::build visits the ghost cells in one global order)
+  std::map<int, Domain> pd;
+  auto peer_dom = [&](int prank) -> const Domain& {
+    auto it = pd.find(prank);
+    if (it == pd.end()) {
+      Domain d;
+      const char* msg = d.create(dom.nxg, dom.nyg, dom.bsx, dom.bsy, dom.ew, dom.ns, prank, dom.npx, dom.npy);
+      CICE_REQUIRE(!msg[0], "resident EVP loop across ranks: cannot rebuild a neighbour's decomposition");
+      it = pd.emplace(prank, std::move(d)).first;
+    }
+    return it->second;
+  };
+  auto msg_with = [](const std::vector<HaloMsg>& v, int peer) -> const HaloMsg* {
+    for (const HaloMsg& m : v)
+      if (m.peer == peer) return &m;
+    return nullptr;
+  };
+  // my ghost cell -> (side, the neighbour's tile that produces it); my edge cell -> ghost cells of neighbours
+  std::vector<int32_t> rsrc_tile(np, -1);            // dep code (<= -2) of a ghost cell owned by another rank
+  std::vector<int32_t> rslot(np, -1), rfwd;
+  for (const HaloMsg& m : dom.recv) {
+    const Domain& d = peer_dom(m.peer);
+    const HaloMsg* ps = msg_with(d.send, dom.rank);
+    CICE_REQUIRE(ps && ps->addr.size() == m.addr.size(), "resident EVP loop across ranks: message lists do not pair up");
+    const Block& pb = d.all[d.local[0]];
+    CICE_REQUIRE(d.nblocks() == 1 && d.nx_block == nx, "resident EVP loop across ranks: the neighbour is not one full-width slab");
+    for (size_t e = 0; e < m.addr.size(); ++e) {
+      const int q = m.addr[e], gj = q / nx + 1;
+      const int side = gj < jlo ? 0 : 1;
+      const int sq = ps->addr[e], si = sq % nx + 1, sj = sq / nx + 1;
+      const int ptile = ((sj - pb.jlo) / (W - 1)) * tiles_x + (si - pb.ilo) / (TX - 1);
+      CICE_REQUIRE(ptile >= 0 && ptile < RP_MAX, "resident EVP loop across ranks: neighbour tile out of range");
+      rsrc_tile[q] = -2 - (side * RP_MAX + ptile);
+      rslot[q] = -2;
+    }
+  }
+  for (const HaloMsg& m : dom.send) {
+    const Domain& d = peer_dom(m.peer);
+    const HaloMsg* pr = msg_with(d.recv, dom.rank);
+    CICE_REQUIRE(pr && pr->addr.size() == m.addr.size(), "resident EVP loop across ranks: message lists do not pair up");
+    const Block& pb = d.all[d.local[0]];
+    for (size_t e = 0; e < m.addr.size(); ++e) {
+      const int q = m.addr[e];
+      const int gq = pr->addr[e], gj = gq / d.nx_block + 1;
+      const int side = gj > pb.jhi ? 0 : 1;          // on the neighbour's TOP ghost row: the neighbour lies to the south
+      CICE_REQUIRE(gq < (1 << 30), "resident EVP loop across ranks: neighbour plane too large");
+      int32_t& sl = rslot[q];
+      if (sl < 0) {
+        sl = (int32_t)(rfwd.size() / 4);
+        rfwd.insert(rfwd.end(), {-1, -1, -1, -1});
+      }
+      int k = 0;
+      while (k < 4 && rfwd[4 * sl + k] >= 0) ++k;
+      CICE_REQUIRE(k < 4, "resident EVP loop across ranks: a cell is mirrored by more than four remote ghost cells");
+      rfwd[4 * sl + k] = (side << 30) | gq;
+    }
+  }
+  if (rfwd.empty()) rfwd.assign(4, -1);
+  std::vector<int32_t> src_of(np, -1);
+  for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
+  auto owner = [&](int i, int j) -> int {   // 1-based cell -> tile producing its velocity: local >= 0, remote <= -2, -1 nobody
+    if (i < 1 || i > nx || j < 1 || j > ny) return -1;
+    int q = (j - 1) * nx + (i - 1);
+    if (rsrc_tile[q] <= -2) return rsrc_tile[q];
+    if (src_of[q] >= 0) q = src_of[q];
+    const int si = q % nx + 1, sj = q / nx + 1;
+    if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
+    return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
+  };
+  std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
+  for (int t = 0; t < nt; ++t) {
+    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    int nd = 0;
+    auto add = [&](int i, int j) {
+      const int o = owner(i, j);
+      if (o == -1 || o == t) return;
+      for (int k = 0; k < nd; ++k)
+        if (deps[(size_t)t * RES_MAXDEP + k] == o) return;
+      CICE_REQUIRE(nd < RES_MAXDEP, "resident EVP loop: a tile has more producers than RES_MAXDEP");
+      deps[(size_t)t * RES_MAXDEP + nd++] = o;
+    };
+    for (int w = -1; w < W; ++w)
+      for (int lx = -1; lx < TX; ++lx) {
+        const int i = i0 + lx, j = j0 + w;
+        if (i > ihi + 1 || j > jhi + 1) continue;
+        const bool uown = lx >= 0 && w >= 0 && lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
+        if (!uown) add(i, j);
+      }
+  }
+  std::vector<int32_t> pub(nt, 0);   // tiles whose OWNED U-cells are mirrored on the rank to the south (1) / north (2)
+  for (int j = jlo; j <= jhi; ++j)
+    for (int i = ilo; i <= ihi; ++i) {
+      const int sl = rslot[(size_t)(j - 1) * nx + (i - 1)];
+      if (sl < 0) continue;
+      const int t = ((j - jlo) / (W - 1)) * tiles_x + (i - ilo) / (TX - 1);
+      for (int k = 0; k < 4; ++k)
+        if (rfwd[4 * sl + k] >= 0) pub[t] |= 1 << ((rfwd[4 * sl + k] >> 30) & 1);
+    }
+  res_pub.alloc(pub.size());
+  res_pub.upload(pub.data(), stream);
+  res_deps.alloc(deps.size());
+  res_deps.upload(deps.data(), stream);
+  res_rslot.alloc(rslot.size());
+  res_rslot.upload(rslot.data(), stream);
+  res_rfwd.alloc(rfwd.size());
+  res_rfwd.upload(rfwd.data(), stream);
+  res_prog.alloc((size_t)(nt + 1) * RES_STRIDE);
+  res_prog.zero(stream);
+  peer_alloc();
+  CICE_HIP(hipStreamSynchronize(stream));
+  res_w = W;
+  res_tiles = nt;
+  res_peer_built = true;
 }
 
 // producer tiles of every tile's halo: the cells it re-reads each subcycle, traced through the on-rank ghost copies
@@ -2481,26 +2783,42 @@ void Evp::build_resident(int W) {
   CICE_HIP(hipStreamSynchronize(stream));
   res_w = W;
   res_tiles = nt;
+  res_peer_built = false;
 }
 
 template <int W>
-static void launch_res(const ResArgs& r, bool damp, dim3 g, hipStream_t s) {
-  if (damp) hipLaunchKernelGGL((k_evp_resident<W, true>), g, dim3(64 * W), 0, s, r);
-  else hipLaunchKernelGGL((k_evp_resident<W, false>), g, dim3(64 * W), 0, s, r);
+static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream_t s) {
+  if (peer) {
+    if constexpr (W <= 11) {   // (12 wavefronts + the table of remote ghost cells do not fit the LDS)
+      if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, true>), g, dim3(64 * W), 0, s, r);
+      else hipLaunchKernelGGL((k_evp_resident<W, false, true>), g, dim3(64 * W), 0, s, r);
+    } else {
+      throw Error{CICE_EINVAL, "resident EVP loop across ranks: at most 11 wavefronts per workgroup"};
+    }
+  } else {
+    if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false>), g, dim3(64 * W), 0, s, r);
+    else hipLaunchKernelGGL((k_evp_resident<W, false, false>), g, dim3(64 * W), 0, s, r);
+  }
 }
 
 // subcycles ksub0 .. ksub0+nsub-1 in one launch; false: not done (time-out), the state is as it was
 bool Evp::run_resident(int ksub0, int nsub) {
+  const bool peer = halo.multi_rank();
   const int W = resident_waves();
-  if (W != res_w || res_deps.n == 0) {
+  if (W != res_w || res_deps.n == 0 || peer != res_peer_built) {
     try {
-      build_resident(W);
-    } catch (const Error&) {   // e.g. a tile with more producers than RES_MAXDEP: not a domain for this loop
+      if (peer) build_resident_peer(W);
+      else build_resident(W);
+    } catch (const Error& e) {   // e.g. a tile with more producers than RES_MAXDEP: not a domain for this loop
+      if (peer) std::fprintf(stderr, "cice4_amd: resident EVP loop across ranks not possible: %s\n", e.msg.c_str());
       resident_failed = true;
       return false;
     }
   }
-  if (res_epoch > 0x70000000u) {   // progress words are compared modulo 2^32 over at most 2^31
+  // progress words are compared modulo 2^32 over at most 2^31.  (Across ranks every rank runs the same sequence of
+  // launches, so the epochs -- and this reset -- stay in step; the neighbours' words about us are theirs to reset.)
+  if (res_epoch > 0x70000000u) {
+    CICE_REQUIRE(!peer, "resident EVP loop across ranks: progress epoch exhausted (re-create the context)");
     res_prog.zero(stream);
     res_epoch = 0;
   }
@@ -2517,32 +2835,46 @@ bool Evp::run_resident(int ksub0, int nsub) {
   r.xu[0] = res_xu[0].p;
   r.xu[1] = res_xu[1].p;
   r.spin_ticks = (long long)res_spin_us * 100;   // wall_clock64() runs at 100 MHz
+  if (peer) {
+    r.rslot = res_rslot.p;
+    r.rfwd = res_rfwd.p;
+    r.rprog = res_rprog.p;
+    r.pub = res_pub.p;
+    for (int sd = 0; sd < 2; ++sd) {
+      r.pxu[sd][0] = peers[sd].xu[0];
+      r.pxu[sd][1] = peers[sd].xu[1];
+      r.pn[sd] = peers[sd].n;
+      // on the neighbour to the south we are the neighbour to the north (side 1), and vice versa
+      r.prp[sd] = peers[sd].rprog ? peers[sd].rprog + (size_t)(1 - sd) * RP_MAX * RES_STRIDE : nullptr;
+    }
+  }
   for (int k = 0; k < 2; ++k)   // cells nobody publishes keep their value: both exchange copies start as (u, v)
     CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
   const dim3 g(8 * ((res_tiles + 7) / 8));
   const bool damp = sc.evp_damping != 0;
-  const bool dense = resident_dense();
+  const bool dense = !peer && resident_dense();
   switch (W) {
-    case 4: launch_res<4>(r, damp, g, stream); break;
-    case 6: launch_res<6>(r, damp, g, stream); break;
-    case 8: launch_res<8>(r, damp, g, stream); break;
-    case 11: launch_res<11>(r, damp, g, stream); break;
-    case 12: launch_res<12>(r, damp, g, stream); break;
+    case 4: launch_res<4>(r, damp, peer, g, stream); break;
+    case 6: launch_res<6>(r, damp, peer, g, stream); break;
+    case 8: launch_res<8>(r, damp, peer, g, stream); break;
+    case 11: launch_res<11>(r, damp, peer, g, stream); break;
+    case 12: launch_res<12>(r, damp, peer, g, stream); break;
     default: throw Error{CICE_EINVAL, "resident_waves must be 4, 6, 8, 11 or 12"};
   }
   CICE_HIP(hipGetLastError());
   unsigned aborted = 0;
+  if (peer && res_peer_agree) halo.all_max_u32(r.abort_flag);   // every rank falls back, or none does
   CICE_HIP(hipMemcpyAsync(&aborted, r.abort_flag, 4, hipMemcpyDeviceToHost, stream));
   CICE_HIP(hipStreamSynchronize(stream));
-  res_epoch += (unsigned)nsub;
+  res_epoch += (unsigned)nsub + (peer ? 3u : 0u);
   if (aborted) {
-    std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident); this range runs as one "
-                         "launch per pair of subcycles%s\n",
+    std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident%s); this range runs as one "
+                         "launch per pair of subcycles%s\n", peer ? ", here or on another rank" : "",
                  dense ? ", later ones with one workgroup per CU" : " and so do later ones");
     if (dense) res_level = 1;   // not every slot of the chip was free: one workgroup per CU from now on
     else resident_failed = true;
     res_prog.zero(stream);
-    res_epoch = 0;
+    if (!peer) res_epoch = 0;   // (across ranks the neighbours hold words about us: the epoch only ever grows)
     return false;
   }
   cur = 1 - cur;   // the result is in the other copy whatever the parity of nsub
@@ -2600,7 +2932,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     build_skew_rows(K, ((dom.nx_block - 2) + 1 + ownl - 1) / ownl, ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
   bool replayed = false;
-  if (nsub >= 2 && can_reside()) replayed = run_resident(ksub0, nsub);
+  if (nsub >= 2 && (can_reside() || can_reside_peer())) replayed = run_resident(ksub0, nsub);
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +

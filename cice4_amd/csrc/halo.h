@@ -13,6 +13,14 @@ struct ncclComm;
 
 namespace cice {
 
+// In-process stand-in for the RCCL communicator: the ranks of one "link" are contexts of ONE process (one host
+// thread each), on one GPU or several; a message travels device -> host mailbox -> device.  What the reference's
+// serial/ directory is to its mpi/ one: the whole multi-rank path -- message lists, pack / unpack kernels, wide-halo
+// refresh, the cross-rank resident loop's agreement -- runs and can be checked on a box with a single GPU, where
+// RCCL refuses two ranks on one device.  Slow by construction (every message synchronises the stream); tests only.
+struct LocalLink;
+LocalLink* local_link_get(int link_id, int nranks);   // the link of that id (created on first use; sizes must agree)
+
 class Halo {
  public:
   Halo() = default;
@@ -21,6 +29,7 @@ class Halo {
   // The RCCL communicator belongs to the CONTEXT (it outlives a change of the block decomposition); a Halo
   // borrows it.
   void set_comm(ncclComm* c, int rank, int nranks);
+  void set_link(LocalLink* l, int rank, int nranks);
   bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
   bool has_refresh() const { return remote_ || nrefresh_ > 0 || nfill_ > 0; }
   // nfields fields of element type T, field k starting at base + k*stride (elements).
@@ -36,6 +45,9 @@ class Halo {
   void update_r4(float* base, int nfields, size_t stride, int loc = LOC_CENTER, int kind = KIND_SCALAR,
                  float fill = 0.0f);
   bool has_fold() const { return fold_; }
+  // in-place maximum of one 32-bit word over the ranks (control decisions every rank has to take alike); no-op
+  // without a communicator
+  void all_max_u32(unsigned* dev_word);
   // Device pointers to the on-rank copy list, for kernels that fold it in.
   const int32_t* d_src() const { return src_.p; }
   const int32_t* d_dst() const { return dst_.p; }
@@ -76,6 +88,11 @@ class Halo {
   int cap_fields_ = 0, total_s_ = 0, total_r_ = 0, generation_ = 0;
   void reserve(int nfields);          // grows the message buffers (never shrinks)
   ncclComm* comm_ = nullptr;
+  LocalLink* link_ = nullptr;
+  template <class T>
+  void link_exchange(const T* sb, T* rb, int nfields, const std::vector<int>& speer, const std::vector<int>& soff,
+                     const std::vector<int>& scnt, int ns, const std::vector<int>& rpeer, const std::vector<int>& roff,
+                     const std::vector<int>& rcnt, int nr);
   static constexpr int MINF = 14;     // u, v and the 12 stresses in one message: allocated up front
 };
 

@@ -3,7 +3,12 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <type_traits>
 
 namespace cice {
@@ -14,6 +19,41 @@ namespace cice {
     if (r_ != ncclSuccess)                                                                      \
       throw ::cice::Error{CICE_ECOMM, std::string(#expr) + ": " + ncclGetErrorString(r_)};      \
   } while (0)
+
+// ---- in-process link (halo.h) ------------------------------------------------------------------------------------
+struct LocalLink {
+  int nranks = 0;
+  std::mutex m;
+  std::condition_variable cv;
+  // box[src * nranks + dst]: the message src posted for dst, its sequence number, and the last one dst has taken
+  std::vector<std::vector<char>> box;
+  std::vector<long> posted, taken;
+  // all-reduce of one word
+  std::vector<unsigned> red_val;
+  std::vector<long> red_seq;
+};
+
+LocalLink* local_link_get(int link_id, int nranks) {
+  static std::mutex gm;
+  static std::map<int, std::unique_ptr<LocalLink>> links;
+  std::lock_guard<std::mutex> g(gm);
+  auto& l = links[link_id];
+  if (!l) {
+    l.reset(new LocalLink());
+    l->nranks = nranks;
+    l->box.resize((size_t)nranks * nranks);
+    l->posted.assign((size_t)nranks * nranks, 0);
+    l->taken.assign((size_t)nranks * nranks, 0);
+    l->red_val.assign(nranks, 0);
+    l->red_seq.assign(nranks, 0);
+  }
+  if (l->nranks != nranks) throw Error{CICE_EINVAL, "cice_comm_init_local: this link exists with another number of ranks"};
+  return l.get();
+}
+
+namespace {
+constexpr int LINK_WAIT_S = 60;   // a rank whose partner never shows up fails instead of hanging
+}
 
 namespace {
 
@@ -227,6 +267,53 @@ void Halo::set_comm(ncclComm* c, int rank, int nranks) {
   comm_ = c;
 }
 
+void Halo::set_link(LocalLink* l, int rank, int nranks) {
+  CICE_REQUIRE(rank == rank_ && nranks == nranks_, "cice_comm_init_local: rank/nranks differ from cice_domain_create");
+  link_ = l;
+}
+
+// One exchange through the in-process link: the packed send buffer goes to the host and into the partners' mailboxes,
+// theirs come back the same way.  Every rank of a link makes the same sequence of calls (the halo updates of the
+// model are collective), so a per-Halo call counter pairs the messages up.
+template <class T>
+void Halo::link_exchange(const T* sb, T* rb, int nfields, const std::vector<int>& speer, const std::vector<int>& soff,
+                         const std::vector<int>& scnt, int ns, const std::vector<int>& rpeer,
+                         const std::vector<int>& roff, const std::vector<int>& rcnt, int nr) {
+  LocalLink& L = *link_;
+  const int R = L.nranks;
+  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
+  CICE_HIP(hipStreamSynchronize(stream_));   // the pack kernel has run
+  for (int m = 0; m < ns; ++m) {
+    const size_t bytes = (size_t)nfields * scnt[m] * sizeof(T);
+    std::vector<char> tmp(bytes);
+    CICE_HIP(hipMemcpy(tmp.data(), sb + (size_t)nfields * soff[m], bytes, hipMemcpyDeviceToHost));
+    std::unique_lock<std::mutex> lk(L.m);
+    const size_t slot = (size_t)rank_ * R + speer[m];
+    // the partner has taken the previous message of this pair
+    if (!L.cv.wait_until(lk, deadline, [&] { return L.taken[slot] == L.posted[slot]; }))
+      throw Error{CICE_ECOMM, "in-process link: the partner rank did not take the previous message (is it running?)"};
+    L.box[slot].swap(tmp);
+    L.posted[slot] += 1;       // messages of a (sender, receiver) pair are numbered by the pair
+    L.cv.notify_all();
+  }
+  for (int m = 0; m < nr; ++m) {
+    const size_t bytes = (size_t)nfields * rcnt[m] * sizeof(T);
+    std::vector<char> tmp;
+    {
+      std::unique_lock<std::mutex> lk(L.m);
+      const size_t slot = (size_t)rpeer[m] * R + rank_;
+      if (!L.cv.wait_until(lk, deadline, [&] { return L.posted[slot] == L.taken[slot] + 1; }))
+        throw Error{CICE_ECOMM, "in-process link: no message from the partner rank (is it running?)"};
+      if (L.box[slot].size() != bytes)
+        throw Error{CICE_ECOMM, "in-process link: the ranks are not making the same sequence of halo updates"};
+      tmp.swap(L.box[slot]);
+      L.taken[slot] += 1;
+      L.cv.notify_all();
+    }
+    CICE_HIP(hipMemcpy(rb + (size_t)nfields * roff[m], tmp.data(), bytes, hipMemcpyHostToDevice));
+  }
+}
+
 // pack -> grouped RCCL send/recv -> unpack for one set of message lists
 template <class T>
 void Halo::exchange(const T* src_base, size_t src_stride, T* dst_base, size_t dst_stride, int nfields,
@@ -237,13 +324,22 @@ void Halo::exchange(const T* src_base, size_t src_stride, T* dst_base, size_t ds
   const int total_s = ns ? soff.back() + scnt.back() : 0;
   const int total_r = nr ? roff.back() + rcnt.back() : 0;
   if (!total_s && !total_r) return;
-  CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
+  CICE_REQUIRE(comm_ != nullptr || link_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
   T* sb = reinterpret_cast<T*>(sendbuf_.p);
   T* rb = reinterpret_cast<T*>(recvbuf_.p);
   if (total_s) {
     const int* meta = reinterpret_cast<const int*>(saddr.p + total_s);
     hipLaunchKernelGGL(k_pack<T>, dim3((total_s + 255) / 256), dim3(256), 0, stream_, src_base, nfields,
                        src_stride, saddr.p, total_s, sb, meta, ns);
+  }
+  if (link_) {
+    link_exchange<T>(sb, rb, nfields, speer, soff, scnt, ns, rpeer, roff, rcnt, nr);
+    if (total_r) {
+      const int* meta = reinterpret_cast<const int*>(raddr.p + total_r);
+      hipLaunchKernelGGL(k_unpack<T>, dim3((total_r + 255) / 256), dim3(256), 0, stream_, dst_base, nfields,
+                         dst_stride, raddr.p, total_r, reinterpret_cast<const T*>(recvbuf_.p), meta, nr);
+    }
+    return;
   }
   const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : (std::is_same<T, float>::value ? ncclFloat : ncclInt32);
   CICE_NCCL(ncclGroupStart());
@@ -282,7 +378,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
     // pack and unpack
     const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
     const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
-    CICE_REQUIRE(comm_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
+    CICE_REQUIRE(comm_ != nullptr || link_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
     T* sb = reinterpret_cast<T*>(sendbuf_.p);
     T* rb = reinterpret_cast<T*>(recvbuf_.p);
     if (total_s) {
@@ -290,15 +386,19 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
       hipLaunchKernelGGL(k_pack<T>, dim3((total_s + 255) / 256), dim3(256), 0, stream_, base, nfields,
                          stride, send_addr_.p, total_s, sb, meta, nsend_);
     }
-    const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : (std::is_same<T, float>::value ? ncclFloat : ncclInt32);
-    CICE_NCCL(ncclGroupStart());
-    for (int m = 0; m < nrecv_; ++m)
-      CICE_NCCL(ncclRecv(rb + (size_t)nfields * recv_off_[m], (size_t)nfields * recv_cnt_[m], dt,
-                         recv_peer_[m], (ncclComm_t)comm_, stream_));
-    for (int m = 0; m < nsend_; ++m)
-      CICE_NCCL(ncclSend(sb + (size_t)nfields * send_off_[m], (size_t)nfields * send_cnt_[m], dt,
-                         send_peer_[m], (ncclComm_t)comm_, stream_));
-    CICE_NCCL(ncclGroupEnd());
+    if (link_) {
+      link_exchange<T>(sb, rb, nfields, send_peer_, send_off_, send_cnt_, nsend_, recv_peer_, recv_off_, recv_cnt_, nrecv_);
+    } else {
+      const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : (std::is_same<T, float>::value ? ncclFloat : ncclInt32);
+      CICE_NCCL(ncclGroupStart());
+      for (int m = 0; m < nrecv_; ++m)
+        CICE_NCCL(ncclRecv(rb + (size_t)nfields * recv_off_[m], (size_t)nfields * recv_cnt_[m], dt,
+                           recv_peer_[m], (ncclComm_t)comm_, stream_));
+      for (int m = 0; m < nsend_; ++m)
+        CICE_NCCL(ncclSend(sb + (size_t)nfields * send_off_[m], (size_t)nfields * send_cnt_[m], dt,
+                           send_peer_[m], (ncclComm_t)comm_, stream_));
+      CICE_NCCL(ncclGroupEnd());
+    }
   }
   if (nrefresh_) {  // sources are owned rows, destinations overlap/ghost rows: disjoint from the wrap list's sources
     int t = nrefresh_ * nfields;
@@ -352,6 +452,42 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
     }
   }
   CICE_HIP(hipGetLastError());
+}
+
+void Halo::all_max_u32(unsigned* dev_word) {
+  if (nranks_ <= 1) return;
+  if (link_) {   // in-process link: every rank posts its word, takes the maximum once all have
+    LocalLink& L = *link_;
+    unsigned v = 0;
+    CICE_HIP(hipStreamSynchronize(stream_));
+    CICE_HIP(hipMemcpy(&v, dev_word, 4, hipMemcpyDeviceToHost));
+    std::unique_lock<std::mutex> lk(L.m);
+    const long seq = L.red_seq[rank_] + 1;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
+    // nobody may still be reading the previous round's values
+    if (!L.cv.wait_until(lk, deadline, [&] {
+          for (int r = 0; r < L.nranks; ++r)
+            if (L.red_seq[r] < seq - 1) return false;
+          return true;
+        }))
+      throw Error{CICE_ECOMM, "in-process link: all-reduce out of step"};
+    L.red_val[rank_] = v;
+    L.red_seq[rank_] = seq;
+    L.cv.notify_all();
+    if (!L.cv.wait_until(lk, deadline, [&] {
+          for (int r = 0; r < L.nranks; ++r)
+            if (L.red_seq[r] < seq) return false;
+          return true;
+        }))
+      throw Error{CICE_ECOMM, "in-process link: a rank did not reach the all-reduce"};
+    unsigned mx = 0;
+    for (int r = 0; r < L.nranks; ++r) mx = std::max(mx, L.red_val[r]);
+    lk.unlock();
+    CICE_HIP(hipMemcpy(dev_word, &mx, 4, hipMemcpyHostToDevice));
+    return;
+  }
+  if (!comm_) return;
+  CICE_NCCL(ncclAllReduce(dev_word, dev_word, 1, ncclUint32, ncclMax, (ncclComm_t)comm_, stream_));
 }
 
 void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap, int loc, int kind, double fill) {

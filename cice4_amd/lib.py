@@ -301,6 +301,10 @@ class Context:
         """CiceError unless the host model's ice_domain_size parameters are the library's compile-time sizes"""
         self._ck(self.lib.cice_check_sizes(self.h, ncat, nilyr, nslyr, max_ntrcr))
 
+    def comm_init_local(self, link_id, rank, nranks):
+        """in-process link instead of an RCCL communicator: the ranks are contexts of this process (tests)"""
+        self._ck(self.lib.cice_comm_init_local(self.h, link_id, rank, nranks))
+
     def comm_count(self):
         """ranks of this context's communicator as RCCL counts them (0 before comm_init)"""
         n = C.c_int(0)
@@ -367,6 +371,17 @@ class Context:
         v = C.c_int(0)
         self._ck(self.lib.cice_evp_get_info(self.h, key.encode(), C.byref(v)))
         return v.value
+
+    def evp_peer_export(self):
+        """(xu0, xu1, rprog, plane): device pointers of this rank's exchange copies / progress words and its plane size"""
+        bufs = (C.c_void_p * 3)(); plane = C.c_longlong(0)
+        self._ck(self.lib.cice_evp_peer_export(self.h, bufs, C.byref(plane)))
+        return bufs[0], bufs[1], bufs[2], plane.value
+
+    def evp_peer_connect(self, side, peer):
+        """side 0: `peer` (an evp_peer_export tuple) is the rank to the south, 1: to the north"""
+        self._ck(self.lib.cice_evp_peer_connect(self.h, side, C.c_void_p(peer[0]), C.c_void_p(peer[1]), C.c_void_p(peer[2]),
+                                                C.c_longlong(peer[3])))
 
     def evp_debug(self, what):
         n = C.c_longlong(0)

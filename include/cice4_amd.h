@@ -118,6 +118,11 @@ int cice_domain_halo_msg(const cice_ctx *ctx, int dir, int msg, int *peer, int *
  * distributed by the caller (MPI_Bcast in a Fortran driver, torch.distributed here). */
 int cice_comm_unique_id(char uid[128]);
 int cice_comm_init(cice_ctx *ctx, const char uid[128], int rank, int nranks);
+/* In-process stand-in for the communicator: the ranks of link `link_id` are contexts of THIS process (one host thread
+ * each, on one GPU or several); messages travel device -> host mailbox -> device.  The counterpart of the reference's
+ * serial/ directory next to mpi/: the whole multi-rank path runs on a box with one GPU (RCCL refuses two ranks on one
+ * device).  Tests only -- every message synchronises the stream. */
+int cice_comm_init_local(cice_ctx *ctx, int link_id, int rank, int nranks);
 /* ranks of the communicator as RCCL counts them (ncclCommCount; = MPI_COMM_SIZE of mpi/ice_communicate.F90:109-136);
  * 0 before cice_comm_init */
 int cice_comm_count(cice_ctx *ctx, int *nranks);
@@ -202,6 +207,22 @@ int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
  * (= sum of icellt / icellu, ice_dyn_evp.F90:160-162) */
 int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucells);
+/* The one-launch subcycle loop ACROSS RANKS: one full-width slab per rank (cice_domain_create with npx = 1); the tiles on
+ * a slab's first / last rows exchange their edge velocities with the neighbouring rank's tiles through stores into the
+ * neighbour's exchange copies and progress words (what replaces the two ice_HaloUpdate calls per subcycle,
+ * source/ice_dyn_evp.F90:397-402, mpi/ice_boundary.F90:1028-1417: no message, no host involvement inside the loop).
+ * Every rank exports its buffers (cice_evp_peer_export: device pointers xu0, xu1, progress words, and its plane size),
+ * hands them to its neighbours through its control plane and connects what it receives: side 0 = the rank to the
+ * south, 1 = to the north.  Two contexts of one process on one GPU pass the pointers as they are (tests); processes on
+ * different GPUs use the _ipc forms (hipIpcGetMemHandle / hipIpcOpenMemHandle; handles travel like the ncclUniqueId).
+ * With every neighbour connected, cice_evp_get_info("resident_peer") is 1 and cice_evp / cice_evp_subcycles run the loop
+ * as one launch per rank; a rank whose launch times out raises a flag that is all-reduced over the communicator
+ * ("resident_peer_agree", default 1) so that all ranks fall back to the launch-per-pair loop together.
+ * "resident_peer_share": contexts sharing one device (default 1; the one-GPU test uses 2). */
+int cice_evp_peer_export(cice_ctx *ctx, void *bufs[3], long long *plane);
+int cice_evp_peer_connect(cice_ctx *ctx, int side, void *xu0, void *xu1, void *rprog, long long plane);
+int cice_evp_peer_export_ipc(cice_ctx *ctx, char handles[3][64], long long *plane);
+int cice_evp_peer_connect_ipc(cice_ctx *ctx, int side, const char handles[3][64], long long plane);
 /* Test / tuning aid: `what` = "skew_times" (after cice_evp_set_option("skew_debug", 1)): start and end wall-clock ticks
  * (10 ns) of every workgroup of the last K-subcycle sweep launch.  *count: in = capacity of out (out may be NULL),
  * out = entries available. */

@@ -512,6 +512,108 @@ def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm
     assert nt1 <= nt <= nt1 + nb * (nxg + 2)        # T lists: each block also lists its N/E ghost ring
 
 
+_LINK = [1000]
+
+
+@pytest.mark.parametrize("mode,R,nyg", [("classic", 2, 72), ("peer", 2, 72), ("peer", 3, 72), ("peer", 2, 16), ("slabs4", 2, 72),
+                                       ("slabs4", 3, 72), ("slabs6-sweep", 2, 96), ("peer-cyclic", 2, 40)])
+def test_ranks_in_one_process(orc, mode, R, nyg):
+    """The multi-rank path with R ranks = R contexts of this process on the one GPU, one host thread each, messages through
+    the in-process link (cice_comm_init_local: pack kernel -> host mailbox -> unpack kernel), against the single-domain
+    checker run, bit for bit on every owned cell:
+      classic  one slab per rank, ghost rows exchanged after every subcycle (what the Fortran drop-in does under MPI);
+      peer     the WHOLE subcycle loop as one launch per rank: the tiles on a slab's first / last rows exchange their
+               edge velocities with the neighbouring rank's tiles by stores into the neighbour's exchange copies and
+               progress words (cice_evp_peer_export / _connect: here plain device pointers), no message inside the loop;
+               2 and 3 ranks (a middle rank has two neighbours), slabs one tile tall, cyclic north-south (both
+               neighbours are the same rank);
+      slabs    wide-halo slabs as bench.py --gpus N cuts them (refresh of u, v, 12 sigma every H subcycles), pairs of
+               subcycles per launch and, "sweep", K subcycles per sweep between the refreshes."""
+    import threading
+    nxg = 96
+    ns = 1 if mode == "peer-cyclic" else 0
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    _LINK[0] += 1
+    link = _LINK[0]
+    bar = threading.Barrier(R)
+    exports, out, errs = [None] * R, [None] * R, []
+
+    def rank_fn(r):
+        try:
+            c = lib.Context(device=0); c.sync()
+            if mode.startswith("slabs"):
+                H = int(mode[5])
+                dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=H)
+            else:
+                dom = c.domain_create(nxg, nyg, nxg, nyg // R, ew=1, ns=ns, rank=r, npx=1, npy=R)
+            assert dom["nblocks"] == 1 and dom["nsend"] >= 1
+            c.comm_init_local(link, r, R)
+            grid = synth.block_fields(gg, dom)
+            s = synth.evp_state(grid, dom, seed=31, cover="patchy")
+            c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+            if mode.startswith("peer"):
+                c.evp_set_option("resident_peer_share", R)
+                exports[r] = c.evp_peer_export()
+                bar.wait(timeout=60)
+                if r > 0 or ns == 1:
+                    c.evp_peer_connect(0, exports[(r - 1) % R])
+                if r < R - 1 or ns == 1:
+                    c.evp_peer_connect(1, exports[(r + 1) % R])
+                assert c.evp_get_info("resident_peer") == 1
+                bar.wait(timeout=60)
+            else:
+                c.evp_set_option("resident", 0)
+                if mode.endswith("sweep"):
+                    c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", 3)
+                    assert c.evp_get_info("skew") == 1
+                else:
+                    c.evp_set_option("skew", 0)
+            c.evp(DT, s)
+            if mode.startswith("peer"):
+                assert c.evp_get_info("resident_peer") == 1, "the cross-rank loop timed out and fell back"
+            out[r] = (dom, s)
+            bar.wait(timeout=120)        # nobody frees buffers a neighbour may still be writing to
+        except BaseException as e:       # noqa: BLE001 -- reported by the main thread
+            errs.append((r, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, errs
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
+        want = _owned(one, s1[k])
+        got = np.zeros_like(want)
+        for r in range(R):
+            dom, s = out[r]
+            part = _owned(dom, s[k])
+            rows = slice(int(dom["j0"][0] + dom["own_jlo"][0] - dom["jlo"][0]),
+                         int(dom["j0"][0] + dom["own_jhi"][0] - dom["jlo"][0]) + 1)
+            got[rows] = part[rows]
+        assert np.array_equal(got, want), (mode, R, k, np.argwhere(got != want)[:5])
+    # ghost rows a neighbour owns are current after evp(dt) (the last exchange of the loop, ice_dyn_evp.F90:397-402)
+    if not mode.startswith("slabs"):
+        for r in range(R):
+            dom, s = out[r]
+            j0, jlo, jhi = int(dom["j0"][0]), int(dom["jlo"][0]), int(dom["jhi"][0])
+            for gj, jg in ((jlo - 2, j0 - 1), (jhi, j0 + (jhi - jlo) + 1)):     # array row, global row
+                if ns == 1:
+                    jg %= nyg
+                if 0 <= jg < nyg:
+                    assert np.array_equal(s["uvel"][0, gj, 1:-1], s1["uvel"][0, jg + 1, 1:-1]), (mode, r, gj)
+
+
 def _evp_with(ctx, grid, s, ndte, damping, **opts):
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
