@@ -277,11 +277,16 @@ static T fold_avg_host(T x1, T x2, int sgn) {
   return (T)0.5 * (x1 + (T)sgn * x2);
 }
 
+// strides (in elements) of the caller's array: level (z1, z2) of block b starts at b * sb + z2 * s2 + z1 * s1; the
+// contiguous (nx, ny, nz, nblocks) array is nz1 = nz, s1 = np, nz2 = 1, sb = nz * np
+struct LevelStrides { int nz1, nz2; size_t s1, s2, sb; };
+
 template <class T>
-static void halo_host_lists(const Domain& dm, T* field, int nz, int loc, int kind, T fill) {
+static void halo_host_lists(const Domain& dm, T* field, const LevelStrides& ls, int loc, int kind, T fill) {
   const size_t np = (size_t)dm.nx_block * dm.ny_block;
   // list address (level-major numbering: block * np + cell) -> element of level 0 in the caller's layout
-  auto at = [&](int32_t a) { const size_t b = (size_t)a / np; return b * (size_t)nz * np + ((size_t)a - b * np); };
+  auto at = [&](int32_t a) { const size_t b = (size_t)a / np; return b * ls.sb + ((size_t)a - b * np); };
+  const int nz = ls.nz1 * ls.nz2;
   const bool fold = dm.fold;
   if (fold) {
     CICE_REQUIRE(loc >= LOC_CENTER && loc <= LOC_EFACE, "halo: field location unknown on a tripole grid");
@@ -290,7 +295,7 @@ static void halo_host_lists(const Domain& dm, T* field, int nz, int loc, int kin
   const int sgn = kind == KIND_SCALAR ? 1 : -1;
   std::vector<T> buf(fold ? 2 * (size_t)dm.nxg : 0);
   for (int z = 0; z < nz; ++z) {
-    T* f = field + (size_t)z * np;
+    T* f = field + (size_t)(z % ls.nz1) * ls.s1 + (size_t)(z / ls.nz1) * ls.s2;
     for (size_t e = 0; e < dm.hsrc.size(); ++e) f[at(dm.hdst[e])] = f[at(dm.hsrc[e])];
     for (int32_t a : dm.hfill) f[at(a)] = fill;
     for (size_t e = 0; e < dm.rsrc.size(); ++e) f[at(dm.rdst[e])] = f[at(dm.rsrc[e])];
@@ -320,7 +325,8 @@ static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, 
   CICE_REQUIRE(c->have_domain, "cice_domain_create has not been called");
   static const bool force_dev = std::getenv("CICE4_AMD_HALO_HOST_ON_DEVICE") != nullptr;   // test aid: the frame path
   if (!domain_has_messages(c->dom) && !force_dev) {
-    halo_host_lists<T>(c->dom, field, nz, loc, kind, (T)fill);
+    const size_t np_ = (size_t)c->dom.nx_block * c->dom.ny_block;
+    halo_host_lists<T>(c->dom, field, LevelStrides{nz, 1, np_, 0, (size_t)nz * np_}, loc, kind, (T)fill);
     return;
   }
   c->need_halo();
@@ -383,6 +389,33 @@ static void halo_host_blocked(cice_ctx* c, T* field, int nz, int loc, int kind, 
                                 np * sizeof(T), nz, hipMemcpyDeviceToHost, c->stream));
   }
   CICE_HIP(hipStreamSynchronize(c->stream));
+}
+
+// The same for a SECTION of a 4-d module array, e.g. trcrn(:,:,1:ntrcr,:,:) in bound_state (source/ice_state.F90:206): the
+// horizontal planes are whole, the levels (z1, z2) and the blocks are strided.  On a one-rank domain the lists are
+// applied in place (no copy of the section: that copy was most of the model's Bound timer); otherwise the section is
+// gathered into a contiguous array, updated by the general path and scattered back.
+template <class T>
+static void halo_host_strided(cice_ctx* c, T* field, const LevelStrides& ls, int loc, int kind, double fill) {
+  CICE_REQUIRE(field && ls.nz1 >= 1 && ls.nz2 >= 1, "bad argument");
+  CICE_REQUIRE(c->have_domain, "cice_domain_create has not been called");
+  const size_t np = (size_t)c->dom.nx_block * c->dom.ny_block;
+  const int nb = c->dom.nblocks(), nz = ls.nz1 * ls.nz2;
+  static const bool force_dev = std::getenv("CICE4_AMD_HALO_HOST_ON_DEVICE") != nullptr;
+  if (!domain_has_messages(c->dom) && !force_dev) {
+    halo_host_lists<T>(c->dom, field, ls, loc, kind, (T)fill);
+    return;
+  }
+  std::vector<T> tmp((size_t)nb * nz * np);
+  for (int b = 0; b < nb; ++b)
+    for (int z = 0; z < nz; ++z)
+      std::memcpy(tmp.data() + ((size_t)b * nz + z) * np,
+                  field + (size_t)b * ls.sb + (size_t)(z / ls.nz1) * ls.s2 + (size_t)(z % ls.nz1) * ls.s1, np * sizeof(T));
+  halo_host_blocked<T>(c, tmp.data(), nz, loc, kind, fill);
+  for (int b = 0; b < nb; ++b)
+    for (int z = 0; z < nz; ++z)
+      std::memcpy(field + (size_t)b * ls.sb + (size_t)(z / ls.nz1) * ls.s2 + (size_t)(z % ls.nz1) * ls.s1,
+                  tmp.data() + ((size_t)b * nz + z) * np, np * sizeof(T));
 }
 
 // Device-resident form: the field already lives in device memory (nlev levels of nblocks*ny_block*nx_block
@@ -727,6 +760,18 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   c_->evp->download(*f);
   CICE_CATCH
 }
+// f1 hand-off: the state the batched thermodynamic step left on the device becomes the dynamics' input without crossing
+// PCIe (valid when nothing on the host has changed aicen / vicen / vsnon since: the caller's statement).
+int cice_evp_adopt_thermo_state(cice_ctx* ctx) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  auto& t = c_->tb;
+  CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
+  CICE_REQUIRE(t.nx == c_->dom.nx_block && t.ny == c_->dom.ny_block && t.nb == c_->dom.nblocks(),
+               "cice_evp_adopt_thermo_state: the thermodynamic batch has another block layout than the dynamics");
+  c_->evp->adopt_state(t.aicen.p, t.vicen.p, t.vsnon.p);
+  CICE_CATCH
+}
 int cice_evp_pin_fields(cice_ctx* ctx, const cice_evp_fields* f) {
   CICE_TRY(ctx)
   NEED_EVP;
@@ -902,6 +947,14 @@ int cice_halo_update_blocked_r4(cice_ctx* ctx, float* field, int nz, int loc, in
 }
 int cice_halo_update_blocked_i4(cice_ctx* ctx, int32_t* field, int nz, int loc, int kind, int32_t fill) {
   CICE_TRY(ctx) halo_host_blocked<int32_t>(c_, field, nz, loc, kind, fill); CICE_CATCH
+}
+int cice_halo_update_strided_r8(cice_ctx* ctx, double* field, int nz1, long long stride1, int nz2, long long stride2,
+                                long long stride_block, int loc, int kind, double fill) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(stride1 >= 0 && stride2 >= 0 && stride_block >= 0, "negative stride");
+  halo_host_strided<double>(c_, field, LevelStrides{nz1, nz2, (size_t)stride1, (size_t)stride2, (size_t)stride_block}, loc,
+                            kind, fill);
+  CICE_CATCH
 }
 int cice_halo_update_dev_ex_r8(cice_ctx* ctx, double* dev_field, int nlev, int loc, int kind, double fill) {
   CICE_TRY(ctx) halo_dev<double>(c_, dev_field, nlev, loc, kind, fill); CICE_CATCH

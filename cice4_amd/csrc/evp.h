@@ -23,6 +23,7 @@ class Evp {
   ~Evp();
   void init(const cice_evp_config& cfg, const cice_evp_grid& g);
   void upload(const cice_evp_fields& f);
+  void adopt_state(const double* d_aicen, const double* d_vicen, const double* d_vsnon);
   void download(cice_evp_fields& f);
   void prepare(double dt);
   void subcycles(int ksub0, int nsub, float* elapsed_ms);
@@ -69,6 +70,7 @@ class Evp {
   cice_evp_config cfg{};
   EvpScalars sc{};
   bool ready = false, prepared = false, counted = false;
+  bool adopted = false;   // aice, vice, vsno, aice0, aicen, vicen came from adopt_state: the next upload may omit them
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
   bool comm_graph = false;   // multi-rank loops: capture the RCCL calls too (opt-in)

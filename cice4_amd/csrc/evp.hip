@@ -2090,9 +2090,13 @@ void Evp::upload(const cice_evp_fields& f) {
             {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx}, {&strocny, f.strocny},
             {&strintx, f.strintx}, {&strinty, f.strinty}};
   for (U& x : us) {
+    // after adopt_state the six state fields are on the device already: a NULL pointer keeps them
+    const bool state6 = x.d == &aice || x.d == &vice || x.d == &vsno || x.d == &aice0 || x.d == &aicen || x.d == &vicen;
+    if (adopted && state6 && x.h == nullptr) continue;
     CICE_REQUIRE(x.h != nullptr, "cice_evp_upload: NULL field");
     x.d->upload(x.h, stream);
   }
+  adopted = false;
   CICE_REQUIRE(f.uvel && f.vvel && f.iceumask, "cice_evp_upload: NULL field");
   CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, stream));
   CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, stream));
@@ -2181,6 +2185,38 @@ long long Evp::debug_read(const char* what, long long* out, long long cap) {
   const long long nn = (long long)skew_dbg.n;
   if (out && nn) CICE_HIP(hipMemcpy(out, skew_dbg.p, (size_t)std::min(nn, cap) * 8, hipMemcpyDeviceToHost));
   return nn;
+}
+
+// aggregate (source/ice_itd.F90:279-): the category sums the dynamics read, formed in the reference's order
+__global__ __launch_bounds__(256) void k_aggregate(size_t np, int nb, int ncat, const double* __restrict__ aicen,
+                                                   const double* __restrict__ vicen, const double* __restrict__ vsnon,
+                                                   double* __restrict__ aice, double* __restrict__ vice,
+                                                   double* __restrict__ vsno, double* __restrict__ aice0) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np * nb) return;
+  const size_t b = t / np, q = t - b * np;
+  double a = c0, v = c0, s = c0;
+  for (int n = 0; n < ncat; ++n) {
+    const size_t c = (b * ncat + n) * np + q;
+    a = a + aicen[c];
+    v = v + vicen[c];
+    s = s + vsnon[c];
+  }
+  aice[t] = a; vice[t] = v; vsno[t] = s;
+  aice0[t] = fmax(c1 - a, c0);
+}
+
+// The ice state of the dynamics taken from arrays that are ALREADY on the device (the batched thermodynamic step's):
+// aicen, vicen copied, aice, vice, vsno, aice0 aggregated here; the next upload() leaves those six alone.
+void Evp::adopt_state(const double* d_aicen, const double* d_vicen, const double* d_vsnon) {
+  CICE_REQUIRE(ready, "cice_evp_adopt_thermo_state before cice_evp_init");
+  CICE_HIP(hipMemcpyAsync(aicen.p, d_aicen, (size_t)NCAT * n * 8, hipMemcpyDeviceToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(vicen.p, d_vicen, (size_t)NCAT * n * 8, hipMemcpyDeviceToDevice, stream));
+  const size_t np = (size_t)dom.nx_block * dom.ny_block;
+  hipLaunchKernelGGL(k_aggregate, grid1(n), dim3(256), 0, stream, np, dom.nblocks(), NCAT, (const double*)aicen.p,
+                     (const double*)vicen.p, d_vsnon, aice.p, vice.p, vsno.p, aice0.p);
+  CICE_HIP(hipGetLastError());
+  adopted = true;
 }
 
 bool Evp::derives_metrics() const { return derive_ok && derive_on; }

@@ -247,6 +247,14 @@ module cice4_amd_c
          integer(c_int) :: field(*)
          integer(c_int), value :: nz, loc, kind, fill
       end function
+      integer(c_int) function cice_halo_update_strided_r8(ctx, field, nz1, stride1, nz2, stride2, stride_block, &
+            loc, kind, fill) bind(C, name='cice_halo_update_strided_r8')
+         import
+         type(c_ptr), value :: ctx, field
+         integer(c_int), value :: nz1, nz2, loc, kind
+         integer(c_long_long), value :: stride1, stride2, stride_block
+         real(c_double), value :: fill
+      end function
       integer(c_int) function cice_comm_unique_id(uid) bind(C, name='cice_comm_unique_id')
          import
          character(kind=c_char), intent(out) :: uid(128)

@@ -235,12 +235,44 @@ contains
    end subroutine ice_HaloUpdate3DI4
 
    subroutine ice_HaloUpdate4DR8(array, halo, fieldLoc, fieldKind, fillValue)
-      real (dbl_kind), dimension(:,:,:,:,:), intent(inout), contiguous :: array
+      ! no `contiguous` here: bound_state passes the section trcrn(:,:,1:ntrcr,:,:) (ice_state.F90:206), and a
+      ! contiguous dummy would make the compiler copy 25 planes in and out around every call.  Whole horizontal planes
+      ! with strided levels / blocks go to the library as they lie; anything else through a contiguous copy.
+      real (dbl_kind), dimension(:,:,:,:,:), intent(inout), target :: array
       type (ice_halo), intent(in) :: halo
       integer (int_kind), intent(in) :: fieldKind, fieldLoc
       real (dbl_kind), intent(in), optional :: fillValue
-      call update_r8(array, size(array,1), size(array,2), size(array,3)*size(array,4), size(array,5), halo, 'ice_HaloUpdate4DR8', &
-                     fieldLoc, fieldKind, fillValue)
+      real (dbl_kind), allocatable :: tmp(:,:,:,:,:)
+      integer (c_long_long) :: s1, s2, sb
+      integer (c_intptr_t) :: a0
+      real (c_double) :: fill
+      integer :: n1, n2, n3, n4, n5
+      n1 = size(array,1); n2 = size(array,2); n3 = size(array,3); n4 = size(array,4); n5 = size(array,5)
+      if (n1 /= nx_block .or. n2 /= ny_block) call abort_ice('ice_HaloUpdate4DR8: horizontal extent is not (nx_block,ny_block)')
+      if (n5 < halo%numBlocks) call abort_ice('ice_HaloUpdate4DR8: fewer blocks in the array than on this task')
+      if (n3*n4 < 1 .or. halo%numBlocks < 1) return
+      if (is_contiguous(array)) then
+         call update_r8(array, n1, n2, n3*n4, n5, halo, 'ice_HaloUpdate4DR8', fieldLoc, fieldKind, fillValue)
+         return
+      endif
+      a0 = transfer(c_loc(array(1,1,1,1,1)), a0)
+      if (transfer(c_loc(array(2,1,1,1,1)), a0) - a0 /= 8 .or. &
+          transfer(c_loc(array(1,2,1,1,1)), a0) - a0 /= 8_c_intptr_t * n1) then   ! planes not whole: copy
+         allocate(tmp(n1,n2,n3,n4,n5))
+         tmp = array
+         call update_r8(tmp, n1, n2, n3*n4, n5, halo, 'ice_HaloUpdate4DR8', fieldLoc, fieldKind, fillValue)
+         array = tmp
+         deallocate(tmp)
+         return
+      endif
+      s1 = 0; s2 = 0; sb = 0
+      if (n3 > 1) s1 = (transfer(c_loc(array(1,1,2,1,1)), a0) - a0) / 8
+      if (n4 > 1) s2 = (transfer(c_loc(array(1,1,1,2,1)), a0) - a0) / 8
+      if (n5 > 1) sb = (transfer(c_loc(array(1,1,1,1,2)), a0) - a0) / 8
+      fill = 0.0_c_double
+      if (present(fillValue)) fill = fillValue
+      call cice_gpu_check(cice_halo_update_strided_r8(cice_gpu_ctx, c_loc(array(1,1,1,1,1)), n3, s1, n4, s2, sb, &
+                          fieldLoc, fieldKind, fill), 'ice_HaloUpdate4DR8')
    end subroutine ice_HaloUpdate4DR8
 
    subroutine ice_HaloUpdate4DR4(array, halo, fieldLoc, fieldKind, fillValue)

@@ -327,6 +327,9 @@ class Context:
     def _evp_fields(s, need_out=True):
         f = EvpFields()
         for n in EVP_IN + EVP_IO:
+            if s.get(n) is None:          # left to the device (evp_adopt_thermo_state)
+                setattr(f, n, None)
+                continue
             setattr(f, n, (_i4(s[n]) if n == "iceumask" else _f8(s[n])))
         for n in EVP_OUT:
             setattr(f, n, _f8(s[n]) if (n in s) else None)
@@ -336,6 +339,11 @@ class Context:
         """Drop-in evp(dt): s holds the module arrays (modified in place)."""
         f = self._evp_fields(s)
         self._ck(self.lib.cice_evp(self.h, C.c_double(dt), C.byref(f)))
+
+    def evp_adopt_thermo_state(self):
+        """aicen, vicen (+ the aggregates) of the dynamics from the batched thermo state on the device; the next
+        evp / evp_upload may leave aice, vice, vsno, aice0, aicen, vicen out (None)"""
+        self._ck(self.lib.cice_evp_adopt_thermo_state(self.h))
 
     def evp_pin_fields(self, s):
         """Page-lock the arrays of s (they must stay alive and keep their addresses)."""

@@ -173,6 +173,13 @@ int cice_evp_pin_fields(cice_ctx *ctx, const cice_evp_fields *f);
 /* Drop-in for `call evp(dt)` (ice_dyn_evp.F90:119-432): upload, run on the GPU,
  * download.  Equivalent to cice_evp_upload + cice_evp_step + cice_evp_download. */
 int cice_evp(cice_ctx *ctx, double dt, cice_evp_fields *f);
+/* Device-resident hand-off from the thermodynamic half-step to the dynamics (SURVEY section 8 f1;
+ * drivers/cice4/CICE_RunMod.F90:374-591 -> source/ice_step_mod.F90:575): aicen, vicen of the batched thermo state
+ * (cice_step_therm1 / cice_thermo_batch_step leave them on the device) become the dynamics' aicen, vicen, and aice, vice,
+ * vsno, aice0 are aggregated from them on the device in the order of `aggregate` (source/ice_itd.F90:279).  The NEXT
+ * cice_evp / cice_evp_upload may then pass NULL for those six fields.  For a caller that has not changed the state on
+ * the host in between (the reference's step_therm2 / transport do: its unchanged driver keeps uploading). */
+int cice_evp_adopt_thermo_state(cice_ctx *ctx);
 int cice_evp_upload(cice_ctx *ctx, const cice_evp_fields *f);   /* in + io fields -> HBM */
 int cice_evp_step(cice_ctx *ctx, double dt);                    /* evp(dt) on resident state */
 int cice_evp_download(cice_ctx *ctx, cice_evp_fields *f);       /* io + out fields -> host */
@@ -272,6 +279,10 @@ int cice_halo_update_ex_i4(cice_ctx *ctx, int32_t *field, int nlev, int loc, int
 int cice_halo_update_blocked_r8(cice_ctx *ctx, double *field, int nz, int loc, int kind, double fill);
 int cice_halo_update_blocked_r4(cice_ctx *ctx, float *field, int nz, int loc, int kind, float fill);
 int cice_halo_update_blocked_i4(cice_ctx *ctx, int32_t *field, int nz, int loc, int kind, int32_t fill);
+/* a section of a 4-d module array such as trcrn(:,:,1:ntrcr,:,:) (ice_state.F90:206): whole horizontal planes, level
+ * (z1, z2) of local block b at field + b * stride_block + z2 * stride2 + z1 * stride1 (strides in elements) */
+int cice_halo_update_strided_r8(cice_ctx *ctx, double *field, int nz1, long long stride1, int nz2, long long stride2,
+                                long long stride_block, int loc, int kind, double fill);
 int cice_halo_update_dev_ex_r8(cice_ctx *ctx, double *dev_field, int nlev, int loc, int kind, double fill);
 /* Device memory on the context's GPU for such resident fields, and blocking copies ordered on the library's stream. */
 int cice_device_alloc(cice_ctx *ctx, size_t bytes, void **dev);

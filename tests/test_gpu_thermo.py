@@ -371,6 +371,56 @@ def test_step_therm1_single_call_equals_the_separate_calls(ctx):
         assert np.array_equal(acc_b[k], acc_a[k]), k
 
 
+def test_thermo_state_handed_to_the_dynamics_on_the_device(ctx):
+    """SURVEY section 8 (f1): cice_thermo_batch_step leaves aicen, vicen, vsnon on the device;
+    cice_evp_adopt_thermo_state makes them the dynamics' input there (aggregates formed on the device in the order of
+    `aggregate`, ice_itd.F90:279) and the next evp(dt) uploads neither them nor aice, vice, vsno, aice0.  The result
+    equals the two PCIe calls -- download the thermo state, aggregate on the host, evp(dt) with everything uploaded --
+    bit for bit."""
+    DTE, NDTE_ = 3600.0, 24
+    nxg, nyg = 70, 44
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    ny, nx, nb = dom["ny"], dom["nx"], 1
+    gg = synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.03, seed=5)
+    grid = synth.block_fields(gg, dom)
+    ctx.thermo_init()
+    batch, _ = _batch_inputs(ny, nx, nb, seed=9)
+    tot = batch["aicen"].sum(axis=1, keepdims=True)      # concentrations of a cell add up to at most 0.95
+    sc = np.where(tot > 0.95, 0.95 / np.maximum(tot, 1e-30), 1.0)
+    for k in ("aicen", "vicen", "vsnon"):
+        batch[k] = np.ascontiguousarray(batch[k] * sc)
+    batch["eicen"] = np.ascontiguousarray(batch["eicen"] * sc)
+    batch["esnon"] = np.ascontiguousarray(batch["esnon"] * sc)
+    ctx.thermo_batch_alloc(nx, ny, nb)
+    ctx.thermo_batch_upload(batch)
+    assert ctx.thermo_batch_step(DTE, yday=150.0)["l_stop"] == 0
+    ctx.thermo_batch_download(batch)
+    st = synth.evp_state(grid, dom, seed=5, cover="patchy")
+    # path A: over PCIe -- the host aggregates (n = 1..ncat in order, ice_itd.F90:279) and uploads everything
+    a = {k: v.copy() for k, v in st.items()}
+    a["aicen"] = batch["aicen"].copy(); a["vicen"] = batch["vicen"].copy()
+    for name, src in (("aice", "aicen"), ("vice", "vicen"), ("vsno", "vsnon")):
+        acc = np.zeros((nb, ny, nx))
+        for n in range(5):
+            acc = acc + batch[src][:, n]
+        a[name] = acc
+    a["aice0"] = np.maximum(1.0 - a["aice"], 0.0)
+    ctx.evp_init(grid, ndte=NDTE_)
+    ctx.evp(DTE, a)
+    # path B: on the device
+    b = {k: v.copy() for k, v in st.items()}
+    for k in ("aice", "vice", "vsno", "aice0", "aicen", "vicen"):
+        b[k] = None
+    ctx.evp_init(grid, ndte=NDTE_)
+    ctx.evp_adopt_thermo_state()
+    ctx.evp(DTE, b)
+    for k in ("uvel", "vvel", "strength", "divu", "shear", "strocnxT", "strocnyT", "stressp_1", "stress12_4", "iceumask"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.abs(a["uvel"]).max() > 1e-4 and a["strength"].max() > 0
+    with pytest.raises(lib.CiceError):       # without a fresh hand-off the six fields are required again
+        ctx.evp(DTE, b)
+
+
 def test_frzmlt_bottom_lateral(ctx, orc):
     ctx.thermo_init(); orc.init_thermo()
     ny, nx = 30, 44
