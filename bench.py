@@ -765,7 +765,7 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
              f"stress + stepu + on-rank halo per level)" if skew_k else
              "k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
              else "k_subcycle (fused stress + stepu + on-rank halo)")
-    ksub = (f"k_evp_resident<{rw}, false>" if resident else
+    ksub = (f"k_evp_resident<{rw}, false" if resident else
             f"k_subcycle_skew<{skew_k}, false, false" if skew_k else
             f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
             else f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>")

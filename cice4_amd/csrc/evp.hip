@@ -229,6 +229,15 @@ __device__ __forceinline__ double down1(double x) {
   return __hiloint2double(hi, lo);
 }
 
+#ifndef SKEW_NT
+#define SKEW_NT 0
+#endif
+__device__ __forceinline__ double ld8nt(const double* p, unsigned off) {
+  return __builtin_nontemporal_load((const double*)((const char*)p + off));
+}
+__device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
+  __builtin_nontemporal_store(v, (double*)((char*)p + off));
+}
 #ifndef SKEW_FAKE_SIGMA_LOAD
 #define SKEW_FAKE_SIGMA_LOAD 0
 #endif
@@ -1002,7 +1011,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         const char* ps = (const char*)u_in + 2 * pstride;
 #pragma unroll
         for (int c = 0; c < 12; ++c) {
-          s[c] = ld8((const double*)ps, q);
+          s[c] = SKEW_NT ? ld8nt((const double*)ps, q) : ld8((const double*)ps, q);
           ps += pstride;
         }
       } else {
@@ -1074,7 +1083,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
           char* po = (char*)s_out + 2 * pstride;
 #pragma unroll
           for (int c = 0; c < 12; ++c) {
-            st8((double*)po, q, s[c]);
+            if (SKEW_NT) st8nt((double*)po, q, s[c]);
+            else st8((double*)po, q, s[c]);
             po += pstride;
           }
           if (LAST) {

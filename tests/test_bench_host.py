@@ -12,11 +12,15 @@ bench = importlib.import_module("bench")
 
 def test_launch_count_matches_the_pairing_rule():
     # one launch per subcycle without pairing
-    assert bench.launches_per_step(120, False, 0) == 120
+    assert bench.launches_per_step(120, False, 0) == (120, 1)
     # pairs; an odd count ends with a single
-    assert bench.launches_per_step(120, True, 0) == 60
-    assert bench.launches_per_step(7, True, 0) == 4
-    assert bench.launches_per_step(1, True, 0) == 1
+    assert bench.launches_per_step(120, True, 0) == (60, 2)
+    assert bench.launches_per_step(7, True, 0)[0] == 4
+    assert bench.launches_per_step(1, True, 0) == (1, 1)
+    # K subcycles per sweep: the rest as pairs / singles
+    assert bench.launches_per_step(240, True, 0, 4) == (60, 4)
+    assert bench.launches_per_step(13, True, 0, 4) == (4, 4)      # 4 + 4 + 4 + 1
+    assert bench.launches_per_step(120, True, 6, 4) == (40, 4)    # refresh every 6: 4 + 2 between refreshes
     # wide-halo slabs: refresh after every `overlap`-th subcycle; pairs never straddle one
     for ndte in (120, 240, 7):
         for h in (2, 4, 6, 12):
@@ -28,8 +32,8 @@ def test_launch_count_matches_the_pairing_rule():
                 else:
                     k += 1
                 n += 1
-            assert bench.launches_per_step(ndte, True, h) == n
-    assert bench.launches_per_step(120, True, 12) == 60   # even overlap: all pairs
+            assert bench.launches_per_step(ndte, True, h)[0] == n
+    assert bench.launches_per_step(120, True, 12)[0] == 60   # even overlap: all pairs
 
 
 @pytest.mark.parametrize("nxg,rows", [(320, 48), (320, 96), (320, 192), (3600, 300), (3600, 1200), (100, 29), (100, 8)])
@@ -51,11 +55,14 @@ def test_archived_counter_passes_are_found_for_the_kernels_the_bench_reports():
     """roofline.traffic / not_hbm_bound come from archived rocprofv3 passes looked up by kernel name: a renamed kernel
     or a reshaped workgroup would silently turn them into null.  The names the library uses
     today must be in profiles/."""
-    for wl, k in (("gx1", "k_evp_resident<4, false>"), ("gx1", "k_evp_resident<11, false>"),
+    for wl, k in (("gx1", "k_evp_resident<4, false"), ("gx1", "k_evp_resident<11, false"),
                   ("gx1", "k_subcycle2<13, false, false, true>"), ("tenth", "k_subcycle2<16, false, false, true>"),
+                  ("tenth", "k_subcycle_skew<4, false, false"),
                   ("gx1", "k_thermo_dense<true>"), ("tenth", "k_thermo_dense<true>")):
         traffic, src = bench.pmc_traffic(wl, k)
         assert traffic and traffic > 1e6 and src.startswith("archived PMC pass profiles/"), (wl, k)
-    for k in ("k_evp_resident<4, false>", "k_evp_resident<11, false>"):
+    for k in ("k_evp_resident<4, false", "k_evp_resident<11, false"):
         sq = bench.pmc_counters("gx1", k)
         assert sq and 500 < sq["valu_per_wave_subcycle"] < 700, k
+    sq = bench.pmc_counters("tenth", "k_subcycle_skew<4, false, false")
+    assert sq and 500 < sq["valu_per_wave_subcycle"] and sq["valu_insts_per_launch"] > 1e8 and sq.get("commit")
