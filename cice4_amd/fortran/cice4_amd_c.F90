@@ -270,6 +270,48 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          integer(c_int), value :: ncat, nilyr, nslyr, max_ntrcr
       end function
+      integer(c_int) function cice_comm_init_local(ctx, link_id, rank, nranks) bind(C, name='cice_comm_init_local')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: link_id, rank, nranks
+      end function
+      ! the one-launch subcycle loop across tasks: exchange copies / progress words of the neighbours (DESIGN.md section 7)
+      integer(c_int) function cice_evp_peer_export_ipc(ctx, handles, plane) bind(C, name='cice_evp_peer_export_ipc')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(out) :: handles(64,3)
+         integer(c_long_long), intent(out) :: plane
+      end function
+      integer(c_int) function cice_evp_peer_connect_ipc(ctx, side, handles, plane) bind(C, name='cice_evp_peer_connect_ipc')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: side
+         character(kind=c_char), intent(in) :: handles(64,3)
+         integer(c_long_long), value :: plane
+      end function
+      integer(c_int) function cice_evp_peer_export(ctx, bufs, plane) bind(C, name='cice_evp_peer_export')
+         import
+         type(c_ptr), value :: ctx
+         type(c_ptr), intent(out) :: bufs(3)
+         integer(c_long_long), intent(out) :: plane
+      end function
+      integer(c_int) function cice_evp_peer_connect(ctx, side, xu0, xu1, rprog, plane) bind(C, name='cice_evp_peer_connect')
+         import
+         type(c_ptr), value :: ctx, xu0, xu1, rprog
+         integer(c_int), value :: side
+         integer(c_long_long), value :: plane
+      end function
+      ! the thermodynamic state on the device becomes the dynamics' input there (SURVEY section 8 f1)
+      integer(c_int) function cice_evp_adopt_thermo_state(ctx) bind(C, name='cice_evp_adopt_thermo_state')
+         import
+         type(c_ptr), value :: ctx
+      end function
+      integer(c_int) function cice_thermo_set_option(ctx, key, value) bind(C, name='cice_thermo_set_option')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: key(*)
+         integer(c_int), value :: value
+      end function
       integer(c_int) function cice_comm_count(ctx, nranks) bind(C, name='cice_comm_count')
          import
          type(c_ptr), value :: ctx
