@@ -108,6 +108,9 @@ def parse():
     p.add_argument("--no-dropin-timing", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline sample budget")
     p.add_argument("--cpu-baseline-worker", default="", help=argparse.SUPPRESS)
+    p.add_argument("--peer-loop", action="store_true",
+                   help="N > 1: one classic slab per rank and the cross-rank one-launch loop (device-initiated exchange through "
+                        "IPC-mapped buffers of the neighbours) instead of wide-halo slabs; grids that fit the chip only (gx1, gx3)")
     p.add_argument("--host-only", action="store_true",
                    help="no GPU: launcher + rendezvous + slab decomposition + one ghost exchange over gloo, checked")
     p.add_argument("--comm-timeout", type=float, default=120.0,
@@ -339,10 +342,17 @@ def launches_per_step(ndte, fused, overlap, skew_k=0):
     return n, max(sizes, key=lambda z: sizes[z] * z)
 
 
-def build_case(ctx, wl, rank, world, overlap=-1, slabs=0):
+def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False):
     nxg, nyg, ndte, _ = workload(wl)
     if nyg % world:
         raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
+    if world > 1 and peer_loop:
+        # one classic slab per rank (ghost rows owned by the neighbours): the decomposition of the cross-rank one-launch loop
+        dom = ctx.domain_create(nxg, nyg, nxg, nyg // world, ew=1, ns=0, rank=rank, npx=1, npy=world)
+        dom["overlap"] = 0
+        gg = synth.global_grid(nxg, nyg)
+        grid = synth.block_fields(gg, dom)
+        return dom, grid, synth.evp_state(grid, dom, cover="full"), ndte
     if world == 1 and slabs > 1:
         rows = nyg // slabs
         if overlap < 0:
@@ -620,16 +630,24 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     """W warm-up + exactly K timed steps of the EVP hot loop on resident state for workload `wl`.
     Returns everything the JSON line needs (rank-local cell counts already reduced over the ranks)."""
     progress(f"{wl}: building the synthetic case")
-    dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs)
+    peer_loop = bool(getattr(args, "peer_loop", False)) and world > 1
+    dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs, peer_loop)
     progress(f"{wl}: case built, device set-up")
     if world > 1:
         # the communicator is created once per context and handed to every decomposition built afterwards
         # (the uid is only used by the first call)
-        uid = [ctx.comm_unique_id() if rank == 0 and not getattr(ctx, "_comm_ready", False) else None]
-        with bounded(args.comm_timeout, "creation of the RCCL communicator (ncclCommInitRank)"):
+        if os.environ.get("CICE4_AMD_BENCH_LINK") == "shm":
+            # diagnostic: the ranks are processes of this host joined by a shared-memory link instead of RCCL (all of them
+            # may then sit on ONE device: CICE4_AMD_BENCH_DEVICE=0) -- the multi-process path on a one-GPU box
             if not getattr(ctx, "_comm_ready", False):
-                dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0] if uid[0] is not None else bytes(128), rank, world)
+                with bounded(args.comm_timeout, "creation of the shared-memory link"):
+                    ctx.comm_init_shm("/cice4_amd_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world, 256 << 20)
+        else:
+            uid = [ctx.comm_unique_id() if rank == 0 and not getattr(ctx, "_comm_ready", False) else None]
+            with bounded(args.comm_timeout, "creation of the RCCL communicator (ncclCommInitRank)"):
+                if not getattr(ctx, "_comm_ready", False):
+                    dist.broadcast_object_list(uid, src=0)
+                ctx.comm_init(uid[0] if uid[0] is not None else bytes(128), rank, world)
         ctx._comm_ready = True
     ctx.evp_init(grid, ndte=ndte)
     if tune and args.waves:
@@ -665,6 +683,19 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
                 f"lanes, owns {62 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
     ctx.evp_set_option("resident", 0 if args.no_resident else 1)
+    if peer_loop:
+        # every rank hands the IPC handles of its exchange copies / progress words to its neighbours (control plane: gloo)
+        share = world if os.environ.get("CICE4_AMD_BENCH_DEVICE") is not None else 1
+        ctx.evp_set_option("resident_peer_share", share)
+        mine = ctx.evp_peer_export_ipc()
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        with bounded(args.comm_timeout, "mapping the neighbours' exchange buffers (hipIpcOpenMemHandle)"):
+            if rank > 0:
+                ctx.evp_peer_connect_ipc(0, every[rank - 1])
+            if rank < world - 1:
+                ctx.evp_peer_connect_ipc(1, every[rank + 1])
+        dist.barrier()
     if tune and args.resident_waves:
         ctx.evp_set_option("resident_waves", args.resident_waves)
     resident = bool(ctx.evp_get_info("resident"))
@@ -815,7 +846,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                 roofline["bound_effective"] = "valu_f64_issue"
     config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
               "subcycles_per_step": ndte,
-              "decomposition": f"1x{world} j-slabs, one block per GPU" + (
+              "decomposition": (f"1x{world} classic j-slabs, cross-rank one-launch loop (device-initiated exchange through the "
+                                f"neighbours' IPC-mapped exchange copies)" if peer_loop and resident else
+                                f"1x{world} j-slabs, one block per GPU") + (
                   f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
                   f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
               "tile": tile, "metrics_recomputed_from_HTN_HTE": derive,
@@ -888,16 +921,13 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
     rank, world, local, dist = init_dist(args.gpus, args.comm_timeout)
-    try:
-        import torch
-        have_torch_gpu = torch.cuda.is_available()
-        if have_torch_gpu:
-            torch.cuda.set_device(local)
-    except Exception:
-        torch, have_torch_gpu = None, False
-
     if os.environ.get("CICE4_AMD_BENCH_DEVICE") is not None:   # diagnostic: several ranks on one device
         local = int(os.environ["CICE4_AMD_BENCH_DEVICE"])
+    import torch                     # (torch.distributed is used for every N > 1: no fallback without it)
+    have_torch_gpu = torch.cuda.is_available()
+    if have_torch_gpu:
+        torch.cuda.set_device(local)
+
     ctx = lib.Context(device=local)
     ctx.sync()                       # fails loudly without a GPU / HIP library
     calib = None

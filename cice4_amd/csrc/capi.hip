@@ -34,7 +34,8 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
-  LocalLink* link = nullptr;   // in-process stand-in for the communicator (cice_comm_init_local; tests)
+  LocalLink* link = nullptr;   // stand-in for the communicator without RCCL (cice_comm_init_local / _shm; tests)
+  bool link_owned = false;     // the shared-memory form belongs to this context
   // Page-locked host ranges of this context: [start, end) in bytes, disjoint.  One manager for the explicit
   // registrations (cice_host_register, cice_evp_pin_fields): a new range that touches registered ones is registered
   // as their union (a whole array after some of its slices), because a copy whose host range is partly registered
@@ -483,6 +484,7 @@ int cice_destroy(cice_ctx* ctx) {
   ctx->frame_halo.reset();
   ctx->halo.reset();
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
+  if (ctx->link && ctx->link_owned) link_close(ctx->link);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CICE_OK;
@@ -720,11 +722,28 @@ int cice_comm_init_local(cice_ctx* ctx, int link_id, int rank, int nranks) {
   CICE_CATCH
 }
 
+// The same between processes of one host (a file under /dev/shm; box_bytes = the largest message).
+int cice_comm_init_shm(cice_ctx* ctx, const char* name, int rank, int nranks, long long box_bytes) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(name && name[0] == '/' && nranks >= 1 && rank >= 0 && rank < nranks && box_bytes > 0,
+               "cice_comm_init_shm: bad arguments (the name must start with '/')");
+  CICE_REQUIRE(!c_->comm && !c_->link, "cice_comm_init_shm: this context already has a communicator");
+  c_->need_halo();
+  c_->link = shm_link_open(name, rank, nranks, (size_t)box_bytes);
+  c_->link_owned = true;
+  c_->comm_rank = rank;
+  c_->comm_nranks = nranks;
+  c_->halo->set_link(c_->link, rank, nranks);
+  if (c_->frame_halo) c_->frame_halo->set_link(c_->link, rank, nranks);
+  CICE_CATCH
+}
+
 // Ranks of this context's communicator as RCCL itself counts them (ncclCommCount); 0 before cice_comm_init.
 int cice_comm_count(cice_ctx* ctx, int* nranks) {
   CICE_TRY(ctx)
   CICE_REQUIRE(nranks != nullptr, "NULL argument");
   *nranks = 0;
+  if (c_->link) *nranks = c_->comm_nranks;
   if (c_->comm) {
     const ncclResult_t r = ncclCommCount(c_->comm, nranks);
     if (r != ncclSuccess) throw Error{CICE_ECOMM, std::string("ncclCommCount: ") + ncclGetErrorString(r)};

@@ -20,6 +20,9 @@ namespace cice {
 // RCCL refuses two ranks on one device.  Slow by construction (every message synchronises the stream); tests only.
 struct LocalLink;
 LocalLink* local_link_get(int link_id, int nranks);   // the link of that id (created on first use; sizes must agree)
+// the same between PROCESSES of one host through a file under /dev/shm (rank 0 creates it); owned by the caller
+LocalLink* shm_link_open(const char* name, int rank, int nranks, size_t box_bytes);
+void link_close(LocalLink* l);
 
 class Halo {
  public:

@@ -2,8 +2,15 @@
 
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <thread>
 #include <condition_variable>
 #include <cstring>
 #include <map>
@@ -20,17 +27,76 @@ namespace cice {
       throw ::cice::Error{CICE_ECOMM, std::string(#expr) + ": " + ncclGetErrorString(r_)};      \
   } while (0)
 
-// ---- in-process link (halo.h) ------------------------------------------------------------------------------------
+// ---- links without RCCL (halo.h) --------------------------------------------------------------------------------------
+// The protocol of both: messages of a (sender, receiver) pair are numbered by the pair; a sender posts message m only
+// after the receiver has taken m - 1 (one mailbox per pair), a receiver takes m once it is posted.  Every wait is bounded.
+namespace {
+constexpr int LINK_WAIT_S = 60;   // a rank whose partner never shows up fails instead of hanging
+}
+
 struct LocalLink {
   int nranks = 0;
+  virtual ~LocalLink() = default;
+  virtual void post(int src, int dst, const void* data, size_t bytes) = 0;   // blocks until the mailbox is free
+  virtual void take(int src, int dst, void* data, size_t bytes) = 0;         // blocks until the message is there
+  virtual unsigned all_max(int rank, unsigned v) = 0;
+};
+
+// ranks = contexts of one process (one host thread each)
+struct InProcLink : LocalLink {
   std::mutex m;
   std::condition_variable cv;
-  // box[src * nranks + dst]: the message src posted for dst, its sequence number, and the last one dst has taken
-  std::vector<std::vector<char>> box;
-  std::vector<long> posted, taken;
-  // all-reduce of one word
+  std::vector<std::vector<char>> box;   // box[src * nranks + dst]
+  std::vector<long> posted, taken, red_seq;
   std::vector<unsigned> red_val;
-  std::vector<long> red_seq;
+  explicit InProcLink(int n) {
+    nranks = n;
+    box.resize((size_t)n * n);
+    posted.assign((size_t)n * n, 0);
+    taken.assign((size_t)n * n, 0);
+    red_seq.assign(n, 0);
+    red_val.assign(n, 0);
+  }
+  void post(int src, int dst, const void* data, size_t bytes) override {
+    std::unique_lock<std::mutex> lk(m);
+    const size_t slot = (size_t)src * nranks + dst;
+    if (!cv.wait_for(lk, std::chrono::seconds(LINK_WAIT_S), [&] { return taken[slot] == posted[slot]; }))
+      throw Error{CICE_ECOMM, "in-process link: the partner rank did not take the previous message (is it running?)"};
+    box[slot].assign((const char*)data, (const char*)data + bytes);
+    posted[slot] += 1;
+    cv.notify_all();
+  }
+  void take(int src, int dst, void* data, size_t bytes) override {
+    std::unique_lock<std::mutex> lk(m);
+    const size_t slot = (size_t)src * nranks + dst;
+    if (!cv.wait_for(lk, std::chrono::seconds(LINK_WAIT_S), [&] { return posted[slot] == taken[slot] + 1; }))
+      throw Error{CICE_ECOMM, "in-process link: no message from the partner rank (is it running?)"};
+    if (box[slot].size() != bytes)
+      throw Error{CICE_ECOMM, "in-process link: the ranks are not making the same sequence of halo updates"};
+    std::memcpy(data, box[slot].data(), bytes);
+    taken[slot] += 1;
+    cv.notify_all();
+  }
+  unsigned all_max(int rank, unsigned v) override {
+    std::unique_lock<std::mutex> lk(m);
+    const long seq = red_seq[rank] + 1;
+    auto all_at = [&](long q) {
+      for (int r = 0; r < nranks; ++r)
+        if (red_seq[r] < q) return false;
+      return true;
+    };
+    // nobody may still be reading the previous round's values
+    if (!cv.wait_for(lk, std::chrono::seconds(LINK_WAIT_S), [&] { return all_at(seq - 1); }))
+      throw Error{CICE_ECOMM, "in-process link: all-reduce out of step"};
+    red_val[rank] = v;
+    red_seq[rank] = seq;
+    cv.notify_all();
+    if (!cv.wait_for(lk, std::chrono::seconds(LINK_WAIT_S), [&] { return all_at(seq); }))
+      throw Error{CICE_ECOMM, "in-process link: a rank did not reach the all-reduce"};
+    unsigned mx = 0;
+    for (int r = 0; r < nranks; ++r) mx = std::max(mx, red_val[r]);
+    return mx;
+  }
 };
 
 LocalLink* local_link_get(int link_id, int nranks) {
@@ -38,22 +104,127 @@ LocalLink* local_link_get(int link_id, int nranks) {
   static std::map<int, std::unique_ptr<LocalLink>> links;
   std::lock_guard<std::mutex> g(gm);
   auto& l = links[link_id];
-  if (!l) {
-    l.reset(new LocalLink());
-    l->nranks = nranks;
-    l->box.resize((size_t)nranks * nranks);
-    l->posted.assign((size_t)nranks * nranks, 0);
-    l->taken.assign((size_t)nranks * nranks, 0);
-    l->red_val.assign(nranks, 0);
-    l->red_seq.assign(nranks, 0);
-  }
+  if (!l) l.reset(new InProcLink(nranks));
   if (l->nranks != nranks) throw Error{CICE_EINVAL, "cice_comm_init_local: this link exists with another number of ranks"};
   return l.get();
 }
 
-namespace {
-constexpr int LINK_WAIT_S = 60;   // a rank whose partner never shows up fails instead of hanging
+// ranks = PROCESSES of one host: a file under /dev/shm holds the counters and one mailbox per (sender, receiver) pair.
+// For running the multi-process path (bench.py --gpus N, the Fortran MPI driver) on a box with ONE GPU, where RCCL
+// refuses two ranks on one device.  Rank 0 creates the file, the others wait for it; polls sleep 20 us.
+struct ShmLink : LocalLink {
+  struct Header {
+    std::atomic<unsigned> magic;
+    unsigned nranks;
+    unsigned long long box_bytes;
+  };
+  char* base = nullptr;
+  size_t total = 0, box_bytes = 0;
+  std::string name;
+  bool owner = false;
+  // layout: Header | posted[R*R] | taken[R*R] | size[R*R] | red_seq[R] | red_val[R] | (pad to 4096) | boxes
+  std::atomic<long>* posted() const { return (std::atomic<long>*)(base + 64); }
+  std::atomic<long>* taken() const { return posted() + (size_t)nranks * nranks; }
+  std::atomic<unsigned long long>* sizes() const { return (std::atomic<unsigned long long>*)(taken() + (size_t)nranks * nranks); }
+  std::atomic<long>* red_seq() const { return (std::atomic<long>*)(sizes() + (size_t)nranks * nranks); }
+  std::atomic<unsigned>* red_val() const { return (std::atomic<unsigned>*)(red_seq() + nranks); }
+  size_t head_bytes() const {
+    const size_t h = 64 + ((size_t)nranks * nranks * 3 + nranks) * 8 + (size_t)nranks * 4;
+    return (h + 4095) / 4096 * 4096;
+  }
+  char* box(size_t slot) const { return base + head_bytes() + slot * box_bytes; }
+  ShmLink(const char* nm, int rank, int n, size_t bbytes) {
+    nranks = n;
+    name = nm;
+    box_bytes = (bbytes + 4095) / 4096 * 4096;
+    total = head_bytes() + (size_t)n * n * box_bytes;
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
+    int fd = -1;
+    if (rank == 0) {
+      (void)shm_unlink(nm);
+      fd = shm_open(nm, O_CREAT | O_EXCL | O_RDWR, 0600);
+      if (fd < 0 || ftruncate(fd, (off_t)total) != 0) throw Error{CICE_ECOMM, std::string("shared-memory link: cannot create ") + nm};
+      owner = true;
+    } else {
+      while ((fd = shm_open(nm, O_RDWR, 0600)) < 0) {
+        if (std::chrono::steady_clock::now() > deadline) throw Error{CICE_ECOMM, std::string("shared-memory link: rank 0 never created ") + nm};
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+      struct stat st;
+      while (fstat(fd, &st) == 0 && (size_t)st.st_size < total) {
+        if (std::chrono::steady_clock::now() > deadline) throw Error{CICE_ECOMM, "shared-memory link: the file never reached its size (do the ranks agree on it?)"};
+        std::this_thread::sleep_for(std::chrono::milliseconds(2));
+      }
+    }
+    base = (char*)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) throw Error{CICE_ECOMM, "shared-memory link: mmap failed"};
+    Header* h = (Header*)base;
+    if (rank == 0) {   // a fresh file is zero-filled: counters start at 0
+      h->nranks = (unsigned)n;
+      h->box_bytes = box_bytes;
+      h->magic.store(0x43494345u, std::memory_order_release);
+    } else {
+      while (h->magic.load(std::memory_order_acquire) != 0x43494345u) {
+        if (std::chrono::steady_clock::now() > deadline) throw Error{CICE_ECOMM, "shared-memory link: rank 0 never initialised the file"};
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+      if (h->nranks != (unsigned)n || h->box_bytes != box_bytes) throw Error{CICE_ECOMM, "shared-memory link: the ranks disagree on its shape"};
+    }
+  }
+  ~ShmLink() override {
+    if (base && base != MAP_FAILED) munmap(base, total);
+    if (owner) (void)shm_unlink(name.c_str());
+  }
+  template <class F>
+  static void wait(F&& ok, const char* what) {
+    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
+    int spins = 0;
+    while (!ok()) {
+      if (++spins < 200) continue;
+      if (std::chrono::steady_clock::now() > deadline) throw Error{CICE_ECOMM, what};
+      std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  }
+  void post(int src, int dst, const void* data, size_t bytes) override {
+    if (bytes > box_bytes) throw Error{CICE_ECOMM, "shared-memory link: message larger than the mailbox (cice_comm_init_shm: box_bytes)"};
+    const size_t slot = (size_t)src * nranks + dst;
+    wait([&] { return taken()[slot].load(std::memory_order_acquire) == posted()[slot].load(std::memory_order_relaxed); },
+         "shared-memory link: the partner rank did not take the previous message (is it running?)");
+    std::memcpy(box(slot), data, bytes);
+    sizes()[slot].store(bytes, std::memory_order_relaxed);
+    posted()[slot].fetch_add(1, std::memory_order_release);
+  }
+  void take(int src, int dst, void* data, size_t bytes) override {
+    const size_t slot = (size_t)src * nranks + dst;
+    wait([&] { return posted()[slot].load(std::memory_order_acquire) == taken()[slot].load(std::memory_order_relaxed) + 1; },
+         "shared-memory link: no message from the partner rank (is it running?)");
+    if (sizes()[slot].load(std::memory_order_relaxed) != bytes)
+      throw Error{CICE_ECOMM, "shared-memory link: the ranks are not making the same sequence of halo updates"};
+    std::memcpy(data, box(slot), bytes);
+    taken()[slot].fetch_add(1, std::memory_order_release);
+  }
+  unsigned all_max(int rank, unsigned v) override {
+    const long seq = red_seq()[rank].load(std::memory_order_relaxed) + 1;
+    auto all_at = [&](long q) {
+      for (int r = 0; r < nranks; ++r)
+        if (red_seq()[r].load(std::memory_order_acquire) < q) return false;
+      return true;
+    };
+    wait([&] { return all_at(seq - 1); }, "shared-memory link: all-reduce out of step");
+    red_val()[rank].store(v, std::memory_order_relaxed);
+    red_seq()[rank].store(seq, std::memory_order_release);
+    wait([&] { return all_at(seq); }, "shared-memory link: a rank did not reach the all-reduce");
+    unsigned mx = 0;
+    for (int r = 0; r < nranks; ++r) mx = std::max(mx, red_val()[r].load(std::memory_order_relaxed));
+    return mx;
+  }
+};
+
+LocalLink* shm_link_open(const char* name, int rank, int nranks, size_t box_bytes) {
+  return new ShmLink(name, rank, nranks, box_bytes);   // owned by the context (cice_destroy)
 }
+void link_close(LocalLink* l) { delete l; }
 
 namespace {
 
@@ -280,36 +451,18 @@ void Halo::link_exchange(const T* sb, T* rb, int nfields, const std::vector<int>
                          const std::vector<int>& scnt, int ns, const std::vector<int>& rpeer,
                          const std::vector<int>& roff, const std::vector<int>& rcnt, int nr) {
   LocalLink& L = *link_;
-  const int R = L.nranks;
-  const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
   CICE_HIP(hipStreamSynchronize(stream_));   // the pack kernel has run
+  std::vector<char> tmp;
   for (int m = 0; m < ns; ++m) {
     const size_t bytes = (size_t)nfields * scnt[m] * sizeof(T);
-    std::vector<char> tmp(bytes);
+    tmp.resize(bytes);
     CICE_HIP(hipMemcpy(tmp.data(), sb + (size_t)nfields * soff[m], bytes, hipMemcpyDeviceToHost));
-    std::unique_lock<std::mutex> lk(L.m);
-    const size_t slot = (size_t)rank_ * R + speer[m];
-    // the partner has taken the previous message of this pair
-    if (!L.cv.wait_until(lk, deadline, [&] { return L.taken[slot] == L.posted[slot]; }))
-      throw Error{CICE_ECOMM, "in-process link: the partner rank did not take the previous message (is it running?)"};
-    L.box[slot].swap(tmp);
-    L.posted[slot] += 1;       // messages of a (sender, receiver) pair are numbered by the pair
-    L.cv.notify_all();
+    L.post(rank_, speer[m], tmp.data(), bytes);
   }
   for (int m = 0; m < nr; ++m) {
     const size_t bytes = (size_t)nfields * rcnt[m] * sizeof(T);
-    std::vector<char> tmp;
-    {
-      std::unique_lock<std::mutex> lk(L.m);
-      const size_t slot = (size_t)rpeer[m] * R + rank_;
-      if (!L.cv.wait_until(lk, deadline, [&] { return L.posted[slot] == L.taken[slot] + 1; }))
-        throw Error{CICE_ECOMM, "in-process link: no message from the partner rank (is it running?)"};
-      if (L.box[slot].size() != bytes)
-        throw Error{CICE_ECOMM, "in-process link: the ranks are not making the same sequence of halo updates"};
-      tmp.swap(L.box[slot]);
-      L.taken[slot] += 1;
-      L.cv.notify_all();
-    }
+    tmp.resize(bytes);
+    L.take(rpeer[m], rank_, tmp.data(), bytes);
     CICE_HIP(hipMemcpy(rb + (size_t)nfields * roff[m], tmp.data(), bytes, hipMemcpyHostToDevice));
   }
 }
@@ -456,33 +609,11 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
 
 void Halo::all_max_u32(unsigned* dev_word) {
   if (nranks_ <= 1) return;
-  if (link_) {   // in-process link: every rank posts its word, takes the maximum once all have
-    LocalLink& L = *link_;
+  if (link_) {   // every rank posts its word and takes the maximum once all have
     unsigned v = 0;
     CICE_HIP(hipStreamSynchronize(stream_));
     CICE_HIP(hipMemcpy(&v, dev_word, 4, hipMemcpyDeviceToHost));
-    std::unique_lock<std::mutex> lk(L.m);
-    const long seq = L.red_seq[rank_] + 1;
-    const auto deadline = std::chrono::steady_clock::now() + std::chrono::seconds(LINK_WAIT_S);
-    // nobody may still be reading the previous round's values
-    if (!L.cv.wait_until(lk, deadline, [&] {
-          for (int r = 0; r < L.nranks; ++r)
-            if (L.red_seq[r] < seq - 1) return false;
-          return true;
-        }))
-      throw Error{CICE_ECOMM, "in-process link: all-reduce out of step"};
-    L.red_val[rank_] = v;
-    L.red_seq[rank_] = seq;
-    L.cv.notify_all();
-    if (!L.cv.wait_until(lk, deadline, [&] {
-          for (int r = 0; r < L.nranks; ++r)
-            if (L.red_seq[r] < seq) return false;
-          return true;
-        }))
-      throw Error{CICE_ECOMM, "in-process link: a rank did not reach the all-reduce"};
-    unsigned mx = 0;
-    for (int r = 0; r < L.nranks; ++r) mx = std::max(mx, L.red_val[r]);
-    lk.unlock();
+    const unsigned mx = link_->all_max(rank_, v);
     CICE_HIP(hipMemcpy(dev_word, &mx, 4, hipMemcpyHostToDevice));
     return;
   }

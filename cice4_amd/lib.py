@@ -305,6 +305,10 @@ class Context:
         """in-process link instead of an RCCL communicator: the ranks are contexts of this process (tests)"""
         self._ck(self.lib.cice_comm_init_local(self.h, link_id, rank, nranks))
 
+    def comm_init_shm(self, name, rank, nranks, box_bytes=64 << 20):
+        """the same between processes of one host (a file under /dev/shm)"""
+        self._ck(self.lib.cice_comm_init_shm(self.h, name.encode(), rank, nranks, C.c_longlong(box_bytes)))
+
     def comm_count(self):
         """ranks of this context's communicator as RCCL counts them (0 before comm_init)"""
         n = C.c_int(0)
@@ -390,6 +394,15 @@ class Context:
         """side 0: `peer` (an evp_peer_export tuple) is the rank to the south, 1: to the north"""
         self._ck(self.lib.cice_evp_peer_connect(self.h, side, C.c_void_p(peer[0]), C.c_void_p(peer[1]), C.c_void_p(peer[2]),
                                                 C.c_longlong(peer[3])))
+
+    def evp_peer_export_ipc(self):
+        """(3 x 64-byte IPC handles, plane): the same buffers for a neighbour in another process"""
+        h = C.create_string_buffer(192); plane = C.c_longlong(0)
+        self._ck(self.lib.cice_evp_peer_export_ipc(self.h, h, C.byref(plane)))
+        return h.raw, plane.value
+
+    def evp_peer_connect_ipc(self, side, peer):
+        self._ck(self.lib.cice_evp_peer_connect_ipc(self.h, side, C.c_char_p(peer[0]), C.c_longlong(peer[1])))
 
     def evp_debug(self, what):
         n = C.c_longlong(0)

@@ -123,6 +123,10 @@ int cice_comm_init(cice_ctx *ctx, const char uid[128], int rank, int nranks);
  * serial/ directory next to mpi/: the whole multi-rank path runs on a box with one GPU (RCCL refuses two ranks on one
  * device).  Tests only -- every message synchronises the stream. */
 int cice_comm_init_local(cice_ctx *ctx, int link_id, int rank, int nranks);
+/* The same between PROCESSES of one host: a file `name` ("/...") under /dev/shm holds one mailbox of box_bytes per pair of
+ * ranks; rank 0 creates it, the others wait for it.  For running a multi-process job (bench.py --gpus N with all ranks on
+ * one device, the MPI build of the Fortran driver) on a box with one GPU.  Tests only. */
+int cice_comm_init_shm(cice_ctx *ctx, const char *name, int rank, int nranks, long long box_bytes);
 /* ranks of the communicator as RCCL counts them (ncclCommCount; = MPI_COMM_SIZE of mpi/ice_communicate.F90:109-136);
  * 0 before cice_comm_init */
 int cice_comm_count(cice_ctx *ctx, int *nranks);

@@ -1,0 +1,116 @@
+"""Rank PROCESSES on one GPU: what a multi-GPU job does, with every rank on device 0 and a shared-memory link in place of
+RCCL (which refuses two ranks on one device).  Covers what the in-process test (test_ranks_in_one_process) cannot: the
+neighbours' exchange buffers mapped through IPC handles (hipIpcGetMemHandle / hipIpcOpenMemHandle), separate address spaces,
+and bench.py --gpus N end to end from the plain command."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+DT, NDTE = 3600.0, 120
+NXG, NYG = 96, 72
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+RANK_CODE = r'''
+import os, sys, pickle
+import numpy as np
+ROOT, mode, outdir = sys.argv[1], sys.argv[2], sys.argv[3]
+sys.path.insert(0, ROOT)
+import torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+torch.cuda.is_available()
+from cice4_amd import lib, synth
+DT, NDTE, NXG, NYG = 3600.0, 120, 96, 72
+c = lib.Context(device=0); c.sync()
+if mode == "slabs":
+    dom = c.domain_create_slabs(NXG, NYG, world, ew=1, ns=0, rank=rank, nranks=world, overlap=4)
+else:
+    dom = c.domain_create(NXG, NYG, NXG, NYG // world, ew=1, ns=0, rank=rank, npx=1, npy=world)
+c.comm_init_shm("/cice4_amd_test_%s" % os.environ["MASTER_PORT"], rank, world, 8 << 20)
+gg = synth.global_grid(NXG, NYG, perturb=0.15, land_frac=0.05, seed=31)
+grid = synth.block_fields(gg, dom)
+s = synth.evp_state(grid, dom, seed=31, cover="patchy")
+c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+if mode == "peer":
+    c.evp_set_option("resident_peer_share", world)
+    every = [None] * world
+    dist.all_gather_object(every, c.evp_peer_export_ipc())
+    if rank > 0: c.evp_peer_connect_ipc(0, every[rank - 1])
+    if rank < world - 1: c.evp_peer_connect_ipc(1, every[rank + 1])
+    assert c.evp_get_info("resident_peer") == 1
+    dist.barrier()
+else:
+    c.evp_set_option("resident", 0)
+c.evp(DT, s)
+fell_back = mode == "peer" and c.evp_get_info("resident_peer") != 1
+r0, r1 = int(dom["own_jlo"][0]) - 1, int(dom["own_jhi"][0])
+j0 = int(dom["j0"][0] + dom["own_jlo"][0] - dom["jlo"][0])
+keys = ("uvel", "vvel", "divu", "shear", "strength", "strintx", "prs_sig", "stressp_1", "stress12_4")
+pickle.dump(dict(j0=j0, fell_back=fell_back, **{k: s[k][0, r0:r1, 1:-1] for k in keys}), open(os.path.join(outdir, "r%d.pkl" % rank), "wb"))
+dist.barrier()                       # nobody unmaps buffers a neighbour may still be writing to
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode,world", [("classic", 2), ("slabs", 2), ("peer", 2), ("peer", 3)])
+def test_rank_processes_on_one_gpu_reproduce_one_domain(tmp_path, mode, world):
+    import pickle
+    sys.path.insert(0, ROOT)
+    from cice4_amd import lib, synth
+    from oracle import oracle
+    orc = oracle.Oracle()
+    c1 = lib.Context()
+    dom1 = c1.domain_create(NXG, NYG, NXG, NYG, ew=1, ns=0)
+    gg = synth.global_grid(NXG, NYG, perturb=0.15, land_frac=0.05, seed=31)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, "-c", RANK_CODE, ROOT, mode, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    parts = sorted((pickle.load(open(tmp_path / f"r{r}.pkl", "rb")) for r in range(world)), key=lambda d: d["j0"])
+    assert not any(p["fell_back"] for p in parts), "the cross-rank loop timed out and fell back"
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strintx", "prs_sig", "stressp_1", "stress12_4"):
+        got = np.concatenate([p[k] for p in parts], axis=0)
+        assert np.array_equal(got, s1[k][0, 1:-1, 1:-1]), (mode, world, k)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("extra", [[], ["--peer-loop"]])
+def test_bench_two_ranks_from_the_plain_command(extra):
+    """`python bench.py --gpus 2` (no torchrun): the bench starts its two rank processes itself; with
+    CICE4_AMD_BENCH_DEVICE=0 / CICE4_AMD_BENCH_LINK=shm both sit on the one GPU and exchange through the shared-memory
+    link.  One JSON line from rank 0, ranks_seen 2."""
+    env = dict(os.environ, CICE4_AMD_BENCH_DEVICE="0", CICE4_AMD_BENCH_LINK="shm")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "gx3", "--steps", "3",
+                        "--warmup", "1", "--no-tenth", "--no-cpu-baseline"] + extra, capture_output=True, text=True,
+                       timeout=500, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
+    if extra:
+        assert "cross-rank one-launch loop" in d["config"]["decomposition"], d["config"]
