@@ -56,6 +56,12 @@ DROPIN=${DROPIN:-0}
 # MPI user of the reference would make (our ice_boundary then also sets up the RCCL communicator).
 MPI=${MPI:-0}
 MPIROOT=${MPIROOT:-/opt/conda}
+# AUS=1: the hot-path modules compiled the way COSIMA's production builds compile them (-DAusCOM -Dcoupled,
+# bld/Macros.nci:56-57) with the constants of drivers/access-om/ice_constants.F90: namelist turning angle / drag / chio,
+# rotation by hemisphere, sea-surface tilt from the ocean model, mom4's cp_ocn and ice salinity.  The macros go to
+# ice_constants, ice_dyn_evp, ice_therm_vertical and ice_atmo only; the set-up and I/O modules of the closure keep the
+# stand-alone form (their AusCOM branches need netCDF and the coupler) -> libcice_<kind>aus_<cfg>.so
+AUS=${AUS:-0}
 KIND=ref
 if [ "$DROPIN" = "1" ]; then
   KIND=dropin
@@ -63,6 +69,18 @@ if [ "$DROPIN" = "1" ]; then
   rm -rf "$OBJ"            # our modules change: never reuse dependents' objects / .mod files
   mkdir -p "$OBJ"
   FFLAGS="${FFLAGS//obj_$CFG/obj_${CFG}_dropin}"
+fi
+if [ "$AUS" = "1" ]; then
+  OBJ0=$OBJ
+  KIND=${KIND}aus
+  OBJ=${OBJ}_aus
+  rm -rf "$OBJ"; mkdir -p "$OBJ"
+  FFLAGS="${FFLAGS//$OBJ0/$OBJ}"
+  # constants: drivers/access-om/ice_constants.F90 (cp_ocn, ice_ref_salinity, ... as COSIMA runs them); the two data
+  # modules of the coupler right behind it
+  SRCS="${SRCS/drivers\/cice4\/ice_constants.F90/drivers/access-om/ice_constants.F90 drivers/access-om/cpl_parameters.F90 drivers/access-om/cpl_arrays_setup.F90}"
+  # (the macro goes to the files named below only: with it ice_read_write.F90, ice_grid.F90 and ice_calendar.F90 turn to
+  # netCDF / the coupler, which this image does not have -- and the hot path does not need)
 fi
 if [ "$MPI" = "1" ]; then
   OBJ0=$OBJ
@@ -75,7 +93,7 @@ fi
 # our own sources unchanged since the last build of this variant: nothing to do (the variants that swap
 # in our modules are otherwise rebuilt from scratch, see above)
 TARGET="$OUT/libcice_${KIND}_$CFG.so"
-if [ "$DROPIN" = "1" ] || [ "$MPI" = "1" ]; then
+if [ "$DROPIN" = "1" ] || [ "$MPI" = "1" ] || [ "$AUS" = "1" ]; then
   if [ -f "$TARGET" ] && [ -z "$(find "$HERE/ref_capi.F90" "$HERE/build_ref.sh" "$HERE/../cice4_amd/fortran" \
         -newer "$TARGET" -name '*.F90' -o -newer "$TARGET" -name '*.sh' 2>/dev/null | head -1)" ]; then
     echo "up to date $TARGET"
@@ -86,6 +104,13 @@ OBJS=""
 for s in $SRCS; do
   src="$REF/$s"
   o=$OBJ/$(basename "${s%.F90}").o
+  FX=""
+  if [ "$AUS" = "1" ]; then
+    case "$(basename $s)" in
+      ice_constants.F90|ice_therm_vertical.F90|ice_atmo.F90) FX="-DAusCOM" ;;
+      ice_dyn_evp.F90) FX="-DAusCOM -Dcoupled" ;;   # `coupled` only where the hot path branches on it (:919-926)
+    esac
+  fi
   if [ "$DROPIN" = "1" ] && [ "$(basename $s)" = "ice_boundary.F90" ]; then
     $FC $FFLAGS -c "$HERE/../cice4_amd/fortran/cice4_amd_c.F90" -o "$OBJ/cice4_amd_c.o"
     OBJS="$OBJS $OBJ/cice4_amd_c.o"
@@ -93,17 +118,18 @@ for s in $SRCS; do
     $FC $FFLAGS -c "$src" -o "$o"
   elif [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_dyn_evp.F90" ]; then
     src="$HERE/../cice4_amd/fortran/ice_dyn_evp.F90"
-    $FC $FFLAGS -c "$src" -o "$o"
+    $FC $FFLAGS $FX -c "$src" -o "$o"
   elif [ "$DROPIN" = "1" ] && [ "$s" = "source/ice_therm_vertical.F90" ]; then
     src="$HERE/../cice4_amd/fortran/ice_therm_vertical.F90"
-    $FC $FFLAGS -c "$src" -o "$o"
+    $FC $FFLAGS $FX -c "$src" -o "$o"
   elif [ ! -f "$o" ] || [ "$src" -nt "$o" ]; then
-    $FC $FFLAGS -c "$src" -o "$o"
+    $FC $FFLAGS $FX -c "$src" -o "$o"
   fi
   OBJS="$OBJS $o"
 done
 EXTRA=""
 if [ "$DROPIN" = "1" ]; then EXTRA="-DDROPIN"; fi
+if [ "$AUS" = "1" ]; then EXTRA="$EXTRA -DREF_AUSCOM"; fi
 $FC $FFLAGS $EXTRA -c "$HERE/ref_capi.F90" -o "$OBJ/ref_capi.o"
 LINK=""
 if [ "$DROPIN" = "1" ]; then

@@ -33,6 +33,10 @@ typedef struct {
 } orc_thermo_cfg;
 
 void orc_set_evp_parameters(double dt, int ndte, int evp_damping, orc_evp_params *p);
+/* on = 1: the -DAusCOM -Dcoupled build of the reference (turning angle and drag from the namelist, rotation by
+ * hemisphere, sea-surface tilt from the ocean model when use_ocnslope); on = 0: the stand-alone build */
+void orc_set_auscom(int on, double cosw, double sinw, double dragio, int use_ocnslope);
+void orc_set_chio(double chio);
 
 void orc_evp_prep1(int nx, int ny, int ilo, int ihi, int jlo, int jhi, const double *aice,
                    const double *vice, const double *vsno, const int32_t *tmask,
@@ -58,6 +62,10 @@ void orc_stress(const orc_evp_params *p, int nx, int ny, int ksub, int icellt,
                 const double *strength, double *const sig[12], double *shear, double *divu,
                 double *prs_sig, double *rdg_conv, double *rdg_shear, double *str);
 
+void orc_evp_finish_fm(int nx, int ny, int icellu, const int32_t *indxui, const int32_t *indxuj,
+                       const double *uvel, const double *vvel, const double *uocn, const double *vocn,
+                       const double *aiu, const double *fm, double *strocnx, double *strocny,
+                       double *strocnxT, double *strocnyT);
 void orc_stepu(int nx, int ny, int icellu, const int32_t *indxui, const int32_t *indxuj,
                const double *aiu, const double *str, const double *uocn, const double *vocn,
                const double *waterx, const double *watery, const double *forcex,

@@ -10,7 +10,20 @@
 #include <time.h>
 
 /* drivers/cice4/ice_constants.F90:49-61,132-179 */
-static const double rhos = 330.0, rhoi = 917.0, rhow = 1026.0, dragio = 0.00536;
+static const double rhos = 330.0, rhoi = 917.0, rhow = 1026.0;
+/* The AusCOM / coupled build of the reference (-DAusCOM -Dcoupled, bld/Macros.nci:56-57) makes the ocean turning angle
+ * and the ice-ocean drag namelist variables (ice_dyn_evp.F90:91-97, ice_init.F90:258-264), rotates with the hemisphere
+ * (:910-913, :1402-1408, :1524-1536) and takes the sea-surface tilt from the ocean model when use_ocnslope is set
+ * (:919-933).  g_aus = 0 is the stand-alone build: the compile-time constants and expressions of that build. */
+static int g_aus = 0, g_ocnslope = 0;
+static double dragio = 0.00536, cosw = 1.0, sinw = 0.0;
+void orc_set_auscom(int on, double cosw_, double sinw_, double dragio_, int use_ocnslope) {
+  g_aus = on;
+  cosw = on ? cosw_ : 1.0;
+  sinw = on ? sinw_ : 0.0;
+  dragio = on ? dragio_ : 0.00536;
+  g_ocnslope = on ? use_ocnslope : 0;
+}
 static const double gravit = 9.80616;
 static const double puny = 1.0e-11;
 static const double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0, p5 = 0.5, p25 = 0.25;
@@ -22,7 +35,7 @@ static const double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0, p5 = 0.5, p25 = 0.25
 #define P027 (P055 * 0.5)
 /* ice_dyn_evp.F90:76-88 */
 #define DRAGW (dragio * rhow)
-static const double eyc = 0.36, cosw = 1.0, sinw = 0.0, a_min = 0.001, m_min = 0.01;
+static const double eyc = 0.36, a_min = 0.001, m_min = 0.01;
 
 #define IX(i, j) ((size_t)((j)-1) * nx + ((i)-1))
 static inline double dmin(double a, double b) { return a < b ? a : b; }
@@ -80,8 +93,7 @@ void orc_evp_prep2(const orc_evp_params *p, int nx, int ny, int ilo, int ihi, in
                    double *strocnx, double *strocny, double *strintx, double *strinty,
                    double *waterx, double *watery, double *forcex, double *forcey,
                    double *const sig[12], double *uvel, double *vvel) {
-  (void)ss_tltx;
-  (void)ss_tlty;
+
   for (int j = 1; j <= ny; j++)
     for (int i = 1; i <= nx; i++) {
       size_t q = IX(i, j);
@@ -124,10 +136,21 @@ void orc_evp_prep2(const orc_evp_params *p, int nx, int ny, int ilo, int ihi, in
     size_t q = IX(indxui[ij], indxuj[ij]);
     umassdtei[q] = umass[q] * p->dtei;
     fm[q] = fcor[q] * umass[q];
-    waterx[q] = uocn[q] * cosw - vocn[q] * sinw;
-    watery[q] = vocn[q] * cosw + uocn[q] * sinw;
-    strtltx[q] = -fm[q] * vocn[q];
-    strtlty[q] = fm[q] * uocn[q];
+    if (g_aus) { /* :910-913: direction of rotation depends on the hemisphere; sign(1., fm): +1 for +-0 ... */
+      const double sg = signbit(fm[q]) ? -1.0 : 1.0;
+      waterx[q] = uocn[q] * cosw - vocn[q] * sinw * sg;
+      watery[q] = vocn[q] * cosw + uocn[q] * sinw * sg;
+    } else {
+      waterx[q] = uocn[q] * cosw - vocn[q] * sinw;
+      watery[q] = vocn[q] * cosw + uocn[q] * sinw;
+    }
+    if (g_aus && g_ocnslope) { /* coupled, :923-925 */
+      strtltx[q] = -gravit * umass[q] * ss_tltx[q];
+      strtlty[q] = -gravit * umass[q] * ss_tlty[q];
+    } else { /* :919-922, and AusCOM without use_ocnslope :928-933 */
+      strtltx[q] = -fm[q] * vocn[q];
+      strtlty[q] = fm[q] * uocn[q];
+    }
     forcex[q] = strairx[q] + strtltx[q];
     forcey[q] = strairy[q] + strtlty[q];
   }
@@ -284,7 +307,7 @@ void orc_stepu(int nx, int ny, int icellu, const int32_t *indxui, const int32_t 
     double vrel = aiu[q] * DRAGW * sqrt(du * du + dv * dv);
     double taux = vrel * waterx[q], tauy = vrel * watery[q];
     double cca = umassdtei[q] + vrel * cosw;
-    double ccb = fm[q] + vrel * sinw;
+    double ccb = (g_aus && fm[q] < 0.) ? fm[q] - vrel * sinw : fm[q] + vrel * sinw; /* :1402-1411 */
     double ab2 = cca * cca + ccb * ccb;
     strintx[q] = uarear[q] * (str[0 * np + IX(i, j)] + str[1 * np + IX(i + 1, j)] +
                               str[2 * np + IX(i, j + 1)] + str[3 * np + IX(i + 1, j + 1)]);
@@ -304,14 +327,28 @@ void orc_evp_finish(int nx, int ny, int icellu, const int32_t *indxui, const int
                     const double *uvel, const double *vvel, const double *uocn,
                     const double *vocn, const double *aiu, double *strocnx, double *strocny,
                     double *strocnxT, double *strocnyT) {
+  orc_evp_finish_fm(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, NULL, strocnx, strocny, strocnxT,
+                    strocnyT);
+}
+
+/* the AusCOM build passes fm as well (:1458-1460) */
+void orc_evp_finish_fm(int nx, int ny, int icellu, const int32_t *indxui, const int32_t *indxuj,
+                       const double *uvel, const double *vvel, const double *uocn, const double *vocn,
+                       const double *aiu, const double *fm, double *strocnx, double *strocny,
+                       double *strocnxT, double *strocnyT) {
   memset(strocnxT, 0, sizeof(double) * nx * ny);
   memset(strocnyT, 0, sizeof(double) * nx * ny);
   for (int ij = 0; ij < icellu; ij++) {
     const size_t q = IX(indxui[ij], indxuj[ij]);
     double du = uocn[q] - uvel[q], dv = vocn[q] - vvel[q];
     double vrel = DRAGW * sqrt(du * du + dv * dv);
-    strocnx[q] = strocnx[q] - vrel * (uvel[q] * cosw - vvel[q] * sinw) * aiu[q];
-    strocny[q] = strocny[q] - vrel * (vvel[q] * cosw + uvel[q] * sinw) * aiu[q];
+    if (g_aus && fm && fm[q] < 0.) { /* :1524-1531 rotate to the opposite direction in the Southern Hemisphere */
+      strocnx[q] = strocnx[q] - vrel * (uvel[q] * cosw + vvel[q] * sinw) * aiu[q];
+      strocny[q] = strocny[q] - vrel * (vvel[q] * cosw - uvel[q] * sinw) * aiu[q];
+    } else {
+      strocnx[q] = strocnx[q] - vrel * (uvel[q] * cosw - vvel[q] * sinw) * aiu[q];
+      strocny[q] = strocny[q] - vrel * (vvel[q] * cosw + uvel[q] * sinw) * aiu[q];
+    }
     strocnxT[q] = strocnx[q] / aiu[q];
     strocnyT[q] = strocny[q] / aiu[q];
   }
@@ -557,9 +594,9 @@ void orc_evp(const orc_domain *d, const orc_evp_params *p, orc_evp_state *s) {
   for (int ksub = 1; ksub <= p->ndte; ksub++) subcycle(d, p, s, &w, ksub); /* :347-404 */
   for (int b = 0; b < d->nblocks; b++) { /* :410-425 */
     size_t o = b * np;
-    orc_evp_finish(nx, ny, w.icellu[b], w.ui + o, w.uj + o, s->uvel + o, s->vvel + o, s->uocn + o,
-                   s->vocn + o, w.aiu + o, s->strocnx + o, s->strocny + o, s->strocnxT + o,
-                   s->strocnyT + o);
+    orc_evp_finish_fm(nx, ny, w.icellu[b], w.ui + o, w.uj + o, s->uvel + o, s->vvel + o, s->uocn + o,
+                      s->vocn + o, w.aiu + o, s->fm + o, s->strocnx + o, s->strocny + o, s->strocnxT + o,
+                      s->strocnyT + o);
   }
   for (int c = 0; c < 2; c++) { /* u2tgrid_vector :427-428, ice_grid.F90:1642 */
     double *f = c ? s->strocnyT : s->strocnxT;

@@ -68,10 +68,13 @@ class EvpState(C.Structure):
 
 
 class Oracle:
-    def __init__(self, omp=False):
-        """omp=True: the -fopenmp build (the two EVP loops spread over OMP_NUM_THREADS host cores; same
+    def __init__(self, omp=False, aus=False):
+        """aus=True: the build with the access-om driver's constants, switched to the AusCOM/coupled branches
+        (set_auscom / set_chio hold their namelist values).  omp=True: the -fopenmp build (the two EVP loops spread over OMP_NUM_THREADS host cores; same
         results) -- bench.py's all-cores cpu_baseline leg only."""
         path = LIB.replace("libcice_oracle.so", "libcice_oracle_omp.so") if omp else LIB
+        if aus:
+            path = LIB.replace("libcice_oracle.so", "libcice_oracle_aus.so")
         if not os.path.exists(path):
             build()
         self.lib = C.CDLL(path)
@@ -80,6 +83,10 @@ class Oracle:
         self.p = EvpParams()
         self.tc = ThermoCfg()
         self.strength_params = (1, 1, 1, 4.0)
+        self.aus = aus
+        if aus:
+            self.set_auscom(True)
+            self.set_chio()
 
     def set_evp_parameters(self, dt, ndte, damping=False):
         self.lib.orc_set_evp_parameters(C.c_double(dt), C.c_int(ndte), C.c_int(int(damping)),
@@ -105,6 +112,14 @@ class Oracle:
                             _p(g["tinyarea"]), _p(strength), self._sigptr(sig), _p(diag["shear"]),
                             _p(diag["divu"]), _p(diag["prs_sig"]), _p(diag["rdg_conv"]),
                             _p(diag["rdg_shear"]), _p(str8))
+
+    def set_auscom(self, on, cosw=1.0, sinw=0.0, dragio=0.00536, use_ocnslope=False):
+        """the -DAusCOM -Dcoupled build's variants of evp_prep2 / stepu / evp_finish (module-wide state of the library)"""
+        self.lib.orc_set_auscom(C.c_int(int(on)), C.c_double(cosw), C.c_double(sinw), C.c_double(dragio),
+                                C.c_int(int(use_ocnslope)))
+
+    def set_chio(self, chio=0.006):
+        self.lib.orc_set_chio(C.c_double(chio))
 
     def stepu(self, icellu, indxui, indxuj, aiu, str8, uocn, vocn, waterx, watery, forcex, forcey,
               umassdtei, fm, uarear, strocnx, strocny, strintx, strinty, uvel, vvel):
@@ -146,6 +161,13 @@ class Oracle:
         self.lib.orc_evp_finish(C.c_int(nx), C.c_int(ny), C.c_int(icellu), _p(indxui), _p(indxuj),
                                 _p(uvel), _p(vvel), _p(uocn), _p(vocn), _p(aiu), _p(strocnx),
                                 _p(strocny), _p(strocnxT), _p(strocnyT))
+
+    def evp_finish_fm(self, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, fm, strocnx, strocny,
+                      strocnxT, strocnyT):
+        ny, nx = uvel.shape
+        self.lib.orc_evp_finish_fm(C.c_int(nx), C.c_int(ny), C.c_int(icellu), _p(indxui), _p(indxuj),
+                                   _p(uvel), _p(vvel), _p(uocn), _p(vocn), _p(aiu), _p(fm), _p(strocnx),
+                                   _p(strocny), _p(strocnxT), _p(strocnyT))
 
     def ice_strength(self, ilo, ihi, jlo, jhi, icells, indxi, indxj, aice, vice, aice0, aicen, vicen):
         ny, nx = aice.shape

@@ -44,7 +44,30 @@ contains
       ntrcr   = 2
       tr_iage = .true.
       booted = .true.
+#ifdef REF_AUSCOM
+      call ref_set_auscom(1.0_c_double, 0.0_c_double, 0.00536_c_double, 0.006_c_double, 0_c_int)   ! ice_init.F90:258-267
+#endif
    end subroutine ref_boot
+
+#ifdef REF_AUSCOM
+   ! AusCOM / coupled build of ice_dyn_evp and ice_therm_vertical: the namelist variables ice_init would read, and the
+   ! coupler array evp writes (sicemass, ice_dyn_evp.F90:246-248: allocated by the access-om driver's set-up otherwise)
+   subroutine ref_set_auscom(cosw_in, sinw_in, dragio_in, chio_in, ocnslope) bind(C, name='ref_set_auscom')
+      use ice_dyn_evp, only: cosw, sinw, dragio
+      use ice_therm_vertical, only: chio
+      use cpl_parameters, only: use_ocnslope
+      use cpl_arrays_setup, only: sicemass
+      use ice_blocks, only: nx_block, ny_block
+      use ice_constants, only: Tocnfrz
+      use ice_atmo, only: iceruf
+      real(c_double), value :: cosw_in, sinw_in, dragio_in, chio_in
+      integer(c_int), value :: ocnslope
+      Tocnfrz = -1.8_dbl_kind; iceruf = 0.0005_dbl_kind       ! ice_init.F90 defaults of the namelist variables
+      cosw = cosw_in; sinw = sinw_in; dragio = dragio_in; chio = chio_in
+      use_ocnslope = (ocnslope /= 0)
+      if (.not. allocated(sicemass)) allocate(sicemass(nx_block, ny_block, max_blocks))
+   end subroutine ref_set_auscom
+#endif
 
    subroutine ref_dims(d) bind(C, name='ref_dims')
       use ice_blocks, only: nx_block, ny_block
@@ -177,9 +200,26 @@ contains
       integer(c_int), intent(in) :: indxui(nx*ny), indxuj(nx*ny)
       real(c_double), dimension(nx,ny), intent(in) :: uvel, vvel, uocn, vocn, aiu
       real(c_double), dimension(nx,ny), intent(inout) :: strocnx, strocny, strocnxT, strocnyT
+#ifdef REF_AUSCOM
+      stop 'ref_evp_finish: the AusCOM build takes fm (ref_evp_finish_fm)'
+#else
       call evp_finish(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, &
          strocnx, strocny, strocnxT, strocnyT)
+#endif
    end subroutine ref_evp_finish
+
+#ifdef REF_AUSCOM
+   subroutine ref_evp_finish_fm(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, &
+         aiu, fm, strocnx, strocny, strocnxT, strocnyT) bind(C, name='ref_evp_finish_fm')
+      use ice_dyn_evp, only: evp_finish
+      integer(c_int), value :: nx, ny, icellu
+      integer(c_int), intent(in) :: indxui(nx*ny), indxuj(nx*ny)
+      real(c_double), dimension(nx,ny), intent(in) :: uvel, vvel, uocn, vocn, aiu, fm
+      real(c_double), dimension(nx,ny), intent(inout) :: strocnx, strocny, strocnxT, strocnyT
+      call evp_finish(nx, ny, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, fm, &
+         strocnx, strocny, strocnxT, strocnyT)
+   end subroutine ref_evp_finish_fm
+#endif
 
 #endif
    subroutine ref_ice_strength(nx, ny, ilo, ihi, jlo, jhi, icells, indxi, indxj, &

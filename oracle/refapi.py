@@ -142,6 +142,18 @@ class Ref:
                                 _p(uvel), _p(vvel), _p(uocn), _p(vocn), _p(aiu), _p(strocnx),
                                 _p(strocny), _p(strocnxT), _p(strocnyT))
 
+    def set_auscom(self, cosw=1.0, sinw=0.0, dragio=0.00536, chio=0.006, use_ocnslope=False):
+        """kind 'refaus' only (the -DAusCOM -Dcoupled build): the namelist values ice_init.F90:258-267 reads"""
+        self.lib.ref_set_auscom(C.c_double(cosw), C.c_double(sinw), C.c_double(dragio), C.c_double(chio),
+                                C.c_int(int(use_ocnslope)))
+
+    def evp_finish_fm(self, icellu, indxui, indxuj, uvel, vvel, uocn, vocn, aiu, fm, strocnx, strocny,
+                      strocnxT, strocnyT):
+        ny, nx = uvel.shape
+        self.lib.ref_evp_finish_fm(C.c_int(nx), C.c_int(ny), C.c_int(icellu), _p(indxui), _p(indxuj),
+                                   _p(uvel), _p(vvel), _p(uocn), _p(vocn), _p(aiu), _p(fm), _p(strocnx),
+                                   _p(strocny), _p(strocnxT), _p(strocnyT))
+
     def ice_strength(self, ilo, ihi, jlo, jhi, icells, indxi, indxj, aice, vice, aice0, aicen, vicen):
         ny, nx = aice.shape
         strength = np.zeros((ny, nx))

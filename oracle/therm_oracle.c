@@ -20,12 +20,16 @@
 
 /* drivers/cice4/ice_constants.F90:49-121 */
 static const double rhos = 330.0, rhoi = 917.0, rhow = 1026.0;
-static const double emissivity = 0.95, cp_ice = 2106.0, cp_ocn = 4218.0, depressT = 0.054;
+static const double emissivity = 0.95, cp_ice = 2106.0, depressT = 0.054;
+#ifdef ORC_AUSCOM /* drivers/access-om/ice_constants.F90:21,48: the two constants the coupled build takes from MOM */
+static const double cp_ocn = 3989.24495292815, ice_ref_salinity = 5.0;
+#else
+static const double cp_ocn = 4218.0, ice_ref_salinity = 4.0;
+#endif
 static const double pi = 3.14159265358979323846;
 static const double stefan_boltzmann = 567.0e-10, Tffresh = 273.15, Lsub = 2.835e6,
                     Lvap = 2.501e6;
 #define Lfresh (Lsub - Lvap)
-static const double ice_ref_salinity = 4.0;
 static const double kice = 2.03, ksno = 0.30;
 static const double qqqice = 11637800.0, TTTice = 5897.8;
 static const double puny = 1.0e-11;
@@ -753,14 +757,18 @@ int orc_thermo_vertical(const orc_thermo_cfg *c, int nx, int ny, double dt, int 
   return 0;
 }
 
-/* frzmlt_bottom_lateral :605-824 (non-AusCOM: cpchr is a compile-time constant) */
+/* frzmlt_bottom_lateral :605-824.  cpchr = -cp_ocn*rhow*chio: chio is the constant 0.006 in the stand-alone build and a
+ * namelist variable in the AusCOM build (:57-59, :673-694); orc_set_chio(0.006) gives the same double either way. */
+static double g_chio = 0.006;
+void orc_set_chio(double chio) { g_chio = chio; }
+
 void orc_frzmlt_bottom_lateral(const orc_thermo_cfg *c, int nx, int ny, int ilo, int ihi, int jlo,
                                int jhi, double dt, const double *aice, const double *frzmlt,
                                const double *eicen, const double *esnon, const double *sst,
                                const double *Tf, const double *strocnxT, const double *strocnyT,
                                double *Tbot, double *fbot, double *rside) {
   const size_t np = (size_t)nx * ny;
-  const double cpchr = -cp_ocn * rhow * 0.006;
+  const double cpchr = -cp_ocn * rhow * g_chio;
   const double floediam = 300.0, alpha = 0.66, m1 = 1.6e-6, m2 = 1.36;
   for (size_t q = 0; q < np; q++) {
     rside[q] = c0;

@@ -21,11 +21,11 @@ def orc():
     return oracle.Oracle()
 
 
-def _ref(cfg):
+def _ref(cfg, kind="ref"):
     from oracle import refapi
-    if not refapi.available(cfg):
-        pytest.skip(f"compiled reference oracle/_ref/libcice_ref_{cfg}.so not built")
-    return refapi.Ref(cfg)
+    if not refapi.available(cfg, kind):
+        pytest.skip(f"compiled reference oracle/_ref/libcice_{kind}_{cfg}.so not built")
+    return refapi.Ref(cfg, kind)
 
 
 @pytest.fixture(scope="session")
@@ -36,6 +36,19 @@ def ref_gx3():
 @pytest.fixture(scope="session")
 def ref_gx3b4():
     return _ref("gx3b4")
+
+
+@pytest.fixture(scope="session")
+def refaus_gx3b4():
+    """the reference compiled -DAusCOM -Dcoupled with the access-om driver's constants (AUS=1 oracle/build_ref.sh)"""
+    return _ref("gx3b4", "refaus")
+
+
+@pytest.fixture(scope="session")
+def orc_aus():
+    from oracle import oracle
+    oracle.build()
+    return oracle.Oracle(aus=True)
 
 
 @pytest.fixture(scope="session")
