@@ -34,6 +34,9 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
+  double chio = 0.006;         // coupled flavour: the namelist's chio (cice_thermo_set_chio)
+  double nml[4] = {1.0, 0.0, 0.00536, 0.0};   // coupled flavour: cosw, sinw, dragio, use_ocnslope last sent to the device
+  bool nml_set = false;
   LocalLink* link = nullptr;   // stand-in for the communicator without RCCL (cice_comm_init_local / _shm; tests)
   bool link_owned = false;     // the shared-memory form belongs to this context
   // Page-locked host ranges of this context: [start, end) in bytes, disjoint.  One manager for the explicit
@@ -1357,6 +1360,44 @@ static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long 
   CICE_HIP(hipMemcpyAsync(status, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
 }
 
+const char* cice_build_flavour(void) {
+#ifdef CICE4_AMD_AUSCOM
+  return "auscom";
+#else
+  return "standalone";
+#endif
+}
+
+int cice_set_auscom(cice_ctx* ctx, double cosw, double sinw, double dragio, int use_ocnslope) {
+  CICE_TRY(ctx)
+#ifdef CICE4_AMD_AUSCOM
+  const double want[4] = {cosw, sinw, dragio, use_ocnslope ? 1.0 : 0.0};
+  if (c_->nml_set && !std::memcmp(want, c_->nml, sizeof(want))) return CICE_OK;   // called before every evp(dt)
+  CICE_HIP(hipStreamSynchronize(c_->stream));   // nothing in flight reads the old values
+  evp_set_namelist(cosw, sinw, dragio, use_ocnslope);
+  std::memcpy(c_->nml, want, sizeof(want));
+  c_->nml_set = true;
+#else
+  (void)cosw; (void)sinw; (void)dragio; (void)use_ocnslope;
+  throw Error{CICE_EINVAL, "cice_set_auscom: this is the stand-alone build of the library (libcice4_amd.so); the coupled "
+                           "one, with the access-om constants and the hemisphere-dependent turning angle, is "
+                           "libcice4_amd_auscom.so"};
+#endif
+  CICE_CATCH
+}
+
+int cice_thermo_set_chio(cice_ctx* ctx, double chio) {
+  CICE_TRY(ctx)
+#ifdef CICE4_AMD_AUSCOM
+  c_->chio = chio;   // a kernel argument of frzmlt_bottom_lateral: later launches see it
+#else
+  (void)chio;
+  throw Error{CICE_EINVAL, "cice_thermo_set_chio: this is the stand-alone build of the library (chio is the constant "
+                           "0.006 there, ice_therm_vertical.F90:680); the coupled one is libcice4_amd_auscom.so"};
+#endif
+  CICE_CATCH
+}
+
 int cice_thermo_set_option(cice_ctx* ctx, const char* key, int value) {
   CICE_TRY(ctx)
   CICE_REQUIRE(key, "NULL key");
@@ -1501,7 +1542,7 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
     CICE_HIP(hipMemcpyAsync(t.fz_in.p + (size_t)k * n2, fin[k], n2 * 8, hipMemcpyHostToDevice, s));
   for (int b = 0; b < t.nb; ++b) {   // frzmlt_bottom_lateral per block, on the uploaded enthalpies
     FrzmltArgs a{};
-    a.nx = t.nx; a.ny = t.ny; a.dt = dt; a.ustar_min = c_->tp.ustar_min;
+    a.nx = t.nx; a.ny = t.ny; a.dt = dt; a.ustar_min = c_->tp.ustar_min; a.chio = c_->chio;
     a.ilo = t.hblk[4 * b]; a.ihi = t.hblk[4 * b + 1]; a.jlo = t.hblk[4 * b + 2]; a.jhi = t.hblk[4 * b + 3];
     const size_t o = (size_t)b * np;
     a.aice = t.fz_in.p + o; a.frzmlt = t.fz_in.p + n2 + o; a.sst = t.fz_in.p + 2 * n2 + o;
@@ -1619,7 +1660,7 @@ int cice_frzmlt_bottom_lateral(cice_ctx* ctx, int nx, int ny, int ilo, int ihi, 
   up(9, eicen, NE); up(9 + NE, esnon, NSN);
   FrzmltArgs a{};
   a.nx = nx; a.ny = ny; a.ilo = ilo; a.ihi = ihi; a.jlo = jlo; a.jhi = jhi; a.dt = dt;
-  a.ustar_min = c_->tp.ustar_min;
+  a.ustar_min = c_->tp.ustar_min; a.chio = c_->chio;
   a.aice = d.p; a.frzmlt = d.p + np; a.sst = d.p + 2 * np; a.Tf = d.p + 3 * np;
   a.strocnxT = d.p + 4 * np; a.strocnyT = d.p + 5 * np;
   a.Tbot = d.p + 6 * np; a.fbot = d.p + 7 * np; a.rside = d.p + 8 * np;

@@ -14,12 +14,16 @@ namespace cice {
 // drivers/cice4/ice_constants.F90:49-121,132-179 (CICE default parameter set)
 namespace K {
 constexpr double rhos = 330.0, rhoi = 917.0, rhow = 1026.0;
-constexpr double cp_ice = 2106.0, cp_ocn = 4218.0, depressT = 0.054, emissivity = 0.95;
+constexpr double cp_ice = 2106.0, depressT = 0.054, emissivity = 0.95;
+#ifdef CICE4_AMD_AUSCOM   // the coupled flavour of the library: drivers/access-om/ice_constants.F90:21,48 (MOM's values)
+constexpr double cp_ocn = 3989.24495292815, ice_ref_salinity = 5.0;
+#else
+constexpr double cp_ocn = 4218.0, ice_ref_salinity = 4.0;
+#endif
 constexpr double dragio = 0.00536, gravit = 9.80616;
 constexpr double pi = 3.14159265358979323846;
 constexpr double stefan_boltzmann = 567.0e-10, Tffresh = 273.15, Lsub = 2.835e6, Lvap = 2.501e6;
 constexpr double Lfresh = Lsub - Lvap;
-constexpr double ice_ref_salinity = 4.0;
 constexpr double kice = 2.03, ksno = 0.30;
 constexpr double qqqice = 11637800.0, TTTice = 5897.8;
 constexpr double puny = 1.0e-11;
@@ -28,8 +32,10 @@ constexpr double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0, p5 = 0.5, p25 = 0.25, p
 constexpr double p166 = 1.0 / 6.0, p333 = 1.0 / 3.0, p111 = 1.0 / 9.0, p222 = 2.0 / 9.0;
 constexpr double p055 = p111 * 0.5, p027 = p055 * 0.5;  // halved, not 1/18, 1/36 (:170-171)
 // source/ice_dyn_evp.F90:76-88
-constexpr double dragw = dragio * rhow, eyc = 0.36, cosw = 1.0, sinw = 0.0, a_min = 0.001,
-                 m_min = 0.01;
+constexpr double eyc = 0.36, a_min = 0.001, m_min = 0.01;
+#ifndef CICE4_AMD_AUSCOM   // namelist variables in the coupled flavour (:91-97): device constants in evp.hip
+constexpr double dragw = dragio * rhow, cosw = 1.0, sinw = 0.0;
+#endif
 // source/ice_therm_vertical.F90:45-49,64-65
 constexpr double saltmax = 3.2, hs_min = 1.0e-4, betak = 0.13, kimin = 0.10, ferrmax = 1.0e-3;
 }  // namespace K

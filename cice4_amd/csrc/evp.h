@@ -150,4 +150,9 @@ class Evp {
   void drop_graph();
 };
 
+#ifdef CICE4_AMD_AUSCOM
+// the coupled flavour's namelist variables (ice_dyn_evp.F90:91-97, ice_init.F90:258-264) on the current device
+void evp_set_namelist(double cosw, double sinw, double dragio, int use_ocnslope);
+#endif
+
 }  // namespace cice

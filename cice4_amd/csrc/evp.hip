@@ -23,6 +23,23 @@ namespace cice {
 
 using namespace K;
 
+#ifdef CICE4_AMD_AUSCOM
+// Namelist variables of the coupled build (ice_dyn_evp.F90:91-97; defaults of ice_init.F90:258-264); dragw is formed
+// as stepu forms it (:1382).  Device constants: every kernel below names them as the stand-alone build names its
+// compile-time constants.
+__constant__ double cosw = 1.0, sinw = 0.0, dragw = dragio * rhow;
+__constant__ int ocnslope = 0;
+
+void evp_set_namelist(double cosw_, double sinw_, double dragio_, int use_ocnslope) {
+  const double dragw_ = dragio_ * rhow;
+  const int os = use_ocnslope != 0;
+  CICE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(cosw), &cosw_, 8));
+  CICE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(sinw), &sinw_, 8));
+  CICE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(dragw), &dragw_, 8));
+  CICE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ocnslope), &os, 4));
+}
+#endif
+
 void EvpScalars::set(double dt, int ndte_, int damping) {
   ndte = ndte_;
   evp_damping = damping;
@@ -152,6 +169,20 @@ __device__ __forceinline__ void stress_cell(const EvpScalars& sc, double u_ne, d
   o.str[7] = strp_tmp - strm_tmp + str12sn - Dyhx * (csigpsw + csigmsw) + Dxhy * csig12sw;
 }
 
+// Ocean stress direction, evp_prep2's expressions (ice_dyn_evp.F90:909-917).  The coupled flavour turns with the
+// hemisphere: sign(1., real(fm)) is the sign BIT of fm (the conversion to single keeps it, zeros included).
+__device__ __forceinline__ void water_of(double uo, double vo, double fmv, double& wx, double& wy) {
+#ifdef CICE4_AMD_AUSCOM
+  const double sg = __builtin_signbit(fmv) ? -1.0 : 1.0;
+  wx = uo * cosw - vo * sinw * sg;
+  wy = vo * cosw + uo * sinw * sg;
+#else
+  (void)fmv;
+  wx = uo * cosw - vo * sinw;
+  wy = vo * cosw + uo * sinw;
+#endif
+}
+
 struct StepuOut {
   double u, v, strintx, strinty, taux, tauy;
 };
@@ -166,7 +197,11 @@ __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu,
   o.taux = vrel * Waterx;
   o.tauy = vrel * Watery;
   const double cca = Umassdtei + vrel * cosw;
+#ifdef CICE4_AMD_AUSCOM   // :1402-1408: the turning angle changes sign with the hemisphere
+  const double ccb = Fm < 0.0 ? Fm - vrel * sinw : Fm + vrel * sinw;
+#else
   const double ccb = Fm + vrel * sinw;
+#endif
   const double ab2 = cca * cca + ccb * ccb;
   o.strintx = Uarear * sx;
   o.strinty = Uarear * sy;
@@ -272,15 +307,13 @@ struct UIn {  // the ten read-only U-cell fields of stepu (ice_dyn_evp.F90:1339-
 template <bool DERIVE>
 __device__ __forceinline__ void load_uin(const SubArgs& a, size_t q, UIn& x) {
   x.aiu = a.aiu[q]; x.uocn = a.uocn[q]; x.vocn = a.vocn[q];
-  if (DERIVE) {  // evp_prep2's own expressions (ice_dyn_evp.F90:915-916) instead of two loads
-    x.waterx = x.uocn * cosw - x.vocn * sinw;
-    x.watery = x.vocn * cosw + x.uocn * sinw;
-  } else {
+  if (!DERIVE) {
     x.waterx = a.waterx[q];
     x.watery = a.watery[q];
   }
   x.forcex = a.forcex[q]; x.forcey = a.forcey[q];
   x.umassdtei = a.umassdtei[q]; x.fm = a.fm[q]; x.uarear = a.uarear[q];
+  if (DERIVE) water_of(x.uocn, x.vocn, x.fm, x.waterx, x.watery);   // instead of two loads
 }
 
 // Momentum update of one U-cell inside the fused kernel + forwarding of the new velocity to
@@ -530,15 +563,13 @@ __device__ __forceinline__ int ld4(const int32_t* p, unsigned off) {
 template <bool DERIVE>
 __device__ __forceinline__ void load_uin_o(const SubArgs& a, size_t base, unsigned qo, UIn& x) {
   x.aiu = ld8(a.aiu + base, qo); x.uocn = ld8(a.uocn + base, qo); x.vocn = ld8(a.vocn + base, qo);
-  if (DERIVE) {  // evp_prep2's own expressions (ice_dyn_evp.F90:915-916) instead of two loads
-    x.waterx = x.uocn * cosw - x.vocn * sinw;
-    x.watery = x.vocn * cosw + x.uocn * sinw;
-  } else {
+  if (!DERIVE) {
     x.waterx = ld8(a.waterx + base, qo);
     x.watery = ld8(a.watery + base, qo);
   }
   x.forcex = ld8(a.forcex + base, qo); x.forcey = ld8(a.forcey + base, qo);
   x.umassdtei = ld8(a.umassdtei + base, qo); x.fm = ld8(a.fm + base, qo); x.uarear = ld8(a.uarear + base, qo);
+  if (DERIVE) water_of(x.uocn, x.vocn, x.fm, x.waterx, x.watery);   // instead of two loads
 }
 
 // stepu_store with the same addressing
@@ -789,8 +820,7 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
     if (PARK) {   // this lane wrote them itself before the first momentum update
       x.aiu = s_x[w][0][lx]; x.uocn = s_x[w][1][lx]; x.vocn = s_x[w][2][lx]; x.forcex = s_x[w][3][lx];
       x.forcey = s_x[w][4][lx]; x.umassdtei = s_x[w][5][lx]; x.fm = s_x[w][6][lx]; x.uarear = s_x[w][7][lx];
-      x.waterx = x.uocn * cosw - x.vocn * sinw;
-      x.watery = x.vocn * cosw + x.uocn * sinw;
+      water_of(x.uocn, x.vocn, x.fm, x.waterx, x.watery);
     } else {
       load_uin_o<DERIVE>(a, base, qo, x);
     }
@@ -1106,8 +1136,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         UIn x;
         x.aiu = xa; x.uocn = xuo; x.vocn = xvo; x.forcex = xfx; x.forcey = xfy; x.umassdtei = xum; x.fm = xfm;
         x.uarear = xur;
-        x.waterx = xuo * cosw - xvo * sinw;   // evp_prep2's own expressions (ice_dyn_evp.F90:915-916)
-        x.watery = xvo * cosw + xuo * sinw;
+        water_of(xuo, xvo, xfm, x.waterx, x.watery);
         if (lastlev) {
           if (own_col && ru >= ja && ru <= jb) {
             if (sa.fwd_rule) {
@@ -1394,7 +1423,9 @@ __global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(c
       const double sy = o.str[4] + s_edge[w + 1][2][lx] + e6 + s_edge[w + 1][3][lx];   // :1417-1418 order
       const double uocn = s_x[w][1][lx], vocn = s_x[w][2][lx];
       // waterx, watery are evp_prep2's own expressions of uocn, vocn (:915-916): recomputed, same bits
-      stepu_cell(un, vn, s_x[w][0][lx], uocn, vocn, uocn * cosw - vocn * sinw, vocn * cosw + uocn * sinw,
+      double wx, wy;
+      water_of(uocn, vocn, s_x[w][6][lx], wx, wy);
+      stepu_cell(un, vn, s_x[w][0][lx], uocn, vocn, wx, wy,
                  s_x[w][3][lx], s_x[w][4][lx], s_x[w][5][lx], s_x[w][6][lx], s_x[w][7][lx], sx, sy, ro);
       un = ro.u;
       vn = ro.v;
@@ -1636,6 +1667,7 @@ struct PrepArgs {
   size_t n;
   const int32_t *blk, *tmask, *umask;
   const double *aice, *vice, *vsno, *aice0, *aicen, *vicen, *strairxT, *strairyT, *uocn, *vocn;
+  const double *ss_tltx, *ss_tlty;
   const double *tarea, *uarea, *fcor;
   double *strairx, *strairy, *tmass, *umass, *aiu, *work1;
   int32_t *icetmask, *iceumask;
@@ -1743,9 +1775,13 @@ __global__ __launch_bounds__(256) void k_prep2(const PrepArgs a) {
       umd = a.umass[t] * a.sc.dtei;
       const double fmv = a.fcor[t] * a.umass[t];
       a.fm[t] = fmv;
-      wx = a.uocn[t] * cosw - a.vocn[t] * sinw;
-      wy = a.vocn[t] * cosw + a.uocn[t] * sinw;
+      water_of(a.uocn[t], a.vocn[t], fmv, wx, wy);
+#ifdef CICE4_AMD_AUSCOM   // :919-933: the tilt from the ocean model's surface slope when use_ocnslope is set
+      const double tx = ocnslope ? -gravit * a.umass[t] * a.ss_tltx[t] : -fmv * a.vocn[t];
+      const double ty = ocnslope ? -gravit * a.umass[t] * a.ss_tlty[t] : fmv * a.uocn[t];
+#else
       const double tx = -fmv * a.vocn[t], ty = fmv * a.uocn[t];
+#endif
       a.strtltx[t] = tx;
       a.strtlty[t] = ty;
       fx = a.strairx[t] + tx;
@@ -1858,8 +1894,14 @@ __global__ __launch_bounds__(256) void k_finish(const PrepArgs a) {
   if (i >= ilo && i <= ihi && j >= jlo && j <= jhi && a.iceumask[t]) {  // the indxu list
     const double du = a.uocn[t] - a.u[t], dv = a.vocn[t] - a.v[t];
     const double vrel = dragw * sqrt(du * du + dv * dv);
+#ifdef CICE4_AMD_AUSCOM   // :1524-1536: rotate to the opposite direction in the Southern Hemisphere
+    const bool south = a.fm[t] < 0.0;
+    const double sx = a.strocnx[t] - vrel * (south ? a.u[t] * cosw + a.v[t] * sinw : a.u[t] * cosw - a.v[t] * sinw) * a.aiu[t];
+    const double sy = a.strocny[t] - vrel * (south ? a.v[t] * cosw - a.u[t] * sinw : a.v[t] * cosw + a.u[t] * sinw) * a.aiu[t];
+#else
     const double sx = a.strocnx[t] - vrel * (a.u[t] * cosw - a.v[t] * sinw) * a.aiu[t];
     const double sy = a.strocny[t] - vrel * (a.v[t] * cosw + a.u[t] * sinw) * a.aiu[t];
+#endif
     a.strocnx[t] = sx;
     a.strocny[t] = sy;
     xT = sx / a.aiu[t];
@@ -2153,6 +2195,7 @@ void Evp::prepare(double dt) {
   a.blk = blk.p; a.tmask = tmask.p; a.umask = umask.p;
   a.aice = aice.p; a.vice = vice.p; a.vsno = vsno.p; a.aice0 = aice0.p; a.aicen = aicen.p;
   a.vicen = vicen.p; a.strairxT = strairxT.p; a.strairyT = strairyT.p; a.uocn = uocn.p; a.vocn = vocn.p;
+  a.ss_tltx = ss_tltx.p; a.ss_tlty = ss_tlty.p;
   a.tarea = tarea.p; a.uarea = uarea.p; a.fcor = fcor.p;
   a.strairx = strairx.p; a.strairy = strairy.p; a.tmass = tmass.p; a.umass = umass.p; a.aiu = aiu.p;
   a.work1 = work1.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
@@ -3032,7 +3075,7 @@ void Evp::finish() {
   a.nx = dom.nx_block; a.ny = dom.ny_block; a.nblocks = dom.nblocks(); a.n = n; a.blk = blk.p;
   a.iceumask = iceumask.p; a.uocn = uocn.p; a.vocn = vocn.p; a.u = uv[cur].p; a.v = uv[cur].p + n;
   a.aiu = aiu.p; a.strocnx = strocnx.p; a.strocny = strocny.p; a.strocnxT = strocnxT.p;
-  a.strocnyT = strocnyT.p; a.tarea = tarea.p; a.uarea = uarea.p;
+  a.strocnyT = strocnyT.p; a.tarea = tarea.p; a.uarea = uarea.p; a.fm = fm.p;
   const dim3 g = grid1(n), blk256(256);
   hipLaunchKernelGGL(k_finish, g, blk256, 0, stream, a);  // :410-425
   // u2tgrid_vector :427-428 = copy, halo update (NE corner), to_tgrid

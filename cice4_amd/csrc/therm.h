@@ -55,6 +55,7 @@ void merge_launch(const MergeArgs& a, hipStream_t s);
 struct FrzmltArgs {
   int nx, ny, ilo, ihi, jlo, jhi;
   double dt, ustar_min;
+  double chio;   // coupled flavour only (ice_therm_vertical.F90:57-60,692-694); the stand-alone build's constant 0.006
   const double *aice, *frzmlt, *eicen, *esnon, *sst, *Tf, *strocnxT, *strocnyT;
   double *Tbot, *fbot, *rside;
 };

@@ -926,12 +926,17 @@ __global__ __launch_bounds__(256) void k_merge(const MergeArgs a) {
   }
 }
 
-// frzmlt_bottom_lateral :605-824 (cpchr compile-time constant of the non-AusCOM build)
+// frzmlt_bottom_lateral :605-824 (cpchr: a compile-time constant of the stand-alone build, formed from the namelist's
+// chio in the coupled one, :673-694)
 __global__ __launch_bounds__(256) void k_frzmlt(const FrzmltArgs a) {
   const size_t np = (size_t)a.nx * a.ny;
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= np) return;
+#ifdef CICE4_AMD_AUSCOM
+  const double cpchr = -cp_ocn * rhow * a.chio;
+#else
   constexpr double cpchr = -cp_ocn * rhow * 0.006;
+#endif
   constexpr double floediam = 300.0, alpha = 0.66, m1 = 1.6e-6, m2 = 1.36;
   const int j = (int)(q / a.nx) + 1, i = (int)(q - (size_t)(j - 1) * a.nx) + 1;
   double rside = c0, Tbot = a.Tf[q], fbot = c0;

@@ -270,6 +270,18 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          integer(c_int), value :: ncat, nilyr, nslyr, max_ntrcr
       end function
+      ! libcice4_amd_auscom.so only (the library for a reference built -DAusCOM -Dcoupled)
+      integer(c_int) function cice_set_auscom(ctx, cosw, sinw, dragio, use_ocnslope) bind(C, name='cice_set_auscom')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: cosw, sinw, dragio
+         integer(c_int), value :: use_ocnslope
+      end function
+      integer(c_int) function cice_thermo_set_chio(ctx, chio) bind(C, name='cice_thermo_set_chio')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: chio
+      end function
       integer(c_int) function cice_comm_init_local(ctx, link_id, rank, nranks) bind(C, name='cice_comm_init_local')
          import
          type(c_ptr), value :: ctx

@@ -12,6 +12,10 @@
 !
 ! Build: put this file in place of source/ice_dyn_evp.F90, add
 ! cice4_amd_c.F90 to the source list and link with -lcice4_amd.
+! With -DAusCOM (bld/Macros.nci:56-57) the module has the coupled build's
+! public entities as well -- the namelist variables cosw, sinw, dragio
+! (ice_init.F90:97,156) -- writes the coupler's sicemass as the
+! reference's evp does (:246-248), and links with -lcice4_amd_auscom.
 !=======================================================================
       module ice_dyn_evp
 
@@ -31,9 +35,15 @@
       logical (kind=log_kind) :: evp_damping
       character (len=char_len) :: yield_curve
 
+#if defined(AusCOM)
+      real (kind=dbl_kind), parameter :: &
+         eyc = 0.36_dbl_kind, a_min = p001, m_min = p01
+      real (kind=dbl_kind) :: dragio, cosw, sinw, dragw   ! namelist (dragw = dragio*rhow)
+#else
       real (kind=dbl_kind), parameter :: &
          dragw = dragio * rhow, eyc = 0.36_dbl_kind, cosw = c1, sinw = c0, &
          a_min = p001, m_min = p01
+#endif
 
       real (kind=dbl_kind) :: ecci, dtei, dte2T, denom1, denom2, rcon
 
@@ -47,10 +57,30 @@
       use ice_state
       use ice_flux
       use ice_timers
+#if defined(AusCOM)
+      use ice_domain, only: nblocks
+      use ice_grid, only: tmask
+      use cpl_parameters, only: use_ocnslope
+      use cpl_arrays_setup, only: sicemass
+#endif
       real (kind=dbl_kind), intent(in) :: dt
       type (cice_evp_fields) :: f
+#if defined(AusCOM)
+      integer (kind=int_kind) :: iblk
+#endif
 
       call ice_timer_start(timer_dynamics)
+#if defined(AusCOM)
+      dragw = dragio * rhow
+      call cice_gpu_check(cice_set_auscom(cice_gpu_ctx, cosw, sinw, dragio, &
+                          merge(1_c_int, 0_c_int, use_ocnslope)), 'cice_set_auscom')
+      ! the ice + snow mass handed to the ocean (:246-248: tmass of evp_prep1, :651-655)
+      if (allocated(sicemass)) then
+         do iblk = 1, nblocks
+            sicemass(:,:,iblk) = merge(rhoi*vice(:,:,iblk) + rhos*vsno(:,:,iblk), c0, tmask(:,:,iblk))
+         enddo
+      endif
+#endif
       f%aice = addr_r8(aice);  f%vice = addr_r8(vice);  f%vsno = addr_r8(vsno)
       f%aice0 = addr_r8(aice0); f%aicen = addr_r8(aicen); f%vicen = addr_r8(vicen)
       f%strairxT = addr_r8(strairxT); f%strairyT = addr_r8(strairyT)

@@ -28,6 +28,9 @@
 
       real (kind=dbl_kind), dimension(nilyr+1) :: salin, Tmlt
       real (kind=dbl_kind) :: ustar_min
+#if defined(AusCOM)
+      real (kind=dbl_kind) :: chio   ! namelist (ice_init.F90:99,156): basal heat transfer, link with -lcice4_amd_auscom
+#endif
       character (char_len) :: conduct
       logical (kind=log_kind) :: l_brine, heat_capacity, calc_Tsfc
 
@@ -106,6 +109,9 @@
       real (kind=dbl_kind), dimension(nx_block,ny_block,ntslyr), intent(in) :: esnon
       real (kind=dbl_kind), dimension(nx_block,ny_block), intent(out) :: Tbot, fbot, rside
 
+#if defined(AusCOM)
+      call cice_gpu_check(cice_thermo_set_chio(cice_gpu_ctx, chio), 'cice_thermo_set_chio')
+#endif
       call cice_gpu_check(cice_frzmlt_bottom_lateral(cice_gpu_ctx, nx_block, ny_block, ilo, ihi, &
          jlo, jhi, dt, aice, frzmlt, eicen, esnon, sst, Tf, strocnxT, strocnyT, Tbot, fbot, rside), &
          'frzmlt_bottom_lateral')

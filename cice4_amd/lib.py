@@ -95,20 +95,27 @@ class ThermoFields(C.Structure):
                 + THERMO_OUT + THERMO_ONSET]
 
 
-_lib = None
+_libs = {}
 
 
-def load():
+def load(flavour="standalone"):
     """Load the HIP library; raises if it has not been built (python -c 'import
-    __graft_entry__ as g; g.build()' or make -C cice4_amd/csrc)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIBPATH):
-            raise CiceError(f"{LIBPATH} not found: build the HIP extension first (make -C cice4_amd/csrc)")
-        _lib = C.CDLL(LIBPATH)
-        _lib.cice_last_error.restype = C.c_char_p
-        _lib.cice_last_error.argtypes = [C.c_void_p]
-    return _lib
+    __graft_entry__ as g; g.build()' or make -C cice4_amd/csrc).  flavour "auscom": libcice4_amd_auscom.so, the
+    build that replaces a reference compiled -DAusCOM -Dcoupled (include/cice4_amd.h: cice_build_flavour)."""
+    if flavour not in _libs:
+        if flavour not in ("standalone", "auscom"):
+            raise CiceError(f"unknown flavour {flavour!r}")
+        path = LIBPATH if flavour == "standalone" else LIBPATH.replace(".so", "_auscom.so")
+        if not os.path.exists(path):
+            raise CiceError(f"{path} not found: build the HIP extension first (make -C cice4_amd/csrc)")
+        lib = C.CDLL(path)
+        lib.cice_last_error.restype = C.c_char_p
+        lib.cice_last_error.argtypes = [C.c_void_p]
+        lib.cice_build_flavour.restype = C.c_char_p
+        if lib.cice_build_flavour().decode() != flavour:
+            raise CiceError(f"{path} reports flavour {lib.cice_build_flavour().decode()!r}")
+        _libs[flavour] = lib
+    return _libs[flavour]
 
 
 def _p(a, dtype=None):
@@ -132,8 +139,9 @@ def _i4(a):
 class Context:
     """One rank = one GPU (cice_ctx)."""
 
-    def __init__(self, device=-1):
-        self.lib = load()
+    def __init__(self, device=-1, flavour="standalone"):
+        self.lib = load(flavour)
+        self.flavour = flavour
         self.h = C.c_void_p()
         rc = self.lib.cice_create(C.byref(self.h), C.c_int(device))
         if rc:
@@ -159,6 +167,15 @@ class Context:
 
     def sync(self):
         self._ck(self.lib.cice_device_sync(self.h))
+
+    def set_auscom(self, cosw=1.0, sinw=0.0, dragio=0.00536, use_ocnslope=False):
+        """flavour "auscom" only: the namelist variables of the coupled build's dynamics (cice_set_auscom)"""
+        self._ck(self.lib.cice_set_auscom(self.h, C.c_double(cosw), C.c_double(sinw), C.c_double(dragio),
+                                          C.c_int(int(use_ocnslope))))
+
+    def set_chio(self, chio=0.006):
+        """flavour "auscom" only: basal heat-transfer coefficient of frzmlt_bottom_lateral (cice_thermo_set_chio)"""
+        self._ck(self.lib.cice_thermo_set_chio(self.h, C.c_double(chio)))
 
     def diag_stream_copy(self, n_doubles):
         ms = C.c_float(0.0)

@@ -133,7 +133,9 @@ if [ "$AUS" = "1" ]; then EXTRA="$EXTRA -DREF_AUSCOM"; fi
 $FC $FFLAGS $EXTRA -c "$HERE/ref_capi.F90" -o "$OBJ/ref_capi.o"
 LINK=""
 if [ "$DROPIN" = "1" ]; then
-  LINK="-L$HERE/../cice4_amd -lcice4_amd -Wl,-rpath,\$ORIGIN/../../cice4_amd"
+  LIBNAME=cice4_amd
+  if [ "$AUS" = "1" ]; then LIBNAME=cice4_amd_auscom; fi
+  LINK="-L$HERE/../cice4_amd -l$LIBNAME -Wl,-rpath,\$ORIGIN/../../cice4_amd"
 fi
 if [ "$MPI" = "1" ]; then
   LINK="$LINK -L$MPIROOT/lib -lmpifort -lmpi -Wl,-rpath,$MPIROOT/lib"

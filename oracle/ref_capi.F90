@@ -545,6 +545,9 @@ contains
       use ice_flux
       use ice_grid
       use ice_dyn_evp, only: fcor_blk
+#ifdef REF_AUSCOM
+      use cpl_arrays_setup, only: sicemass
+#endif
       character(kind=c_char), intent(in) :: cname(*)
       integer(c_int), value :: dir
       real(c_double), intent(inout) :: buf(nx_block,ny_block,*)
@@ -583,6 +586,9 @@ contains
       case ('strintx'); F2(strintx)
       case ('strinty'); F2(strinty)
       case ('fm'); F2(fm)
+#ifdef REF_AUSCOM
+      case ('sicemass'); F2(sicemass)
+#endif
       case ('stressp_1'); F2(stressp_1)
       case ('stressp_2'); F2(stressp_2)
       case ('stressp_3'); F2(stressp_3)

@@ -19,12 +19,25 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(cice_[a-z0-9_]+)\s*\(", src)))
 
 
-def test_header_symbols_exported():
-    l = lib.load()
+@pytest.mark.parametrize("flavour", ["standalone", "auscom"])
+def test_header_symbols_exported(flavour):
+    """both builds of the library: libcice4_amd.so and libcice4_amd_auscom.so (the one for a -DAusCOM -Dcoupled
+    reference) export the whole header and say which one they are"""
+    l = lib.load(flavour)
     names = declared_symbols()
     assert len(names) >= 30
     for n in names:
         assert hasattr(l, n), f"{n} declared in include/cice4_amd.h but not exported"
+    assert l.cice_build_flavour().decode() == flavour
+
+
+def test_namelist_setters_belong_to_the_coupled_build():
+    """no device needed to be told so: the stand-alone build has the turning angle, drag and chio compiled in"""
+    c = lib.Context()
+    with pytest.raises(lib.CiceError, match="libcice4_amd_auscom.so"):
+        c.set_auscom(sinw=0.2)
+    with pytest.raises(lib.CiceError, match="libcice4_amd_auscom.so"):
+        c.set_chio(0.004)
 
 
 def test_product_never_imports_the_oracle():

@@ -116,6 +116,8 @@ def test_whole_evp(refaus_gx3b4, orc_aus, nml):
         for k in EVP_OUT:
             assert np.array_equal(ref.get(k), so[k]), (cover, damping, k)
         assert (so["fm"] < 0).any() and (so["fm"] > 0).any() and np.abs(so["uvel"]).max() > 0.01
+        # the coupler's ice + snow mass, written by the reference's evp (ice_dyn_evp.F90:246-248)
+        assert np.array_equal(ref.get("sicemass"), np.where(grid["tmask"] != 0, 917.0 * s["vice"] + 330.0 * s["vsno"], 0.0))
 
 
 def test_the_stand_alone_namelist_on_the_auscom_build_is_not_the_stand_alone_build(refaus_gx3b4, ref_gx3b4):
