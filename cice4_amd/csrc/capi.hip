@@ -34,6 +34,8 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
+  CopyFan fan;                 // side streams for entries that move many separate host arrays (cice_step_therm1)
+  hipStream_t cs() { return fan.forked ? fan.next() : stream; }   // the stream for the next host <-> device copy
   double chio = 0.006;         // coupled flavour: the namelist's chio (cice_thermo_set_chio)
   double nml[4] = {1.0, 0.0, 0.00536, 0.0};   // coupled flavour: cosw, sinw, dragio, use_ocnslope last sent to the device
   bool nml_set = false;
@@ -55,16 +57,15 @@ struct cice_ctx {
       if (lo >= r.first && hi <= r.second) return;            // already inside a registered range
     for (const auto& r : pin_refused)
       if (lo >= r.first && hi <= r.second) return;
-    bool drained = false;
+    const uintptr_t lo0 = lo, hi0 = hi;
+    std::vector<std::pair<uintptr_t, uintptr_t>> released;   // registered ranges the new one touches
     for (size_t k = 0; k < pin_ranges.size();) {
-      if (pin_ranges[k].first <= hi && lo <= pin_ranges[k].second) {
+      if (pin_ranges[k].first <= hi0 && lo0 <= pin_ranges[k].second) {
         lo = std::min(lo, pin_ranges[k].first);
         hi = std::max(hi, pin_ranges[k].second);
-        if (!drained) {                                       // no copy may be in flight on a range being released
-          (void)hipDeviceSynchronize();
-          drained = true;
-        }
+        if (released.empty()) (void)hipDeviceSynchronize();    // no copy may be in flight on a range being released
         if (hipHostUnregister((void*)pin_ranges[k].first) != hipSuccess) (void)hipGetLastError();
+        released.push_back(pin_ranges[k]);
         pin_ranges.erase(pin_ranges.begin() + k);
       } else {
         ++k;
@@ -72,10 +73,16 @@ struct cice_ctx {
     }
     if (hipHostRegister((void*)lo, hi - lo, hipHostRegisterDefault) == hipSuccess) {
       pin_ranges.push_back({lo, hi});
-    } else {   // registered by somebody else, or not registrable: stays pageable
-      (void)hipGetLastError();
-      pin_refused.push_back({lo, hi});
+      return;
     }
+    // registered by somebody else, or not registrable: what was page-locked before stays page-locked (the union is
+    // all or nothing for the runtime, not for us), only the request itself stays pageable and is not asked for again
+    (void)hipGetLastError();
+    for (const auto& r : released) {
+      if (hipHostRegister((void*)r.first, r.second - r.first, hipHostRegisterDefault) == hipSuccess) pin_ranges.push_back(r);
+      else (void)hipGetLastError();
+    }
+    pin_refused.push_back({lo0, hi0});
   }
   void unpin_all() {
     for (const auto& r : pin_ranges)
@@ -1287,7 +1294,7 @@ static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fb
     if (!with_fbot_tbot && (x.d == &t.fbot || x.d == &t.Tbot)) continue;   // produced on the device
     if (!with_coef && (x.d == &t.lhcoef || x.d == &t.shcoef)) continue;    // likewise (atmo_boundary_layer)
     CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
-    x.d->upload(x.h, c_->stream);
+    x.d->upload(x.h, c_->cs());
   }
   if (c_->have_thermo && !c_->tp.calc_Tsfc) {  // surface fluxes are inputs (ice_therm_vertical.F90:213-217)
     const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
@@ -1295,7 +1302,7 @@ static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fb
     const int plane[3] = {0, 1, 3};
     for (int k = 0; k < 3; ++k) {
       CICE_REQUIRE(in3[k] != nullptr, "cice_thermo_batch_upload: calc_Tsfc = F needs fsurfn, fcondtopn, flatn");
-      CICE_HIP(hipMemcpyAsync(t.out15.p + (size_t)plane[k] * nc, in3[k], nc * 8, hipMemcpyHostToDevice, c_->stream));
+      CICE_HIP(hipMemcpyAsync(t.out15.p + (size_t)plane[k] * nc, in3[k], nc * 8, hipMemcpyHostToDevice, c_->cs()));
     }
   }
 }
@@ -1435,7 +1442,6 @@ int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_u
 static void batch_download(cice_ctx* c_, cice_thermo_fields* h) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && h, "cice_thermo_batch_alloc has not been called");
-  hipStream_t s = c_->stream;
   const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
   struct D { const DevBuf<double>* d; double* h; };
   D ds[] = {{&t.aicen, h->aicen}, {&t.trcrn, h->trcrn}, {&t.vicen, h->vicen}, {&t.vsnon, h->vsnon},
@@ -1443,13 +1449,13 @@ static void batch_download(cice_ctx* c_, cice_thermo_fields* h) {
             {&t.Sswabs, h->Sswabs}, {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset},
             {&t.frz_onset, h->frz_onset}};
   for (D& x : ds)
-    if (x.h) x.d->download(x.h, s);
+    if (x.h) x.d->download(x.h, c_->cs());
   double* houts[15] = {h->fsurfn, h->fcondtopn, h->fsensn, h->flatn, h->fswabsn, h->flwoutn, h->evapn,
                        h->freshn, h->fsaltn, h->fhocnn, h->meltt, h->melts, h->meltb, h->congel,
                        h->snoice};
   for (int k = 0; k < 15; ++k)
     if (houts[k])
-      CICE_HIP(hipMemcpyAsync(houts[k], t.out15.p + (size_t)k * nc, nc * 8, hipMemcpyDeviceToHost, s));
+      CICE_HIP(hipMemcpyAsync(houts[k], t.out15.p + (size_t)k * nc, nc * 8, hipMemcpyDeviceToHost, c_->cs()));
 }
 
 int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
@@ -1461,23 +1467,26 @@ int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
 
 // aicen_init_dev: device copy of the initial concentrations (cice_step_therm1 keeps one); otherwise
 // f->aicen_init is uploaded
+// phases: the uploads, the kernel and the downloads can be asked for separately (cice_step_therm1 puts its copies on
+// side streams and the uploads in front of every kernel)
+enum { MRG_UP = 1, MRG_RUN = 2, MRG_DOWN = 4, MRG_ALL = 7 };
 static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* aicen_init_dev,
-                        bool atmo_on_device = false) {
+                        bool atmo_on_device = false, int phases = MRG_ALL) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0 && f, "cice_thermo_batch_alloc has not been called");
   hipStream_t s = c_->stream;
   const size_t n2 = (size_t)t.nx * t.ny * t.nb, nc = n2 * NCAT;
   DevBuf<double>&up = t.mrg_in, &acc = t.mrg_acc;
   const double* hin[5] = {f->aicen_init, f->strairxn, f->strairyn, f->Trefn, f->Qrefn};
-  for (int k = 0; k < 5; ++k) {
+  for (int k = 0; k < 5 && (phases & MRG_UP); ++k) {
     if (k == 0 && aicen_init_dev) continue;
     if (k > 0 && atmo_on_device) continue;    // strairxn, strairyn, Trefn, Qrefn were produced in place
     CICE_REQUIRE(hin[k] != nullptr, "cice_thermo_batch_merge: NULL input");
-    CICE_HIP(hipMemcpyAsync(up.p + (size_t)k * nc, hin[k], nc * 8, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(up.p + (size_t)k * nc, hin[k], nc * 8, hipMemcpyHostToDevice, c_->cs()));
   }
-  for (int k = 0; k < 20; ++k) {
+  for (int k = 0; k < 20 && (phases & MRG_UP); ++k) {
     CICE_REQUIRE(f->acc[k] != nullptr, "cice_thermo_batch_merge: NULL accumulator");
-    CICE_HIP(hipMemcpyAsync(acc.p + (size_t)k * n2, f->acc[k], n2 * 8, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(acc.p + (size_t)k * n2, f->acc[k], n2 * 8, hipMemcpyHostToDevice, c_->cs()));
   }
   MergeArgs a{};
   a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.blk = t.blk.p;
@@ -1492,9 +1501,9 @@ static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* 
     a.src[k] = src[k];
     a.acc[k] = acc.p + (size_t)k * n2;
   }
-  merge_launch(a, s);
-  for (int k = 0; k < 20; ++k)
-    CICE_HIP(hipMemcpyAsync(f->acc[k], acc.p + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToHost, s));
+  if (phases & MRG_RUN) merge_launch(a, s);
+  for (int k = 0; k < 20 && (phases & MRG_DOWN); ++k)
+    CICE_HIP(hipMemcpyAsync(f->acc[k], acc.p + (size_t)k * n2, n2 * 8, hipMemcpyDeviceToHost, c_->cs()));
 }
 
 int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
@@ -1518,14 +1527,25 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
   CICE_REQUIRE(fz->aice && fz->frzmlt && fz->sst && fz->Tf && fz->strocnxT && fz->strocnyT, "NULL frzmlt input");
   hipStream_t s = c_->stream;
   const size_t np = (size_t)t.nx * t.ny, n2 = np * t.nb, nc = n2 * NCAT;
+  // every upload first, spread over the side streams (about 150 separate host arrays), then the kernels
+  c_->fan.fork(s);
   batch_upload(c_, st, false, atm == nullptr);
-  if (atm) {   // atmo_boundary_layer for every category (CICE_RunMod.F90:402-425), on the state before the update
+  if (atm) {
     CICE_REQUIRE(atm->uatm && atm->vatm && atm->wind && atm->zlvl, "NULL atmosphere input");
     CICE_REQUIRE(atm->calc_strair || (atm->strax && atm->stray), "calc_strair = F needs strax, stray");
     if (t.atm_in.n < 6 * n2) t.atm_in.alloc(6 * n2);
     const double* ain[6] = {atm->uatm, atm->vatm, atm->wind, atm->zlvl, atm->strax, atm->stray};
     for (int k = 0; k < (atm->calc_strair ? 4 : 6); ++k)
-      CICE_HIP(hipMemcpyAsync(t.atm_in.p + (size_t)k * n2, ain[k], n2 * 8, hipMemcpyHostToDevice, s));
+      CICE_HIP(hipMemcpyAsync(t.atm_in.p + (size_t)k * n2, ain[k], n2 * 8, hipMemcpyHostToDevice, c_->cs()));
+  }
+  {
+    const double* fin[6] = {fz->aice, fz->frzmlt, fz->sst, fz->Tf, fz->strocnxT, fz->strocnyT};
+    for (int k = 0; k < 6; ++k)
+      CICE_HIP(hipMemcpyAsync(t.fz_in.p + (size_t)k * n2, fin[k], n2 * 8, hipMemcpyHostToDevice, c_->cs()));
+  }
+  batch_merge(c_, mg, t.mrg_in.p, atm != nullptr, MRG_UP);
+  c_->fan.join();
+  if (atm) {   // atmo_boundary_layer for every category (CICE_RunMod.F90:402-425), on the state before the update
     AtmoArgs a{};
     a.p.init();
     a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.ocn = 0; a.calc_strair = atm->calc_strair != 0;
@@ -1537,9 +1557,6 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
     a.lhcoef = t.lhcoef.p; a.shcoef = t.shcoef.p;
     atmo_launch_dense(a, s);
   }
-  const double* fin[6] = {fz->aice, fz->frzmlt, fz->sst, fz->Tf, fz->strocnxT, fz->strocnyT};
-  for (int k = 0; k < 6; ++k)
-    CICE_HIP(hipMemcpyAsync(t.fz_in.p + (size_t)k * n2, fin[k], n2 * 8, hipMemcpyHostToDevice, s));
   for (int b = 0; b < t.nb; ++b) {   // frzmlt_bottom_lateral per block, on the uploaded enthalpies
     FrzmltArgs a{};
     a.nx = t.nx; a.ny = t.ny; a.dt = dt; a.ustar_min = c_->tp.ustar_min; a.chio = c_->chio;
@@ -1555,18 +1572,21 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
   CICE_HIP(hipMemcpyAsync(t.mrg_in.p, t.aicen.p, nc * 8, hipMemcpyDeviceToDevice, s));
   unsigned long long h[2];
   batch_step(c_, dt, yday, h, nullptr, nullptr);
-  batch_merge(c_, mg, t.mrg_in.p, atm != nullptr);
+  batch_merge(c_, mg, t.mrg_in.p, atm != nullptr, MRG_RUN);
+  c_->fan.fork(s);   // ... and every download after the last kernel
+  batch_merge(c_, mg, t.mrg_in.p, atm != nullptr, MRG_DOWN);
   batch_download(c_, st);
   if (atm) {
     double* aout[6] = {atm->strairxn, atm->strairyn, atm->Trefn, atm->Qrefn, atm->lhcoef, atm->shcoef};
     const double* asrc[6] = {t.mrg_in.p + nc, t.mrg_in.p + 2 * nc, t.mrg_in.p + 3 * nc, t.mrg_in.p + 4 * nc,
                              t.lhcoef.p, t.shcoef.p};
     for (int k = 0; k < 6; ++k)
-      if (aout[k]) CICE_HIP(hipMemcpyAsync(aout[k], asrc[k], nc * 8, hipMemcpyDeviceToHost, s));
+      if (aout[k]) CICE_HIP(hipMemcpyAsync(aout[k], asrc[k], nc * 8, hipMemcpyDeviceToHost, c_->cs()));
   }
-  if (fz->Tbot) t.Tbot.download(fz->Tbot, s);
-  if (fz->fbot) t.fbot.download(fz->fbot, s);
-  if (fz->rside) CICE_HIP(hipMemcpyAsync(fz->rside, t.fz_in.p + 6 * n2, n2 * 8, hipMemcpyDeviceToHost, s));
+  if (fz->Tbot) t.Tbot.download(fz->Tbot, c_->cs());
+  if (fz->fbot) t.fbot.download(fz->fbot, c_->cs());
+  if (fz->rside) CICE_HIP(hipMemcpyAsync(fz->rside, t.fz_in.p + 6 * n2, n2 * 8, hipMemcpyDeviceToHost, c_->cs()));
+  c_->fan.join();
   CICE_HIP(hipStreamSynchronize(s));
   if (n_updates) *n_updates = (long long)h[1];
   decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/cice4_amd.h"
@@ -96,6 +97,62 @@ struct DevBuf {
   }
   void download(T* h, hipStream_t s) const {
     CICE_HIP(hipMemcpyAsync(h, p, n * sizeof(T), hipMemcpyDeviceToHost, s));
+  }
+};
+
+// Host <-> device copies of MANY separate arrays.  Consecutive copies on one stream leave about 10 us between them
+// (each waits for the completion signal of the one before): 1 MB planes move at 30 GB/s where the link does 55.
+// Copies on several streams overlap.  fork(main): the side streams wait for everything enqueued on `main` so far;
+// next(): the stream for the next copy, round robin; join(): `main` waits for every side stream.
+// CICE4_AMD_COPY_STREAMS in the environment sets their number (1: next() is `main` itself).  Measured at gx1 size
+// (scripts/gpu_r3_fan.sh): evp(dt) over PCIe 2.88 / 2.52 ms with 1 / 2, cice_step_therm1 7.21 / 6.57 ms; 3 and 4 are
+// no faster and, in a process that holds other streams (torch), many times slower once the runtime's hardware queues
+// are oversubscribed -- hence 2.
+struct CopyFan {
+  static constexpr int NMAX = 4;
+  hipStream_t side[NMAX] = {};
+  hipEvent_t ev[NMAX + 1] = {};
+  int n = 0, k = 0;
+  bool forked = false;
+  hipStream_t main = nullptr;
+  CopyFan() = default;
+  CopyFan(const CopyFan&) = delete;
+  CopyFan& operator=(const CopyFan&) = delete;
+  ~CopyFan() {
+    for (int i = 0; i < NMAX; ++i)
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+    for (int i = 0; i <= NMAX; ++i)
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+  }
+  static int wanted() {
+    static const int w = [] {
+      const char* e = std::getenv("CICE4_AMD_COPY_STREAMS");
+      const int v = e ? std::atoi(e) : 2;
+      return v < 1 ? 1 : (v > NMAX ? NMAX : v);
+    }();
+    return w;
+  }
+  void fork(hipStream_t m) {
+    main = m;
+    k = 0;
+    n = wanted();
+    forked = n > 1;
+    if (!forked) return;
+    for (int i = 0; i < n; ++i)
+      if (!side[i]) CICE_HIP(hipStreamCreateWithFlags(&side[i], hipStreamNonBlocking));
+    for (int i = 0; i <= n; ++i)
+      if (!ev[i]) CICE_HIP(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    CICE_HIP(hipEventRecord(ev[n], main));
+    for (int i = 0; i < n; ++i) CICE_HIP(hipStreamWaitEvent(side[i], ev[n], 0));
+  }
+  hipStream_t next() { return forked ? side[k++ % n] : main; }
+  void join() {
+    if (!forked) return;
+    for (int i = 0; i < n; ++i) {
+      CICE_HIP(hipEventRecord(ev[i], side[i]));
+      CICE_HIP(hipStreamWaitEvent(main, ev[i], 0));
+    }
+    forked = false;
   }
 };
 

@@ -91,11 +91,16 @@ class Evp {
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
   mutable int waves2_auto = 0;  // the automatic choice, once made
   // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
+  CopyFan fan;                   // side streams of upload / download (many separate host arrays)
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
   bool res_dense = true;         // allow three 4-wavefront workgroups per CU
   int res_spin_us = 200000;      // bound of every wait inside the resident kernel
   int res_level = 0;             // 0: dense allowed, 1: one workgroup per CU only (after a dense time-out)
+  int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
+  int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
+  int res_occ[5][2][2] = {};     // workgroups of k_evp_resident<W, DAMP, PEER> one CU holds, 0 = not asked yet
+  int resident_occupancy(int W, bool damp, bool peer);
   int res_w = 0, res_tiles = 0;  // what res_deps was built for
   unsigned res_epoch = 0;
   DevBuf<int32_t> res_deps;

@@ -1263,7 +1263,10 @@ __device__ __forceinline__ void st_sys(double* base, unsigned off, double v) {
 // its halo cells and writes the ghost cells owned by other ranks into the result itself (no halo update afterwards);
 // everything another rank writes or reads is a system-scope access.
 template <int W, bool DAMP, bool PEER>
-__global__ __launch_bounds__(64 * W, (64 * W + 255) / 256) void k_evp_resident(const ResArgs r) {
+// (second bound: wavefronts per SIMD.  W = 4 runs three workgroups per CU in the dense shape -- one rank only --, W = 11,
+// 12 put three wavefronts of one workgroup on a SIMD: both need the 168-register budget whatever the compiler would
+// like to use)
+__global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
   __shared__ double s_edge[W][4][TX];
@@ -1966,7 +1969,11 @@ void Evp::set_option(const char* key, int value) {
     if (value == 2) {                              // 2: also forget an earlier time-out
       resident_failed = false;
       res_level = 0;
+      res_retry_in = 0;
     }
+  } else if (!std::strcmp(key, "resident_retry_steps")) {   // evp(dt) calls until a time-out is forgiven, 0 = never
+    CICE_REQUIRE(value >= 0, "resident_retry_steps must be >= 0");
+    res_retry_steps = value;
   } else if (!std::strcmp(key, "resident_peer_share")) {   // contexts that share this device in the cross-rank loop (tests: 2)
     CICE_REQUIRE(value >= 1 && value <= 8, "resident_peer_share must be 1 .. 8");
     res_peer_share = value;
@@ -2141,38 +2148,41 @@ void Evp::upload(const cice_evp_fields& f) {
             {&vocn, f.vocn}, {&ss_tltx, f.ss_tltx}, {&ss_tlty, f.ss_tlty}, {&fm, f.fm},
             {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx}, {&strocny, f.strocny},
             {&strintx, f.strintx}, {&strinty, f.strinty}};
+  fan.fork(stream);
   for (U& x : us) {
     // after adopt_state the six state fields are on the device already: a NULL pointer keeps them
     const bool state6 = x.d == &aice || x.d == &vice || x.d == &vsno || x.d == &aice0 || x.d == &aicen || x.d == &vicen;
     if (adopted && state6 && x.h == nullptr) continue;
     CICE_REQUIRE(x.h != nullptr, "cice_evp_upload: NULL field");
-    x.d->upload(x.h, stream);
+    x.d->upload(x.h, fan.next());
   }
   adopted = false;
   CICE_REQUIRE(f.uvel && f.vvel && f.iceumask, "cice_evp_upload: NULL field");
-  CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, stream));
-  CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, stream));
+  CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, fan.next()));
+  CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, fan.next()));
   const double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
                           f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3,
                           f.stress12_4};
   for (int c = 0; c < 12; ++c) {
     CICE_REQUIRE(hs[c] != nullptr, "cice_evp_upload: NULL stress");
-    CICE_HIP(hipMemcpyAsync(sig[cur].p + (size_t)c * n, hs[c], n * 8, hipMemcpyHostToDevice, stream));
+    CICE_HIP(hipMemcpyAsync(sig[cur].p + (size_t)c * n, hs[c], n * 8, hipMemcpyHostToDevice, fan.next()));
   }
-  iceumask.upload(f.iceumask, stream);
+  iceumask.upload(f.iceumask, fan.next());
+  fan.join();
   CICE_HIP(hipStreamSynchronize(stream));
   prepared = false;
 }
 
 void Evp::download(cice_evp_fields& f) {
   CICE_REQUIRE(ready, "cice_evp_download before cice_evp_init");
-  CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, stream));
-  CICE_HIP(hipMemcpyAsync(f.vvel, uv[cur].p + n, n * 8, hipMemcpyDeviceToHost, stream));
+  fan.fork(stream);
+  CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, fan.next()));
+  CICE_HIP(hipMemcpyAsync(f.vvel, uv[cur].p + n, n * 8, hipMemcpyDeviceToHost, fan.next()));
   double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
                     f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3, f.stress12_4};
   for (int c = 0; c < 12; ++c)
-    CICE_HIP(hipMemcpyAsync(hs[c], sig[cur].p + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, stream));
-  iceumask.download(f.iceumask, stream);
+    CICE_HIP(hipMemcpyAsync(hs[c], sig[cur].p + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, fan.next()));
+  iceumask.download(f.iceumask, fan.next());
   struct D { const DevBuf<double>* d; double* h; };
   D ds[] = {{&fm, f.fm}, {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx},
             {&strocny, f.strocny}, {&strintx, f.strintx}, {&strinty, f.strinty}, {&strairx, f.strairx},
@@ -2180,12 +2190,17 @@ void Evp::download(cice_evp_fields& f) {
             {&rdg_conv, f.rdg_conv}, {&rdg_shear, f.rdg_shear}, {&prs_sig, f.prs_sig},
             {&strocnxT, f.strocnxT}, {&strocnyT, f.strocnyT}};
   for (D& x : ds)
-    if (x.h) x.d->download(x.h, stream);
+    if (x.h) x.d->download(x.h, fan.next());
+  fan.join();
   CICE_HIP(hipStreamSynchronize(stream));
 }
 
 void Evp::prepare(double dt) {
   CICE_REQUIRE(ready, "cice_evp_prepare before cice_evp_init");
+  if (res_retry_in > 0 && --res_retry_in == 0) {   // a time-out of the one-launch loop, res_retry_steps calls ago
+    resident_failed = false;
+    res_level = 0;
+  }
   EvpScalars nsc;
   nsc.set(dt, cfg.ndte, cfg.evp_damping);
   if (std::memcmp(&nsc, &sc, sizeof(sc)) != 0) drop_graph();  // scalars are baked into the graph
@@ -2890,6 +2905,48 @@ static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream
   }
 }
 
+template <int W>
+static int occ_res(bool damp, bool peer) {
+  int nb = 0;
+  hipError_t e;
+  if (peer) {
+    if constexpr (W <= 11) {
+      e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, true>, 64 * W, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, true>, 64 * W, 0);
+    } else {
+      return 0;
+    }
+  } else {
+    e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, false>, 64 * W, 0)
+             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false>, 64 * W, 0);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return nb;
+}
+
+// workgroups of this instantiation one CU holds, as the runtime computes it from the code object (registers, LDS): the
+// loop needs every tile resident at once, and a kernel that grew past its budget must not find that out by time-out
+int Evp::resident_occupancy(int W, bool damp, bool peer) {
+  const int wi = W == 4 ? 0 : W == 6 ? 1 : W == 8 ? 2 : W == 11 ? 3 : 4;
+  int& c = res_occ[wi][damp][peer];
+  if (c == 0) {
+    int nb = 0;
+    switch (W) {
+      case 4: nb = occ_res<4>(damp, peer); break;
+      case 6: nb = occ_res<6>(damp, peer); break;
+      case 8: nb = occ_res<8>(damp, peer); break;
+      case 11: nb = occ_res<11>(damp, peer); break;
+      case 12: nb = occ_res<12>(damp, peer); break;
+      default: break;
+    }
+    c = nb > 0 ? nb : -1;
+  }
+  return c > 0 ? c : 0;
+}
+
 // subcycles ksub0 .. ksub0+nsub-1 in one launch; false: not done (time-out), the state is as it was
 bool Evp::run_resident(int ksub0, int nsub) {
   const bool peer = halo.multi_rank();
@@ -2942,6 +2999,21 @@ bool Evp::run_resident(int ksub0, int nsub) {
   const dim3 g(8 * ((res_tiles + 7) / 8));
   const bool damp = sc.evp_damping != 0;
   const bool dense = !peer && resident_dense();
+  {   // every workgroup of the launch has to be resident at once
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    const int per_cu = resident_occupancy(W, damp, peer);
+    if ((long long)per_cu * ncu < (long long)g.x) {
+      std::fprintf(stderr, "cice4_amd: resident EVP loop not used: %u workgroups of %d wavefronts, the device holds %d x %d "
+                           "of this kernel\n", g.x, W, per_cu, ncu);
+      if (dense) res_level = 1;
+      else resident_failed = true;   // a property of the build and the device: not retried
+      return false;
+    }
+  }
   switch (W) {
     case 4: launch_res<4>(r, damp, peer, g, stream); break;
     case 6: launch_res<6>(r, damp, peer, g, stream); break;
@@ -2950,7 +3022,13 @@ bool Evp::run_resident(int ksub0, int nsub) {
     case 12: launch_res<12>(r, damp, peer, g, stream); break;
     default: throw Error{CICE_EINVAL, "resident_waves must be 4, 6, 8, 11 or 12"};
   }
-  CICE_HIP(hipGetLastError());
+  if (const hipError_t le = hipGetLastError(); le != hipSuccess) {   // nothing ran: the other loops take the range
+    std::fprintf(stderr, "cice4_amd: resident EVP loop could not be launched (%s); this range runs as one launch per pair "
+                         "of subcycles and so do later ones\n", hipGetErrorString(le));
+    CICE_REQUIRE(!peer, "resident EVP loop across ranks: launch failed on this rank");   // the others would wait for us
+    resident_failed = true;
+    return false;
+  }
   unsigned aborted = 0;
   if (peer && res_peer_agree) halo.all_max_u32(r.abort_flag);   // every rank falls back, or none does
   CICE_HIP(hipMemcpyAsync(&aborted, r.abort_flag, 4, hipMemcpyDeviceToHost, stream));
@@ -2962,6 +3040,9 @@ bool Evp::run_resident(int ksub0, int nsub) {
                  dense ? ", later ones with one workgroup per CU" : " and so do later ones");
     if (dense) res_level = 1;   // not every slot of the chip was free: one workgroup per CU from now on
     else resident_failed = true;
+    // whoever held the slots may be gone later: look again after res_retry_steps calls (across ranks only where the
+    // ranks agreed on the time-out, so that they also agree on the retry)
+    res_retry_in = (!peer || res_peer_agree) ? res_retry_steps : 0;
     res_prog.zero(stream);
     if (!peer) res_epoch = 0;   // (across ranks the neighbours hold words about us: the epoch only ever grows)
     return false;

@@ -530,7 +530,6 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
     // sources are physical cells, destinations ghost cells: the on-rank refresh below may run between
     // pack and unpack
     const int total_s = nsend_ ? send_off_.back() + send_cnt_.back() : 0;
-    const int total_r = nrecv_ ? recv_off_.back() + recv_cnt_.back() : 0;
     CICE_REQUIRE(comm_ != nullptr || link_ != nullptr, "halo: cice_comm_init has not been called on a multi-rank domain");
     T* sb = reinterpret_cast<T*>(sendbuf_.p);
     T* rb = reinterpret_cast<T*>(recvbuf_.p);

@@ -44,6 +44,7 @@ class Transport {
   const Domain& dom;
   Halo& halo;
   hipStream_t stream;
+  CopyFan fan;   // side streams of the state upload / download
   size_t n = 0;  // nblocks * nx_block * ny_block
   int ntrace = 0, ntrcr = 0;
   TransportKernelArgs a{};

@@ -28,7 +28,6 @@ constexpr double p5625m = -9.0 / 16.0, p52083 = 25.0 / 48.0;
 // init_remap :266-319: geometric means of a unit square cell
 constexpr double xav = c0, yav = c0, xxav = c1 / c12, yyav = c1 / c12, xyav = c0, xxxav = c0, xxyav = c0, xyyav = c0,
                  yyyav = c0;
-constexpr int NG = 6;  // ngroups
 
 struct Cell {
   int b, i, j;  // block, 1-based i, j
@@ -641,25 +640,27 @@ void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop
   // host arrays are (nx,ny,levels,nblocks); the device keeps (nx,ny,nblocks) per level
   auto up = [&](double* d, const double* h, int levels) {
     if (levels == 1 || nb == 1) {
-      CICE_HIP(hipMemcpyAsync(d, h, (size_t)levels * n * 8, hipMemcpyHostToDevice, stream));
+      CICE_HIP(hipMemcpyAsync(d, h, (size_t)levels * n * 8, hipMemcpyHostToDevice, fan.next()));
       return;
     }
     for (int b = 0; b < nb; ++b)
       CICE_HIP(hipMemcpy2DAsync(d + (size_t)b * np, n * 8, h + (size_t)b * levels * np, np * 8, np * 8, levels,
-                                hipMemcpyHostToDevice, stream));
+                                hipMemcpyHostToDevice, fan.next()));
   };
   auto down = [&](double* h, const double* d, int levels) {
     if (levels == 1 || nb == 1) {
-      CICE_HIP(hipMemcpyAsync(h, d, (size_t)levels * n * 8, hipMemcpyDeviceToHost, stream));
+      CICE_HIP(hipMemcpyAsync(h, d, (size_t)levels * n * 8, hipMemcpyDeviceToHost, fan.next()));
       return;
     }
     for (int b = 0; b < nb; ++b)
       CICE_HIP(hipMemcpy2DAsync(h + (size_t)b * levels * np, np * 8, d + (size_t)b * np, n * 8, np * 8, levels,
-                                hipMemcpyDeviceToHost, stream));
+                                hipMemcpyDeviceToHost, fan.next()));
   };
+  fan.fork(stream);
   up(aice0.p, f.aice0, 1); up(aicen.p, f.aicen, NCAT); up(trcrn.p, f.trcrn, NCAT * NTRCR); up(vicen.p, f.vicen, NCAT);
   up(vsnon.p, f.vsnon, NCAT); up(eicen.p, f.eicen, NCAT * NILYR); up(esnon.p, f.esnon, NCAT * NSLYR);
   up(uv.p, f.uvel, 1); up(uv.p + n, f.vvel, 1);
+  fan.join();
   CICE_HIP(hipMemsetAsync(key.p, 0xff, 8, stream));
   a.dt = dt;
   const unsigned gx = (unsigned)((np + 255) / 256);
@@ -694,9 +695,11 @@ void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop
   halo.update_r8(eicen.p, NCAT * NILYR, n, true, LOC_CENTER, KIND_SCALAR);
   halo.update_r8(esnon.p, NCAT * NSLYR, n, true, LOC_CENTER, KIND_SCALAR);
   CICE_HIP(hipGetLastError());
+  fan.fork(stream);
   down(f.aice0, aice0.p, 1); down(f.aicen, aicen.p, NCAT); down(f.trcrn, trcrn.p, NCAT * NTRCR);
   down(f.vicen, vicen.p, NCAT); down(f.vsnon, vsnon.p, NCAT); down(f.eicen, eicen.p, NCAT * NILYR);
   down(f.esnon, esnon.p, NCAT * NSLYR);
+  fan.join();
   unsigned long long hk = 0;
   CICE_HIP(hipMemcpyAsync(&hk, key.p, 8, hipMemcpyDeviceToHost, stream));
   CICE_HIP(hipStreamSynchronize(stream));

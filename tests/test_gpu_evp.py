@@ -815,6 +815,29 @@ def test_resident_loop_gives_up_cleanly(ctx, orc):
         assert np.array_equal(sg[k], ref[k]), ("after", k)
 
 
+def test_resident_loop_is_tried_again_later(ctx):
+    """a time-out may be somebody else's doing (a co-tenant holding CUs): after resident_retry_steps calls of evp(dt) the
+    shape that timed out is tried again"""
+    nxg, nyg = 320, 384
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=5), dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=3, cover="patchy")
+    ref, _ = _evp_with(ctx, grid, s, 12, False, fuse=1, resident=0)
+    ctx.evp_init(grid, ndte=12, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_retry_steps", 2); ctx.evp_set_option("resident_spin_us", 0)
+    seen = []
+    for call in range(4):
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp(DT, sg)              # call 0: the dense shape times out
+        ctx.evp_set_option("resident_spin_us", 200000)
+        seen.append((ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")))
+        for k in EVP_OUT_FIELDS + ("iceumask",):
+            assert np.array_equal(sg[k], ref[k]), (call, k)
+    # after call 0 and 1: one workgroup per CU; call 2 is the second call after the time-out: dense again, and it stays
+    assert seen == [(1, 0), (1, 0), (1, 1), (1, 1)], seen
+    ctx.evp_set_option("resident_retry_steps", 64)
+
+
 def test_fused_pairs_not_used_where_ghost_rows_change(ctx):
     """Several blocks per rank without overlap rows, or a cyclic N-S edge: ghost rows are refreshed
     after every subcycle, so the one-subcycle kernel must run."""
