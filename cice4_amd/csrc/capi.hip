@@ -34,7 +34,8 @@ struct cice_ctx {
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
   int comm_rank = -1, comm_nranks = 0;
-  CopyFan fan;                 // side streams for entries that move many separate host arrays (cice_step_therm1)
+  CopyFan fan;                 // side streams for the entries that move many separate host arrays: ONE set per context,
+                               // shared by the dynamics, the thermodynamic half-step and the transport
   hipStream_t cs() { return fan.forked ? fan.next() : stream; }   // the stream for the next host <-> device copy
   double chio = 0.006;         // coupled flavour: the namelist's chio (cice_thermo_set_chio)
   double nml[4] = {1.0, 0.0, 0.00536, 0.0};   // coupled flavour: cosw, sinw, dragio, use_ocnslope last sent to the device
@@ -766,7 +767,7 @@ int cice_evp_init(cice_ctx* ctx, const cice_evp_config* cfg, const cice_evp_grid
   CICE_TRY(ctx)
   CICE_REQUIRE(cfg && grid, "NULL argument");
   c_->need_halo();
-  c_->evp.reset(new Evp(c_->dom, *c_->halo, c_->stream));
+  c_->evp.reset(new Evp(c_->dom, *c_->halo, c_->stream, c_->fan));
   c_->evp->init(*cfg, *grid);
   CICE_CATCH
 }
@@ -785,8 +786,11 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
   c_->evp->upload(*f);
-  c_->evp->step(dt);
-  c_->evp->download(*f);
+  c_->evp->prepare(dt);
+  c_->evp->download_early(*f);
+  c_->evp->subcycles(1, c_->evp->ndte(), nullptr);
+  c_->evp->finish();
+  c_->evp->download(*f, true);
   CICE_CATCH
 }
 // f1 hand-off: the state the batched thermodynamic step left on the device becomes the dynamics' input without crossing
@@ -1698,7 +1702,7 @@ int cice_transport_init(cice_ctx* ctx, const cice_transport_config* cfg, const c
   CICE_TRY(ctx)
   CICE_REQUIRE(cfg && grid, "NULL argument");
   c_->need_halo();
-  c_->transport.reset(new Transport(c_->dom, *c_->halo, c_->stream));
+  c_->transport.reset(new Transport(c_->dom, *c_->halo, c_->stream, c_->fan));
   c_->transport->init(*cfg, *grid);
   CICE_CATCH
 }

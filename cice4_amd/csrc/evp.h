@@ -19,15 +19,17 @@ struct EvpScalars {  // set_evp_parameters, ice_dyn_evp.F90:535-577
 
 class Evp {
  public:
-  Evp(const Domain& d, Halo& h, hipStream_t s) : dom(d), halo(h), stream(s) {}
+  Evp(const Domain& d, Halo& h, hipStream_t s, CopyFan& f) : dom(d), halo(h), stream(s), fan(f) {}
   ~Evp();
   void init(const cice_evp_config& cfg, const cice_evp_grid& g);
   void upload(const cice_evp_fields& f);
   void adopt_state(const double* d_aicen, const double* d_vicen, const double* d_vsnon);
-  void download(cice_evp_fields& f);
+  void download(cice_evp_fields& f, bool early_done = false);
+  void download_early(cice_evp_fields& f);   // after prepare(): what the preparation left final, while the loop runs
   void prepare(double dt);
   void subcycles(int ksub0, int nsub, float* elapsed_ms);
   void finish();
+  int ndte() const { return cfg.ndte; }
   void step(double dt) {
     prepare(dt);
     subcycles(1, sc.ndte, nullptr);
@@ -91,7 +93,7 @@ class Evp {
   int waves2 = 0;            // fused kernel: wavefronts per workgroup, 0 = auto
   mutable int waves2_auto = 0;  // the automatic choice, once made
   // resident loop (k_evp_resident): one tile per CU for the whole range of subcycles
-  CopyFan fan;                   // side streams of upload / download (many separate host arrays)
+  CopyFan& fan;                  // the context's side streams for upload / download (many separate host arrays)
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
   bool res_dense = true;         // allow three 4-wavefront workgroups per CU

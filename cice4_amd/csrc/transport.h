@@ -29,7 +29,7 @@ struct TransportKernelArgs {
 
 class Transport {
  public:
-  Transport(const Domain& d, Halo& h, hipStream_t s) : dom(d), halo(h), stream(s) {}
+  Transport(const Domain& d, Halo& h, hipStream_t s, CopyFan& f) : dom(d), halo(h), stream(s), fan(f) {}
   void init(const cice_transport_config& c, const cice_transport_grid& g);
   // one transport_remap(dt) on host arrays (upload, remap, bound_state on the device, download)
   void remap(double dt, const cice_transport_fields& f, int32_t* l_stop, int32_t* istop, int32_t* jstop);
@@ -44,7 +44,7 @@ class Transport {
   const Domain& dom;
   Halo& halo;
   hipStream_t stream;
-  CopyFan fan;   // side streams of the state upload / download
+  CopyFan& fan;  // the context's side streams for the state upload / download
   size_t n = 0;  // nblocks * nx_block * ny_block
   int ntrace = 0, ntrcr = 0;
   TransportKernelArgs a{};
