@@ -161,7 +161,8 @@ static std::string g_create_err;
   cice_ctx* c_ = (ctx_); \
   if (!c_) return CICE_EINVAL; \
   try {                        \
-    c_->bind_device();
+    c_->bind_device();         \
+    c_->fan.forked = false;   /* an entry that failed between fork and join leaves nothing behind for the next */
 #define CICE_CATCH                                            \
   }                                                           \
   catch (const Error& e) {                                    \
@@ -787,10 +788,11 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   CICE_REQUIRE(f, "NULL argument");
   c_->evp->upload(*f);
   c_->evp->prepare(dt);
-  c_->evp->download_early(*f);
+  static const bool early = [] { const char* e = std::getenv("CICE4_AMD_EARLY_DOWNLOAD"); return !(e && e[0] == '0'); }();
+  if (early) c_->evp->download_early(*f);
   c_->evp->subcycles(1, c_->evp->ndte(), nullptr);
   c_->evp->finish();
-  c_->evp->download(*f, true);
+  c_->evp->download(*f, early);
   CICE_CATCH
 }
 // f1 hand-off: the state the batched thermodynamic step left on the device becomes the dynamics' input without crossing
@@ -1195,10 +1197,11 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
   if (li.n < 2 * np) li.alloc(2 * np);
   auto up = [&](int plane, const double* h, int planes = 1) {
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
-    CICE_HIP(hipMemcpyAsync(d.p + (size_t)plane * np, h, (size_t)planes * np * 8, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(d.p + (size_t)plane * np, h, (size_t)planes * np * 8, hipMemcpyHostToDevice, c_->cs()));
   };
   // of the tracers only Tsfc is read and written by the column physics (:137-142, :508-513)
   const int it_T = c_->tp.nt_Tsfc - 1;
+  c_->fan.fork(s);   // 22 separate host arrays in, 27 out: spread over the side streams
   up(A_AICEN, aicen); up(A_TRCRN + it_T, trcrn + (size_t)it_T * np); up(A_VICEN, vicen); up(A_VSNON, vsnon);
   up(A_EICEN, eicen, NILYR); up(A_ESNON, esnon, NSLYR);
   up(A_FLW, flw); up(A_POTT, potT); up(A_QA, Qa); up(A_RHOA, rhoa); up(A_FSNOW, fsnow);
@@ -1210,9 +1213,10 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
     up(A_OUT + 0, fsurfn); up(A_OUT + 1, fcondtopn); up(A_OUT + 3, flatn);
   }
   if (icells) {
-    CICE_HIP(hipMemcpyAsync(li.p, indxi, (size_t)icells * 4, hipMemcpyHostToDevice, s));
-    CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, s));
+    CICE_HIP(hipMemcpyAsync(li.p, indxi, (size_t)icells * 4, hipMemcpyHostToDevice, c_->cs()));
+    CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, c_->cs()));
   }
+  c_->fan.join();
   c_->tkey.alloc(2);
   CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
   CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
@@ -1232,9 +1236,10 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
   a.mlt_onset = P(A_MLT); a.frz_onset = P(A_FRZ);
   a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
   thermo_launch_list(a, s);
+  c_->fan.fork(s);
   auto down = [&](int plane, double* h, int planes = 1) {
     CICE_REQUIRE(h != nullptr, "thermo_vertical: NULL array");
-    CICE_HIP(hipMemcpyAsync(h, d.p + (size_t)plane * np, (size_t)planes * np * 8, hipMemcpyDeviceToHost, s));
+    CICE_HIP(hipMemcpyAsync(h, d.p + (size_t)plane * np, (size_t)planes * np * 8, hipMemcpyDeviceToHost, c_->cs()));
   };
   down(A_AICEN, aicen); down(A_TRCRN + it_T, trcrn + (size_t)it_T * np); down(A_VICEN, vicen); down(A_VSNON, vsnon);
   down(A_EICEN, eicen, NILYR); down(A_ESNON, esnon, NSLYR);
@@ -1243,6 +1248,7 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
                        fhocnn, meltt, melts, meltb, congel, snoice};
   for (int k = 0; k < 15; ++k) down(A_OUT + k, houts[k]);
   down(A_MLT, mlt_onset); down(A_FRZ, frz_onset);
+  c_->fan.join();
   unsigned long long key = 0;
   CICE_HIP(hipMemcpyAsync(&key, c_->tkey.p, 8, hipMemcpyDeviceToHost, s));
   CICE_HIP(hipStreamSynchronize(s));
@@ -1298,6 +1304,14 @@ static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fb
     if (!with_fbot_tbot && (x.d == &t.fbot || x.d == &t.Tbot)) continue;   // produced on the device
     if (!with_coef && (x.d == &t.lhcoef || x.d == &t.shcoef)) continue;    // likewise (atmo_boundary_layer)
     CICE_REQUIRE(x.h != nullptr, "cice_thermo_batch_upload: NULL field");
+    if (x.d == &t.trcrn && c_->have_thermo) {
+      // of trcrn(nx, ny, max_ntrcr, ncat, nblocks) the column physics reads and writes the surface temperature only:
+      // that plane of every (category, block), one strided copy (5 planes at ncat = 5 instead of 25)
+      const size_t np = (size_t)t.nx * t.ny, o = (size_t)(c_->tp.nt_Tsfc - 1) * np;
+      CICE_HIP(hipMemcpy2DAsync(t.trcrn.p + o, (size_t)NTRCR * np * 8, x.h + o, (size_t)NTRCR * np * 8, np * 8,
+                                (size_t)NCAT * t.nb, hipMemcpyHostToDevice, c_->cs()));
+      continue;
+    }
     x.d->upload(x.h, c_->cs());
   }
   if (c_->have_thermo && !c_->tp.calc_Tsfc) {  // surface fluxes are inputs (ice_therm_vertical.F90:213-217)
@@ -1452,8 +1466,16 @@ static void batch_download(cice_ctx* c_, cice_thermo_fields* h) {
             {&t.eicen, h->eicen}, {&t.esnon, h->esnon}, {&t.fswsfc, h->fswsfc}, {&t.fswint, h->fswint},
             {&t.Sswabs, h->Sswabs}, {&t.Iswabs, h->Iswabs}, {&t.mlt_onset, h->mlt_onset},
             {&t.frz_onset, h->frz_onset}};
-  for (D& x : ds)
-    if (x.h) x.d->download(x.h, c_->cs());
+  for (D& x : ds) {
+    if (!x.h) continue;
+    if (x.d == &t.trcrn && c_->have_thermo) {   // the surface-temperature plane, as it was uploaded
+      const size_t np = (size_t)t.nx * t.ny, o = (size_t)(c_->tp.nt_Tsfc - 1) * np;
+      CICE_HIP(hipMemcpy2DAsync(x.h + o, (size_t)NTRCR * np * 8, t.trcrn.p + o, (size_t)NTRCR * np * 8, np * 8,
+                                (size_t)NCAT * t.nb, hipMemcpyDeviceToHost, c_->cs()));
+      continue;
+    }
+    x.d->download(x.h, c_->cs());
+  }
   double* houts[15] = {h->fsurfn, h->fcondtopn, h->fsensn, h->flatn, h->fswabsn, h->flwoutn, h->evapn,
                        h->freshn, h->fsaltn, h->fhocnn, h->meltt, h->melts, h->meltb, h->congel,
                        h->snoice};

@@ -2153,6 +2153,9 @@ void Evp::upload(const cice_evp_fields& f) {
     // after adopt_state the six state fields are on the device already: a NULL pointer keeps them
     const bool state6 = x.d == &aice || x.d == &vice || x.d == &vsno || x.d == &aice0 || x.d == &aicen || x.d == &vicen;
     if (adopted && state6 && x.h == nullptr) continue;
+#ifndef CICE4_AMD_AUSCOM   // the stand-alone build forms the tilt from the currents (:919-922) and never reads the slope
+    if (x.d == &ss_tltx || x.d == &ss_tlty) continue;
+#endif
     CICE_REQUIRE(x.h != nullptr, "cice_evp_upload: NULL field");
     x.d->upload(x.h, fan.next());
   }

@@ -338,32 +338,18 @@ typedef struct {
 } cice_thermo_fields;
 
 int cice_thermo_batch_alloc(cice_ctx *ctx, int nx_block, int ny_block, int nblocks);
+/* Host -> device / device -> host of the batch.  Of trcrn(nx, ny, max_ntrcr, ncat, nblocks) only the surface-temperature
+ * plane (nt_Tsfc of cice_thermo_init) of every (category, block) travels: the column physics reads and writes no other
+ * tracer; the other planes of the host array are left as they are. */
 int cice_thermo_batch_upload(cice_ctx *ctx, const cice_thermo_fields *host);
-/* One pass over all (cell,category) columns.  n_updates: number of columns updated;
- * l_stop/istop/jstop/nstop/bstop: first failing column in (block, category, list) order. */
-/* Which reference build this library replaces: "standalone" (libcice4_amd.so: drivers/cice4/ice_constants.F90, the
- * compile-time cosw = 1, sinw = 0, dragio, chio of source/ice_dyn_evp.F90:76-88 and ice_therm_vertical.F90:680) or
- * "auscom" (libcice4_amd_auscom.so: the reference compiled -DAusCOM -Dcoupled, bld/Macros.nci:56-57, with
- * drivers/access-om/ice_constants.F90: MOM's cp_ocn and reference salinity; the ocean turning angle rotates with the
- * hemisphere in evp_prep2 / stepu / evp_finish, ice_dyn_evp.F90:910-913,1402-1408,1524-1536).  The two are separate
- * shared libraries, as the two are separate builds of the reference; a process may load both. */
-const char *cice_build_flavour(void);
-/* "auscom" flavour only (CICE_EINVAL in the stand-alone one): the namelist variables that build reads in
- * ice_init.F90:97,156,258-264 -- cosw, sinw (ocean turning angle), dragio (ice-ocean drag) of ice_dyn_evp.F90:91-97 --
- * and use_ocnslope (cpl_parameters: the tilt term from ss_tltx/ss_tlty instead of the geostrophic currents,
- * ice_dyn_evp.F90:919-933).  Defaults: 1, 0, 0.00536, 0.  Takes effect for every later call on this device (the
- * context's stream is drained first); a call that changes nothing returns at once, so the drop-in makes it before
- * every evp(dt). */
-int cice_set_auscom(cice_ctx *ctx, double cosw, double sinw, double dragio, int use_ocnslope);
-/* "auscom" flavour only: chio, the basal heat-transfer coefficient of frzmlt_bottom_lateral
- * (ice_therm_vertical.F90:57-60,692-694; namelist, default 0.006 = the stand-alone build's constant). */
-int cice_thermo_set_chio(cice_ctx *ctx, double chio);
 /* Tuning switches of the batched step; results never depend on them.  "sort_chunk" (0 = off, the default; 256 .. 2048):
  * the columns of every chunk of that many consecutive cells of a (category, block) plane are ordered by the work they
  * are expected to take (the solver iterations of the previous step, snow / no snow, cold / melting surface) before
  * wavefronts are formed, "sort_group" (1, 2, 4, 8, 16, 32) adjacent cells staying together (built,
  * bit-exact, measured slower than the unsorted kernel at every setting, hence off). */
 int cice_thermo_set_option(cice_ctx *ctx, const char *key, int value);
+/* One pass over all (cell,category) columns.  n_updates: number of columns updated;
+ * l_stop/istop/jstop/nstop/bstop: first failing column in (block, category, list) order. */
 int cice_thermo_batch_step(cice_ctx *ctx, double dt, double yday, long long *n_updates,
                            int32_t *l_stop, int32_t *istop, int32_t *jstop, int32_t *nstop,
                            int32_t *bstop, float *elapsed_ms);
@@ -465,6 +451,24 @@ int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *
 /* Test aid: make the next cice_transport_remap stop after kernel stage stop_stage (0: run through) and / or copy
  * work array `which` (-1: none) to `out`; *count = its length in doubles. */
 int cice_transport_debug(cice_ctx *ctx, int stop_stage, int which, double *out, long long *count);
+
+/* Which reference build this library replaces: "standalone" (libcice4_amd.so: drivers/cice4/ice_constants.F90, the
+ * compile-time cosw = 1, sinw = 0, dragio, chio of source/ice_dyn_evp.F90:76-88 and ice_therm_vertical.F90:680) or
+ * "auscom" (libcice4_amd_auscom.so: the reference compiled -DAusCOM -Dcoupled, bld/Macros.nci:56-57, with
+ * drivers/access-om/ice_constants.F90: MOM's cp_ocn and reference salinity; the ocean turning angle rotates with the
+ * hemisphere in evp_prep2 / stepu / evp_finish, ice_dyn_evp.F90:910-913,1402-1408,1524-1536).  The two are separate
+ * shared libraries, as the two are separate builds of the reference; a process may load both. */
+const char *cice_build_flavour(void);
+/* "auscom" flavour only (CICE_EINVAL in the stand-alone one): the namelist variables that build reads in
+ * ice_init.F90:97,156,258-264 -- cosw, sinw (ocean turning angle), dragio (ice-ocean drag) of ice_dyn_evp.F90:91-97 --
+ * and use_ocnslope (cpl_parameters: the tilt term from ss_tltx/ss_tlty instead of the geostrophic currents,
+ * ice_dyn_evp.F90:919-933).  Defaults: 1, 0, 0.00536, 0.  Takes effect for every later call on this device (the
+ * context's stream is drained first); a call that changes nothing returns at once, so the drop-in makes it before
+ * every evp(dt). */
+int cice_set_auscom(cice_ctx *ctx, double cosw, double sinw, double dragio, int use_ocnslope);
+/* "auscom" flavour only: chio, the basal heat-transfer coefficient of frzmlt_bottom_lateral
+ * (ice_therm_vertical.F90:57-60,692-694; namelist, default 0.006 = the stand-alone build's constant). */
+int cice_thermo_set_chio(cice_ctx *ctx, double chio);
 
 #ifdef __cplusplus
 }

@@ -238,7 +238,13 @@ def test_batched_step_equals_per_category_calls(ctx, orc):
     ctx.thermo_batch_upload(batch)
     st = ctx.thermo_batch_step(DT, yday=150.0, timed=True)
     assert st["l_stop"] == 0 and st["ms"] > 0
+    # of trcrn only the surface temperature travels (the column physics touches no other tracer): whatever the host
+    # holds in the other planes when the batch comes back stays there
+    orig = batch["trcrn"][:, :, 1:].copy()
+    batch["trcrn"][:, :, 1:] = 7.0
     ctx.thermo_batch_download(batch)
+    assert np.all(batch["trcrn"][:, :, 1:] == 7.0)
+    batch["trcrn"][:, :, 1:] = orig
     nupd = 0
     for b in range(nb):
         mlt = percat[(b, 0)][0]["mlt_onset"].copy(); frz = percat[(b, 0)][0]["frz_onset"].copy()
