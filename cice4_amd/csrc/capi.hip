@@ -787,12 +787,8 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
   c_->evp->upload(*f);
-  c_->evp->prepare(dt);
-  static const bool early = [] { const char* e = std::getenv("CICE4_AMD_EARLY_DOWNLOAD"); return !(e && e[0] == '0'); }();
-  if (early) c_->evp->download_early(*f);
-  c_->evp->subcycles(1, c_->evp->ndte(), nullptr);
-  c_->evp->finish();
-  c_->evp->download(*f, early);
+  c_->evp->step(dt);
+  c_->evp->download(*f);
   CICE_CATCH
 }
 // f1 hand-off: the state the batched thermodynamic step left on the device becomes the dynamics' input without crossing

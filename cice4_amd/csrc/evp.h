@@ -24,12 +24,10 @@ class Evp {
   void init(const cice_evp_config& cfg, const cice_evp_grid& g);
   void upload(const cice_evp_fields& f);
   void adopt_state(const double* d_aicen, const double* d_vicen, const double* d_vsnon);
-  void download(cice_evp_fields& f, bool early_done = false);
-  void download_early(cice_evp_fields& f);   // after prepare(): what the preparation left final, while the loop runs
+  void download(cice_evp_fields& f);
   void prepare(double dt);
   void subcycles(int ksub0, int nsub, float* elapsed_ms);
   void finish();
-  int ndte() const { return cfg.ndte; }
   void step(double dt) {
     prepare(dt);
     subcycles(1, sc.ndte, nullptr);

@@ -2176,21 +2176,7 @@ void Evp::upload(const cice_evp_fields& f) {
   prepared = false;
 }
 
-// What evp_prep1 / evp_prep2 / ice_strength leave final -- the wind stress on the U grid, the strength, fm, the tilt
-// terms, iceumask -- can travel while the subcycling runs: the link is idle in that direction then.  (The side streams
-// are not joined here; download(f, true) queues behind these copies on the same streams and joins.)
-void Evp::download_early(cice_evp_fields& f) {
-  CICE_REQUIRE(prepared, "cice_evp_download_early before cice_evp_prepare");
-  fan.fork(stream);
-  iceumask.download(f.iceumask, fan.next());
-  struct D { const DevBuf<double>* d; double* h; };
-  D ds[] = {{&fm, f.fm}, {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strairx, f.strairx}, {&strairy, f.strairy},
-            {&strength, f.strength}};
-  for (D& x : ds)
-    if (x.h) x.d->download(x.h, fan.next());
-}
-
-void Evp::download(cice_evp_fields& f, bool early_done) {
+void Evp::download(cice_evp_fields& f) {
   CICE_REQUIRE(ready, "cice_evp_download before cice_evp_init");
   fan.fork(stream);
   CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, fan.next()));
@@ -2199,18 +2185,15 @@ void Evp::download(cice_evp_fields& f, bool early_done) {
                     f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3, f.stress12_4};
   for (int c = 0; c < 12; ++c)
     CICE_HIP(hipMemcpyAsync(hs[c], sig[cur].p + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, fan.next()));
-  if (!early_done) iceumask.download(f.iceumask, fan.next());
+  iceumask.download(f.iceumask, fan.next());
   struct D { const DevBuf<double>* d; double* h; };
   D ds[] = {{&fm, f.fm}, {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx},
             {&strocny, f.strocny}, {&strintx, f.strintx}, {&strinty, f.strinty}, {&strairx, f.strairx},
             {&strairy, f.strairy}, {&strength, f.strength}, {&divu, f.divu}, {&shear, f.shear},
             {&rdg_conv, f.rdg_conv}, {&rdg_shear, f.rdg_shear}, {&prs_sig, f.prs_sig},
             {&strocnxT, f.strocnxT}, {&strocnyT, f.strocnyT}};
-  for (D& x : ds) {
-    const bool early = x.d == &fm || x.d == &strtltx || x.d == &strtlty || x.d == &strairx || x.d == &strairy ||
-                       x.d == &strength;
-    if (x.h && !(early && early_done)) x.d->download(x.h, fan.next());
-  }
+  for (D& x : ds)
+    if (x.h) x.d->download(x.h, fan.next());
   fan.join();
   CICE_HIP(hipStreamSynchronize(stream));
 }
