@@ -30,6 +30,7 @@ struct cice_ctx {
   std::unique_ptr<Halo> halo;
   std::unique_ptr<Evp> evp;
   std::unique_ptr<Transport> transport;
+  std::unique_ptr<Upwind> upwind;
   // RCCL communicator of this rank (cice_comm_init): created once, handed to every Halo built afterwards --
   // the block decomposition may change (cice_domain_create*), the set of ranks does not
   ncclComm_t comm = nullptr;
@@ -493,6 +494,7 @@ int cice_destroy(cice_ctx* ctx) {
   ctx->unpin_all();
   ctx->evp.reset();
   ctx->transport.reset();
+  ctx->upwind.reset();
   ctx->frame_halo.reset();
   ctx->halo.reset();
   if (ctx->comm) (void)ncclCommDestroy(ctx->comm);
@@ -566,6 +568,7 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
   CICE_CATCH
@@ -582,6 +585,7 @@ int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, in
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
   CICE_CATCH
@@ -618,6 +622,7 @@ int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
   CICE_CATCH
@@ -1731,6 +1736,24 @@ int cice_transport_remap(cice_ctx* ctx, double dt, const cice_transport_fields* 
   CICE_REQUIRE(c_->transport != nullptr, "cice_transport_init has not been called");
   CICE_REQUIRE(f, "NULL argument");
   c_->transport->remap(dt, *f, l_stop, istop, jstop);
+  CICE_CATCH
+}
+
+int cice_transport_upwind_init(cice_ctx* ctx, const cice_transport_config* cfg, int nt_Tsfc, const double* HTE,
+                               const double* HTN, const double* tarea) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(cfg, "NULL argument");
+  c_->need_halo();
+  c_->upwind.reset(new Upwind(c_->dom, *c_->halo, c_->stream, c_->fan));
+  c_->upwind->init(*cfg, nt_Tsfc, HTE, HTN, tarea);
+  CICE_CATCH
+}
+
+int cice_transport_upwind(cice_ctx* ctx, double dt, const cice_transport_fields* f) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(c_->upwind != nullptr, "cice_transport_upwind_init has not been called");
+  CICE_REQUIRE(f, "NULL argument");
+  c_->upwind->step(dt, *f);
   CICE_CATCH
 }
 

@@ -26,6 +26,7 @@ constexpr double pi = 3.14159265358979323846;
 constexpr double stefan_boltzmann = 567.0e-10, Tffresh = 273.15, Lsub = 2.835e6, Lvap = 2.501e6;
 constexpr double Lfresh = Lsub - Lvap;
 constexpr double kice = 2.03, ksno = 0.30;
+constexpr double Tocnfrz = -1.8;   // :72 (a namelist variable with this default in the coupled build)
 constexpr double qqqice = 11637800.0, TTTice = 5897.8;
 constexpr double puny = 1.0e-11;
 constexpr double c0 = 0.0, c1 = 1.0, c2 = 2.0, c4 = 4.0, p5 = 0.5, p25 = 0.25, p1 = 0.1,

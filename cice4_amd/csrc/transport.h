@@ -55,4 +55,35 @@ class Transport {
   DevBuf<unsigned long long> key;
 };
 
+// advection = 'upwind' (source/ice_transport_driver.F90:672-834 transport_upwind, :1570-1878 state_to_work,
+// work_to_state, upwind_field; compute_tracers source/ice_itd.F90:1482-1590): first-order donor-cell transport of
+// aice0, the state of every category (area, volumes, tracer x area / volume) and the layer enthalpies.
+struct UpwindArgs {
+  int nx, ny, nb, ntrcr, narr, nlev;   // narr = 1 + ncat*(3+ntrcr) work planes, nlev = narr + ncat*(nilyr+nslyr)
+  int dep[NTRCR], it_Tsfc;
+  double dt;
+  const int32_t* blk;
+  const double *HTE, *HTN, *tarea, *uvel, *vvel;
+  double *uee, *vnn;
+  double *aice0, *aicen, *trcrn, *vicen, *vsnon, *eicen, *esnon;
+  double *phi, *phi2;   // (nx,ny,nb) per level: the fields before / after upwind_field
+};
+
+class Upwind {
+ public:
+  Upwind(const Domain& d, Halo& h, hipStream_t s, CopyFan& f) : dom(d), halo(h), stream(s), fan(f) {}
+  void init(const cice_transport_config& c, int nt_Tsfc, const double* HTE, const double* HTN, const double* tarea);
+  void step(double dt, const cice_transport_fields& f);   // one transport_upwind(dt) on host arrays
+
+ private:
+  const Domain& dom;
+  Halo& halo;
+  hipStream_t stream;
+  CopyFan& fan;
+  size_t n = 0;
+  UpwindArgs a{};
+  DevBuf<int32_t> blk;
+  DevBuf<double> HTE, HTN, tarea, uv, edge, aice0, aicen, trcrn, vicen, vsnon, eicen, esnon, phi, phi2;
+};
+
 }  // namespace cice

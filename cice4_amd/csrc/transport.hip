@@ -725,4 +725,223 @@ size_t Transport::debug_fetch(int which, double* out) {
   return b.n;
 }
 
+// ====================================================================================================================
+// advection = 'upwind'
+// ====================================================================================================================
+namespace {
+
+struct UCell {
+  int b, i, j;
+  size_t q, c;
+};
+__device__ __forceinline__ bool ucell_of(const UpwindArgs& a, UCell& k) {
+  const size_t np = (size_t)a.nx * a.ny;
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= np) return false;
+  k.b = blockIdx.z;
+  k.q = q;
+  k.c = (size_t)k.b * np + q;
+  k.j = (int)(q / a.nx) + 1;
+  k.i = (int)(q - (size_t)(k.j - 1) * a.nx) + 1;
+  return true;
+}
+__device__ __forceinline__ bool uphysical(const UpwindArgs& a, const UCell& k) {
+  const int32_t* e = a.blk + 4 * k.b;
+  return k.i >= e[0] && k.i <= e[1] && k.j >= e[2] && k.j <= e[3];
+}
+__device__ __forceinline__ size_t ulvl(const UpwindArgs& a, int level) { return (size_t)level * a.nb * a.nx * a.ny; }
+
+// corner velocities averaged to the east / north edges (:718-731); elsewhere the halo update fills in
+__global__ __launch_bounds__(256) void k_up_edges(const UpwindArgs a) {
+  UCell k;
+  if (!ucell_of(a, k)) return;
+  double ue = c0, vn = c0;
+  if (uphysical(a, k)) {
+    ue = p5 * (a.uvel[k.c] + a.uvel[k.c - a.nx]);
+    vn = p5 * (a.vvel[k.c] + a.vvel[k.c - 1]);
+  }
+  a.uee[k.c] = ue;
+  a.vnn[k.c] = vn;
+}
+
+// state_to_work (:1570-1677) for level blockIdx.y < narr, the enthalpies as they are behind it
+__global__ __launch_bounds__(256) void k_up_pack(const UpwindArgs a) {
+  UCell k;
+  if (!ucell_of(a, k)) return;
+  const int L = blockIdx.y;
+  double v;
+  if (L == 0) {
+    v = a.aice0[k.c];
+  } else if (L < a.narr) {
+    const int per = 3 + a.ntrcr, n = (L - 1) / per, r = (L - 1) - n * per;
+    const size_t cn = ulvl(a, n) + k.c;
+    if (r == 0) v = a.aicen[cn];
+    else if (r == 1) v = a.vicen[cn];
+    else if (r == 2) v = a.vsnon[cn];
+    else {
+      const int it = r - 3;
+      const double t = a.trcrn[ulvl(a, n * NTRCR + it) + k.c];
+      const int d = a.dep[it];
+      v = (d == 0 ? a.aicen[cn] : d == 1 ? a.vicen[cn] : a.vsnon[cn]) * t;
+    }
+  } else if (L < a.narr + NCAT * NILYR) {
+    v = a.eicen[ulvl(a, L - a.narr) + k.c];
+  } else {
+    v = a.esnon[ulvl(a, L - a.narr - NCAT * NILYR) + k.c];
+  }
+  a.phi[ulvl(a, L) + k.c] = v;
+}
+
+// upwind_field (:1796-1878): the donor-cell fluxes through the four edges of a physical cell, evaluated from the
+// field before the update (the reference fills worka / workb for the whole block first)
+__device__ __forceinline__ double upw(double dt, double y1, double y2, double av, double h) {
+  return p5 * dt * h * ((av + fabs(av)) * y1 + (av - fabs(av)) * y2);   // :1850
+}
+__global__ __launch_bounds__(256) void k_up_advect(const UpwindArgs a) {
+  UCell k;
+  if (!ucell_of(a, k)) return;
+  const size_t o = ulvl(a, blockIdx.y) + k.c;
+  const double* f = a.phi + o;
+  double v = f[0];
+  if (uphysical(a, k)) {
+    const size_t c = k.c;
+    const int nx = a.nx;
+    const double wa = upw(a.dt, f[0], f[1], a.uee[c], a.HTE[c]);
+    const double waw = upw(a.dt, f[-1], f[0], a.uee[c - 1], a.HTE[c - 1]);
+    const double wb = upw(a.dt, f[0], f[nx], a.vnn[c], a.HTN[c]);
+    const double wbs = upw(a.dt, f[-nx], f[0], a.vnn[c - nx], a.HTN[c - nx]);
+    v = v - (wa - waw + wb - wbs) / a.tarea[c];   // :1866-1868
+  }
+  a.phi2[o] = v;
+}
+
+// work_to_state (:1686-1787) with compute_tracers (ice_itd.F90:1482-1590) on every cell of the block
+__global__ __launch_bounds__(256) void k_up_unpack(const UpwindArgs a) {
+  UCell k;
+  if (!ucell_of(a, k)) return;
+  const int n = blockIdx.y;   // 0: aice0, 1..ncat
+  if (n == 0) {
+    a.aice0[k.c] = a.phi2[k.c];
+    return;
+  }
+  const int per = 3 + a.ntrcr, L0 = 1 + (n - 1) * per;
+  const size_t cn = ulvl(a, n - 1) + k.c;
+  const double ai = a.phi2[ulvl(a, L0) + k.c], vi = a.phi2[ulvl(a, L0 + 1) + k.c], vs = a.phi2[ulvl(a, L0 + 2) + k.c];
+  a.aicen[cn] = ai;
+  a.vicen[cn] = vi;
+  a.vsnon[cn] = vs;
+  for (int it = 0; it < a.ntrcr; ++it) {
+    const double at = a.phi2[ulvl(a, L0 + 3 + it) + k.c];
+    double t;
+    if (it == a.it_Tsfc) t = ai > puny ? at / ai : Tocnfrz;
+    else if (a.dep[it] == 0) t = ai > puny ? at / ai : c0;
+    else if (a.dep[it] == 1) t = vi > c0 ? at / vi : c0;
+    else t = vs > c0 ? at / vs : c0;
+    a.trcrn[ulvl(a, (n - 1) * NTRCR + it) + k.c] = t;
+  }
+#pragma unroll
+  for (int l = 0; l < NILYR; ++l) {
+    const int e = (n - 1) * NILYR + l;
+    a.eicen[ulvl(a, e) + k.c] = a.phi2[ulvl(a, a.narr + e) + k.c];
+  }
+#pragma unroll
+  for (int l = 0; l < NSLYR; ++l) {
+    const int e = (n - 1) * NSLYR + l;
+    a.esnon[ulvl(a, e) + k.c] = a.phi2[ulvl(a, a.narr + NCAT * NILYR + e) + k.c];
+  }
+}
+
+}  // namespace
+
+void Upwind::init(const cice_transport_config& c, int nt_Tsfc, const double* hHTE, const double* hHTN, const double* htarea) {
+  CICE_REQUIRE(dom.nblocks() > 0, "cice_transport_upwind_init: no local blocks (call cice_domain_create first)");
+  CICE_REQUIRE(dom.overlap == 0, "cice_transport_upwind_init: wide-halo slab domains are for the EVP bench only");
+  CICE_REQUIRE(c.ntrcr >= 1 && c.ntrcr <= NTRCR, "cice_transport_upwind_init: ntrcr out of range");
+  CICE_REQUIRE(nt_Tsfc >= 1 && nt_Tsfc <= c.ntrcr, "cice_transport_upwind_init: nt_Tsfc out of range");
+  CICE_REQUIRE(hHTE && hHTN && htarea, "cice_transport_upwind_init: NULL grid array");
+  const size_t np = (size_t)dom.nx_block * dom.ny_block;
+  n = (size_t)dom.nblocks() * np;
+  std::vector<int32_t> hb;
+  for (int gid : dom.local) {
+    const Block& b = dom.all[gid];
+    hb.insert(hb.end(), {b.ilo, b.ihi, b.jlo, b.jhi});
+  }
+  blk.alloc(hb.size());
+  blk.upload(hb.data(), stream);
+  HTE.alloc(n); HTE.upload(hHTE, stream);
+  HTN.alloc(n); HTN.upload(hHTN, stream);
+  tarea.alloc(n); tarea.upload(htarea, stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+  a = UpwindArgs{};
+  a.nx = dom.nx_block; a.ny = dom.ny_block; a.nb = dom.nblocks(); a.ntrcr = c.ntrcr;
+  a.narr = 1 + NCAT * (3 + c.ntrcr);
+  a.nlev = a.narr + NCAT * (NILYR + NSLYR);
+  a.it_Tsfc = nt_Tsfc - 1;
+  for (int it = 0; it < NTRCR; ++it) a.dep[it] = 0;
+  for (int it = 0; it < c.ntrcr; ++it) {
+    CICE_REQUIRE(c.trcr_depend[it] >= 0 && c.trcr_depend[it] <= 2, "cice_transport_upwind_init: trcr_depend must be 0, 1 or 2");
+    a.dep[it] = c.trcr_depend[it];
+  }
+  uv.alloc(2 * n); edge.alloc(2 * n);
+  aice0.alloc(n); aicen.alloc(n * NCAT); trcrn.alloc(n * NCAT * NTRCR); vicen.alloc(n * NCAT); vsnon.alloc(n * NCAT);
+  eicen.alloc(n * NCAT * NILYR); esnon.alloc(n * NCAT * NSLYR);
+  phi.alloc(n * a.nlev); phi2.alloc(n * a.nlev);
+  a.blk = blk.p; a.HTE = HTE.p; a.HTN = HTN.p; a.tarea = tarea.p;
+  a.uvel = uv.p; a.vvel = uv.p + n; a.uee = edge.p; a.vnn = edge.p + n;
+  a.aice0 = aice0.p; a.aicen = aicen.p; a.trcrn = trcrn.p; a.vicen = vicen.p; a.vsnon = vsnon.p;
+  a.eicen = eicen.p; a.esnon = esnon.p; a.phi = phi.p; a.phi2 = phi2.p;
+}
+
+void Upwind::step(double dt, const cice_transport_fields& f) {
+  CICE_REQUIRE(n > 0, "cice_transport_upwind_init has not been called");
+  CICE_REQUIRE(f.aice0 && f.aicen && f.trcrn && f.vicen && f.vsnon && f.eicen && f.esnon && f.uvel && f.vvel,
+               "cice_transport_upwind: NULL field");
+  const size_t np = (size_t)dom.nx_block * dom.ny_block;
+  const int nb = dom.nblocks();
+  // host arrays are (nx,ny,levels,nblocks); the device keeps (nx,ny,nblocks) per level
+  auto copy = [&](double* d, double* h, int levels, bool up) {
+    if (levels == 1 || nb == 1) {
+      if (up) CICE_HIP(hipMemcpyAsync(d, h, (size_t)levels * n * 8, hipMemcpyHostToDevice, fan.next()));
+      else CICE_HIP(hipMemcpyAsync(h, d, (size_t)levels * n * 8, hipMemcpyDeviceToHost, fan.next()));
+      return;
+    }
+    for (int b = 0; b < nb; ++b) {
+      if (up) CICE_HIP(hipMemcpy2DAsync(d + (size_t)b * np, n * 8, h + (size_t)b * levels * np, np * 8, np * 8, levels,
+                                        hipMemcpyHostToDevice, fan.next()));
+      else CICE_HIP(hipMemcpy2DAsync(h + (size_t)b * levels * np, np * 8, d + (size_t)b * np, n * 8, np * 8, levels,
+                                     hipMemcpyDeviceToHost, fan.next()));
+    }
+  };
+  struct S { DevBuf<double>* d; double* h; int levels; };
+  S st[] = {{&aice0, f.aice0, 1}, {&aicen, f.aicen, NCAT}, {&trcrn, f.trcrn, NCAT * NTRCR}, {&vicen, f.vicen, NCAT},
+            {&vsnon, f.vsnon, NCAT}, {&eicen, f.eicen, NCAT * NILYR}, {&esnon, f.esnon, NCAT * NSLYR}};
+  fan.fork(stream);
+  for (S& x : st) copy(x.d->p, x.h, x.levels, true);
+  copy(uv.p, const_cast<double*>(f.uvel), 1, true);
+  copy(uv.p + n, const_cast<double*>(f.vvel), 1, true);
+  fan.join();
+  a.dt = dt;
+  const unsigned gx = (unsigned)((np + 255) / 256);
+  const dim3 blk256(256);
+  hipLaunchKernelGGL(k_up_edges, dim3(gx, 1, nb), blk256, 0, stream, a);
+  halo.update_r8(a.uee, 1, n, true, LOC_EFACE, KIND_VECTOR);   // :735-738
+  halo.update_r8(a.vnn, 1, n, true, LOC_NFACE, KIND_VECTOR);
+  hipLaunchKernelGGL(k_up_pack, dim3(gx, a.nlev, nb), blk256, 0, stream, a);
+  hipLaunchKernelGGL(k_up_advect, dim3(gx, a.nlev, nb), blk256, 0, stream, a);
+  hipLaunchKernelGGL(k_up_unpack, dim3(gx, NCAT + 1, nb), blk256, 0, stream, a);
+  // bound_state (source/ice_state.F90:162-217), :826-829
+  halo.update_r8(aicen.p, NCAT, n, true, LOC_CENTER, KIND_SCALAR);
+  for (int c = 0; c < NCAT; ++c)
+    halo.update_r8(trcrn.p + (size_t)c * NTRCR * n, a.ntrcr, n, true, LOC_CENTER, KIND_SCALAR);
+  halo.update_r8(vicen.p, NCAT, n, true, LOC_CENTER, KIND_SCALAR);
+  halo.update_r8(vsnon.p, NCAT, n, true, LOC_CENTER, KIND_SCALAR);
+  halo.update_r8(eicen.p, NCAT * NILYR, n, true, LOC_CENTER, KIND_SCALAR);
+  halo.update_r8(esnon.p, NCAT * NSLYR, n, true, LOC_CENTER, KIND_SCALAR);
+  CICE_HIP(hipGetLastError());
+  fan.fork(stream);
+  for (S& x : st) copy(x.d->p, x.h, x.levels, false);
+  fan.join();
+  CICE_HIP(hipStreamSynchronize(stream));
+}
+
 }  // namespace cice

@@ -127,6 +127,20 @@ module cice4_amd_c
          type(cice_transport_config), intent(in) :: cfg
          type(cice_transport_grid), intent(in) :: grid
       end function
+      integer(c_int) function cice_transport_upwind_init(ctx, cfg, nt_Tsfc, HTE, HTN, tarea) &
+            bind(C, name='cice_transport_upwind_init')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_transport_config), intent(in) :: cfg
+         integer(c_int), value :: nt_Tsfc
+         type(c_ptr), value :: HTE, HTN, tarea
+      end function
+      integer(c_int) function cice_transport_upwind(ctx, dt, f) bind(C, name='cice_transport_upwind')
+         import
+         type(c_ptr), value :: ctx
+         real(c_double), value :: dt
+         type(cice_transport_fields), intent(in) :: f
+      end function
       integer(c_int) function cice_transport_remap(ctx, dt, f, l_stop, istop, jstop) &
             bind(C, name='cice_transport_remap')
          import

@@ -7,7 +7,7 @@
 ! state_to_tracers, horizontal_remap, tracers_to_state and bound_state in one call); nothing of the
 ! reference's implementation is kept here.  source/ice_transport_remap.F90 stays in the build unchanged
 ! (ice_step_mod and the drivers `use` it) but is no longer called.
-! advection = 'upwind' is not provided: transport_upwind stops with a message.
+! advection = 'upwind' runs on the GPU as well (cice_transport_upwind_init / cice_transport_upwind).
 !=======================================================================
       module ice_transport_driver
 
@@ -23,7 +23,7 @@
       save
 
       character (len=char_len) :: advection   ! 'remap' or 'upwind' (ice_init.F90 reads it by this name)
-      logical, private :: fields_pinned = .false.
+      logical, private :: fields_pinned = .false., upwind_ready = .false.
 
       contains
 
@@ -52,6 +52,7 @@
          call cice_gpu_check(cice_transport_init(cice_gpu_ctx, cfg, g), 'init_transport')
          if (my_task == master_task) write(nu_diag,*) 'Incremental remapping on the GPU (libcice4_amd)'
       endif
+
       call ice_timer_stop(timer_advect)
       end subroutine init_transport
 
@@ -90,9 +91,42 @@
 
 !=======================================================================
       subroutine transport_upwind (dt)
+      use ice_state
+      use ice_grid, only: HTE, HTN, tarea
       use ice_exit, only: abort_ice
+      use ice_timers
       real (kind=dbl_kind), intent(in) :: dt
-      call abort_ice("transport_upwind: advection = 'upwind' is not provided by the GPU transport module")
+      type (cice_transport_fields) :: f
+      type (cice_transport_config) :: cfg
+      integer :: np
+
+      call ice_timer_start(timer_advect)
+      if (.not. upwind_ready) then   ! (init_transport does nothing for this scheme in the reference, :81-170)
+         if (.not. cice_gpu_domain_ready) &
+            call abort_ice('transport_upwind: the device block topology does not exist yet (init_evp or ice_HaloCreate first)')
+         call cice_gpu_check(cice_check_sizes(cice_gpu_ctx, ncat, nilyr, nslyr, max_ntrcr), 'transport_upwind')
+         if (ntrcr > size(cfg%trcr_depend)) &
+            call abort_ice('transport_upwind: more tracers than the GPU transport module is built for')
+         cfg%ntrcr = ntrcr
+         cfg%trcr_depend = 0
+         cfg%trcr_depend(1:ntrcr) = trcr_depend(1:ntrcr)
+         call cice_gpu_check(cice_transport_upwind_init(cice_gpu_ctx, cfg, nt_Tsfc, addr_r8(HTE), addr_r8(HTN), &
+                             addr_r8(tarea)), 'transport_upwind')
+         upwind_ready = .true.
+      endif
+      f%aice0 = addr_r8(aice0); f%aicen = addr_r8(aicen); f%trcrn = addr_r8(trcrn)
+      f%vicen = addr_r8(vicen); f%vsnon = addr_r8(vsnon); f%eicen = addr_r8(eicen); f%esnon = addr_r8(esnon)
+      f%uvel = addr_r8(uvel); f%vvel = addr_r8(vvel)
+      if (.not. fields_pinned) then
+         np = size(aice0)
+         call cice_gpu_pin_r8(aice0, np); call cice_gpu_pin_r8(aicen, np*ncat)
+         call cice_gpu_pin_r8(trcrn, np*ncat*max_ntrcr); call cice_gpu_pin_r8(vicen, np*ncat)
+         call cice_gpu_pin_r8(vsnon, np*ncat); call cice_gpu_pin_r8(eicen, np*ntilyr)
+         call cice_gpu_pin_r8(esnon, np*ntslyr)
+         fields_pinned = .true.
+      endif
+      call cice_gpu_check(cice_transport_upwind(cice_gpu_ctx, dt, f), 'transport_upwind')
+      call ice_timer_stop(timer_advect)
       end subroutine transport_upwind
 
       end module ice_transport_driver

@@ -577,6 +577,20 @@ class Context:
             setattr(g, n, _f8(self._tgrid[n]))
         self._ck(self.lib.cice_transport_init(self.h, C.byref(cfg), C.byref(g)))
 
+    def transport_upwind_init(self, HTE, HTN, tarea, ntrcr=2, trcr_depend=(0, 1), nt_Tsfc=1):
+        cfg = TransportConfig()
+        cfg.ntrcr = ntrcr
+        for k, d in enumerate(trcr_depend):
+            cfg.trcr_depend[k] = d
+        self._ck(self.lib.cice_transport_upwind_init(self.h, C.byref(cfg), C.c_int(nt_Tsfc), _f8(HTE), _f8(HTN), _f8(tarea)))
+
+    def transport_upwind(self, dt, s):
+        """advection = 'upwind' on the arrays of transport_remap, updated in place"""
+        f = TransportFields()
+        for n, _t in TransportFields._fields_:
+            setattr(f, n, _f8(s[n]))
+        self._ck(self.lib.cice_transport_upwind(self.h, C.c_double(dt), C.byref(f)))
+
     def transport_remap(self, dt, s):
         """s: aice0, uvel, vvel (nb,ny,nx); aicen, vicen, vsnon (nb,ncat,ny,nx); trcrn (nb,ncat,5,ny,nx); eicen
         (nb,ncat*nilyr,ny,nx); esnon (nb,ncat*nslyr,ny,nx); state updated in place.  Returns (l_stop, istop, jstop)."""

@@ -448,6 +448,14 @@ typedef struct {
 int cice_transport_init(cice_ctx *ctx, const cice_transport_config *cfg, const cice_transport_grid *grid);
 int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *f, int32_t *l_stop,
                          int32_t *istop, int32_t *jstop);
+/* advection = 'upwind' (source/ice_transport_driver.F90:672-834 transport_upwind with state_to_work :1570, upwind_field
+ * :1796, work_to_state :1686 and compute_tracers, source/ice_itd.F90:1482): first-order donor-cell transport of aice0, of
+ * every category's area, volumes and tracers and of the layer enthalpies, then bound_state, on the device.  HTE, HTN,
+ * tarea: (nx_block, ny_block, nblocks) of this rank; nt_Tsfc: 1-based index of the surface temperature among the tracers
+ * (it becomes Tocnfrz where a category's area vanishes).  Same host arrays as cice_transport_remap, updated in place. */
+int cice_transport_upwind_init(cice_ctx *ctx, const cice_transport_config *cfg, int nt_Tsfc, const double *HTE,
+                               const double *HTN, const double *tarea);
+int cice_transport_upwind(cice_ctx *ctx, double dt, const cice_transport_fields *f);
 /* Test aid: make the next cice_transport_remap stop after kernel stage stop_stage (0: run through) and / or copy
  * work array `which` (-1: none) to `out`; *count = its length in doubles. */
 int cice_transport_debug(cice_ctx *ctx, int stop_stage, int which, double *out, long long *count);

@@ -779,4 +779,10 @@ contains
       call transport_remap(dt)
    end subroutine ref_transport_remap
 
+   subroutine ref_transport_upwind(dt) bind(C, name='ref_transport_upwind')
+      use ice_transport_driver, only: transport_upwind
+      real(c_double), value :: dt
+      call transport_upwind(dt)
+   end subroutine ref_transport_upwind
+
 end module ref_capi

@@ -296,6 +296,10 @@ class Ref:
         """transport_remap(dt) (ice_transport_driver.F90:179) on the module state."""
         self.lib.ref_transport_remap(C.c_double(dt))
 
+    def transport_upwind(self, dt):
+        """transport_upwind(dt) (ice_transport_driver.F90:672) on the module state."""
+        self.lib.ref_transport_upwind(C.c_double(dt))
+
     def halo_nd(self, a, loc=1, kind=1):
         """Generic ice_HaloUpdate on a C-ordered array (nblk[,nt][,nz],ny,nx) of float64,
         float32 or int32 -- the 2-d/3-d/4-d x R8/R4/I4 specifics."""

@@ -129,6 +129,36 @@ def test_restart_round_trip_with_dropin_modules():
 
 
 @pytest.mark.gpu
+def test_whole_model_with_upwind_advection():
+    """namelist advection = 'upwind' (ice_step_mod.F90:581-582 calls transport_upwind instead of transport_remap): the
+    drop-in transport module runs that scheme on the GPU too.  25 steps (the dump is written at the day boundary) of the
+    whole model, pure reference and drop-in modules on this host, all records of the restart dump."""
+    exe = {k: os.path.join(ROOT, "oracle", "_ref", "cice_%s_gx3" % k) for k in ("ref", "dropin")}
+    for e in exe.values():
+        if not os.path.exists(e):
+            pytest.skip("%s not built" % e)
+    dirs = {k: tempfile.mkdtemp(prefix="cice_upw_%s_" % k) for k in ("ref", "dropin")}
+    try:
+        rec = {}
+        for kind in ("ref", "dropin"):
+            driver.write_rundir(dirs[kind], npt=25, overrides={"ice_nml": dict(advection="upwind")})
+            log = driver.run(exe[kind], dirs[kind])
+            rec[kind] = driver.read_restart(driver.restart_path(dirs[kind]), 100, 116)
+        assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" not in log
+        assert rec["ref"][0] == rec["dropin"][0]
+        for k in rec["ref"][1]:
+            a, g = rec["dropin"][1][k], rec["ref"][1][k]
+            if TOL_EXP == 0.0:
+                assert np.array_equal(a, g), (k, np.abs(a - g).max())
+            else:
+                assert np.abs(a - g).max() <= TOL_EXP * max(np.abs(g).max(), 1e-300), k
+        assert np.abs(rec["ref"][1]["uvel"]).max() > 0.05
+    finally:
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
     """The whole model on the real gx3 grid cut into 10 x 12 blocks of 10 x 10 cells (max_blocks = 120), the four
     all-land blocks eliminated by the reference's own create_distribution: multi-block EVP (per-subcycle halo updates

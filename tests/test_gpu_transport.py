@@ -2,7 +2,8 @@
 `call transport_remap(dt)` of the compiled reference (source/ice_transport_driver.F90:179,
 source/ice_transport_remap.F90:328), one process per configuration (tests/transport_case.py): 2 x 2 and padded
 3 x 3 blocks, cyclic / open edges, tripole north boundary, and the real gx3 grid and land mask cut into 120 blocks
-with the all-land ones eliminated.  Every state array incl. ghost cells, three flow / ice-cover regimes: bit for bit."""
+with the all-land ones eliminated.  Every state array incl. ghost cells, three flow / ice-cover regimes: bit for bit.
+The same configurations for advection = 'upwind' (cice_transport_upwind against `call transport_upwind(dt)`, :672)."""
 import os
 import subprocess
 import sys
@@ -21,5 +22,19 @@ def test_transport_remap_equals_reference(case):
     if not refapi.available(case[0]):
         pytest.skip(f"oracle/_ref/libcice_ref_{case[0]}.so not built")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "transport_case.py"), *case],
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "TRANSPORT-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-4000:]
+
+
+# (no open east-west edge here: the reference's transport_upwind keeps its edge velocities in automatic arrays that
+#  ice_HaloUpdate leaves untouched on an open edge, :699-738 -- what it computes there is not defined)
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [c for c in CASES if c[1] != "open"], ids=lambda c: "-".join(c))
+def test_transport_upwind_equals_reference(case):
+    from oracle import refapi
+    if not refapi.available(case[0]):
+        pytest.skip(f"oracle/_ref/libcice_ref_{case[0]}.so not built")
+    args = list(case) + ["-"] * (4 - len(case)) + ["upwind"]
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "transport_case.py"), *args],
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "TRANSPORT-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-4000:]

@@ -1,11 +1,12 @@
 """One horizontal-transport comparison in its own process (the compiled reference allows ONE init_domain per
 process and library).  Started by tests/test_gpu_transport.py:
 
-    python tests/transport_case.py <cfg> <ew> <ns> [gx3]
+    python tests/transport_case.py <cfg> <ew> <ns> [gx3|-] [upwind]
 
 `call transport_remap(dt)` of the compiled reference (source/ice_transport_driver.F90:179; oracle/_ref) on its own
 module arrays, block distribution and boundary types, against cice_transport_remap on the MI355X with the same
-inputs: every state array, ghost cells included, bit for bit.  Prints 'TRANSPORT-OK <n checks>'.
+inputs: every state array, ghost cells included, bit for bit.  With `upwind`: `call transport_upwind(dt)` (:672) against
+cice_transport_upwind.  Prints 'TRANSPORT-OK <n checks>'.
 """
 import os
 import sys
@@ -24,7 +25,8 @@ DT = 3600.0
 def main():
     cfg, ew, ns = sys.argv[1:4]
     gridkw = {}
-    if len(sys.argv) > 4:   # the reference's own gx3 grid + land mask, written from the committed fixture
+    upwind = len(sys.argv) > 5 and sys.argv[5] == "upwind"
+    if len(sys.argv) > 4 and sys.argv[4] == "gx3":   # the reference's own gx3 grid + land mask, written from the committed fixture
         d = tempfile.mkdtemp()
         z = np.load(os.path.join(ROOT, "tests", "golden", "gx3_grid_kmt.npz"))
         with open(os.path.join(d, "global_gx3.grid"), "wb") as f:
@@ -53,7 +55,11 @@ def main():
     dom = ctx.domain_create_map(nxg, nyg, bsx, bsy, owner, ew=BND[ew], ns=BND[ns], local_id=lid)
     assert dom["nblocks"] == nbl
     grid = {k: np.ascontiguousarray(ref.get(k)[:nbl]) for k in ("HTN", "HTE", "dxt", "dyt", "dxu", "dyu", "tarear", "hm")}
-    ctx.transport_init(grid, ntrcr=2, trcr_depend=(0, 1))
+    if upwind:
+        ctx.transport_upwind_init(grid["HTE"], grid["HTN"], np.ascontiguousarray(ref.get("tarea")[:nbl]), ntrcr=2,
+                                  trcr_depend=(0, 1), nt_Tsfc=1)
+    else:
+        ctx.transport_init(grid, ntrcr=2, trcr_depend=(0, 1))
     rng = np.random.default_rng(20261004)
     nchk = 0
     hm = grid["hm"]
@@ -117,8 +123,12 @@ def main():
                    eicen=st[4][:nbl].copy(), esnon=st[5][:nbl].copy(), aice0=a0[:nbl].copy(), uvel=uu[:nbl].copy(),
                    vvel=vv[:nbl].copy())
         before = {k: v.copy() for k, v in dev.items()}
-        ref.transport_remap(DT)
-        assert ctx.transport_remap(DT, dev) == (0, 0, 0)
+        if upwind:
+            ref.transport_upwind(DT)
+            ctx.transport_upwind(DT, dev)
+        else:
+            ref.transport_remap(DT)
+            assert ctx.transport_remap(DT, dev) == (0, 0, 0)
         want = dict(aicen=ref.get("aicen", nbm * NC).reshape(nbm, NC, ny, nx), trcrn=ref.get("trcrn", nbm * NC * NT).reshape(nbm, NC, NT, ny, nx),
                     vicen=ref.get("vicen", nbm * NC).reshape(nbm, NC, ny, nx), vsnon=ref.get("vsnon", nbm * NC).reshape(nbm, NC, ny, nx),
                     eicen=ref.get("eicen", nbm * NC * NI).reshape(nbm, NC * NI, ny, nx),
