@@ -307,7 +307,7 @@ static void halo_host_lists(const Domain& dm, T* field, const LevelStrides& ls, 
     CICE_REQUIRE(kind >= KIND_SCALAR && kind <= KIND_ANGLE, "halo: field kind unknown on a tripole grid");
   }
   const int sgn = kind == KIND_SCALAR ? 1 : -1;
-  std::vector<T> buf(fold ? 2 * (size_t)dm.nxg : 0);
+  std::vector<T> buf(fold ? (size_t)dm.fold_rows() * dm.nxg : 0);
   for (int z = 0; z < nz; ++z) {
     T* f = field + (size_t)(z % ls.nz1) * ls.s1 + (size_t)(z / ls.nz1) * ls.s2;
     for (size_t e = 0; e < dm.hsrc.size(); ++e) f[at(dm.hdst[e])] = f[at(dm.hsrc[e])];
@@ -560,8 +560,8 @@ int cice_device_sync(cice_ctx* ctx) {
 int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew, int ns, int rank,
                        int npx, int npy) {
   CICE_TRY(ctx)
-  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 3,
-               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole)");
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 4,
+               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole) or 4 (tripoleT)");
   c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;  // test aid, see domain.h
   const char* msg = c_->dom.create(nxg, nyg, bsx, bsy, ew, ns, rank, npx, npy);
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create: ") + msg};
@@ -577,8 +577,8 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
 int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew, int ns, int rank,
                            int nranks, const int* owner, const int* local_id) {
   CICE_TRY(ctx)
-  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 3,
-               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole)");
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 4,
+               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole) or 4 (tripoleT)");
   c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;
   const char* msg = c_->dom.create_map(nxg, nyg, bsx, bsy, ew, ns, rank, nranks, owner, local_id);
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_map: ") + msg};

@@ -70,12 +70,12 @@ const char* Domain::create_map(int nx_global, int ny_global, int block_size_x, i
 const char* Domain::build(const std::vector<int>& owner, const std::vector<int>& lid) {
   nx_block = bsx + 2; ny_block = bsy + 2;
   if (ew < 0 || ew > BND_CLOSED) return "east-west boundary must be open, cyclic or closed";
-  if (ns < 0 || ns > BND_TRIPOLE) return "unknown north-south boundary";
-  if (ns == BND_TRIPOLE) {
+  if (ns < 0 || ns > BND_TRIPOLET) return "unknown north-south boundary";
+  if (tripole()) {
     if (ew != BND_CYCLIC) return "a tripole north boundary needs a cyclic east-west boundary";
     if (nxg % 2) return "a tripole north boundary needs an even nx_global";
-    if (nyg - (nby - 1) * bsy < 2 && nby > 1) return "tripole: the top block row needs two physical rows";
-    if (nyg < 2) return "tripole: fewer than two rows";
+    if (nyg - (nby - 1) * bsy < fold_rows() && nby > 1) return "tripole: the top block row has fewer physical rows than the fold needs";
+    if (nyg < fold_rows()) return "tripole: fewer rows than the fold needs";
   }
   all.clear(); local.clear(); hsrc.clear(); hdst.clear(); hfill.clear(); send.clear(); recv.clear();
   rsrc.clear(); rdst.clear(); overlap = 0;
@@ -113,7 +113,7 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
   auto addr = [&](const Block& b, int i, int j) {  // 1-based (i,j)
     return (int32_t)((long long)b.local_id * np + (long long)(j - 1) * nx_block + (i - 1));
   };
-  const int ns_wrap = (ns == BND_TRIPOLE) ? BND_OPEN : ns;   // south edge of a tripole grid is open (:246)
+  const int ns_wrap = tripole() ? BND_OPEN : ns;   // south edge of a tripole grid is open (:246)
 
   std::map<int, HaloMsg> smap, rmap;
   // Visit every ghost cell of every block in one global order; both ends of a message
@@ -153,19 +153,26 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
   for (auto& kv : smap) send.push_back(std::move(kv.second));
   for (auto& kv : rmap) recv.push_back(std::move(kv.second));
 
-  if (ns == BND_TRIPOLE) {
-    // ranks that own a block of the top block row each assemble the whole buffer
+  if (tripole()) {
+    // The fold buffer holds the top R physical rows of the whole grid: R = 2 for a fold through U points, 3 for one
+    // through T points (tripoleRows).  Ranks that own a block of the top block row each assemble the whole buffer.
+    const int R = fold_rows();
+    const bool tfold = ns == BND_TRIPOLET;
     std::vector<char> top_rank(nranks, 0);
     for (const Block& b : all)
       if (b.jb == nby - 1 && b.owner >= 0) top_rank[b.owner] = 1;
     fold = top_rank[rank] != 0;
     std::map<int, HaloMsg> fs, fr;
-    for (const Block& s : all) {   // 1. top two physical rows of every top-row block -> buffer
+    for (const Block& s : all) {   // 1. top R physical rows of every top-row block -> buffer (:3702-3722)
       if (s.jb != nby - 1 || s.owner < 0) continue;
-      for (int r = 0; r < 2; ++r)
+      for (int r = 0; r < R; ++r)
         for (int i = s.ilo; i <= s.ihi; ++i) {
           const int32_t b = (int32_t)(r * nxg + s.i0 + (i - s.ilo));
-          const int j = s.jhi - 1 + r;
+          // U-fold: rows jhi-1, jhi.  T-fold: the 'north' message fills the three buffer rows with jhi-2, jhi-1, jhi
+          // (:3702-3722), then the 'northeast' / 'northwest' messages of the same block, which kept the U-fold's two
+          // rows, overwrite rows 1 and 2 with jhi-1, jhi (:3813-3826, :3859-3872): what the update works on is
+          // jhi-1, jhi, jhi -- reproduced here as the reference runs, not as its comments describe it
+          const int j = tfold ? s.jhi - 1 + std::min(r, 1) : s.jhi - 1 + r;
           if (s.owner == rank) {
             fold_lsrc.push_back(addr(s, i, j));
             fold_bidx.push_back(b);
@@ -181,18 +188,26 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
     for (auto& kv : fs) fold_send.push_back(std::move(kv.second));
     for (auto& kv : fr) fold_recv.push_back(std::move(kv.second));
     if (fold) {
-      // 2. symmetry of the degenerate top row (serial/ice_boundary.F90:784-823); 1-based i as there
-      for (int i = 1; i <= nxg / 2 - 1; ++i) {
-        fold_lo[LOC_NECORNER - 1].push_back(nxg + i - 1);
-        fold_hi[LOC_NECORNER - 1].push_back(nxg + (nxg - i) - 1);
-      }
-      for (int i = 1; i <= nxg / 2; ++i) {
-        fold_lo[LOC_NFACE - 1].push_back(nxg + i - 1);
-        fold_hi[LOC_NFACE - 1].push_back(nxg + (nxg + 1 - i) - 1);
+      // 2. symmetry of the degenerate top row of the buffer (serial/ice_boundary.F90:725-823); 1-based i as there.
+      // U-fold: NE-corner and N-face fields lie on the fold; T-fold: centre and E-face fields do.
+      const int top = (R - 1) * nxg;
+      auto pair = [&](int loc, int i, int idst) {
+        fold_lo[loc - 1].push_back(top + i - 1);
+        fold_hi[loc - 1].push_back(top + idst - 1);
+      };
+      if (tfold) {
+        for (int i = 2; i <= nxg / 2; ++i) pair(LOC_CENTER, i, nxg - i + 2);      // :735-743
+        for (int i = 1; i <= nxg / 2; ++i) pair(LOC_EFACE, i, nxg + 1 - i);       // :757-765
+      } else {
+        for (int i = 1; i <= nxg / 2 - 1; ++i) pair(LOC_NECORNER, i, nxg - i);    // :792-800
+        for (int i = 1; i <= nxg / 2; ++i) pair(LOC_NFACE, i, nxg + 1 - i);       // :814-822
       }
       // 3. copy out (:3726-3750 list, :831-866 offsets): rows jhi (jj = 1) and jhi+1 (jj = 2) of every
-      // top-row block of this rank, columns 1 .. ihi+1
-      const int ioff[4] = {0, 1, 0, 1}, joff[4] = {0, 1, 1, 0};  // center, NE corner, N face, E face
+      // top-row block of this rank, columns 1 .. ihi+1.  Offsets in the order centre, NE corner, N face, E face.
+      const int ioffU[4] = {0, 1, 0, 1}, joffU[4] = {0, 1, 1, 0};
+      const int ioffT[4] = {-1, 0, -1, 0}, joffT[4] = {0, 1, 1, 0};
+      const int* ioff = tfold ? ioffT : ioffU;
+      const int* joff = tfold ? joffT : joffU;
       for (int gid : local) {
         const Block& d = all[gid];
         if (d.jb != nby - 1) continue;
@@ -204,7 +219,7 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
               const int jSrc = 4 - jj - joff[l];
               if (iSrc == 0) iSrc = nxg;
               if (iSrc > nxg) iSrc -= nxg;
-              if (jSrc > 2 || jSrc < 1) continue;
+              if (jSrc > R || jSrc < 1) continue;
               fold_out[l].dst.push_back(addr(d, i, d.jhi + jj - 1));
               fold_out[l].src.push_back((int32_t)((jSrc - 1) * nxg + iSrc - 1));
             }

@@ -15,7 +15,8 @@
 
 namespace cice {
 
-enum Boundary { BND_OPEN = 0, BND_CYCLIC = 1, BND_CLOSED = 2, BND_TRIPOLE = 3 };
+// BND_TRIPOLE: fold through U points ('tripole'), BND_TRIPOLET: through T points ('tripoleT', source/ice_blocks.F90:228-233)
+enum Boundary { BND_OPEN = 0, BND_CYCLIC = 1, BND_CLOSED = 2, BND_TRIPOLE = 3, BND_TRIPOLET = 4 };
 // field location / kind codes of ice_HaloUpdate (drivers/cice4/ice_constants.F90:185-205); they only matter on
 // a tripole boundary
 enum FieldLoc { LOC_CENTER = 1, LOC_NECORNER = 2, LOC_NFACE = 3, LOC_EFACE = 4 };
@@ -41,6 +42,8 @@ struct Domain {
   int nx_block = 0, ny_block = 0;
   int nbx = 0, nby = 0, npx = 1, npy = 1, rank = 0, nranks = 1;
   int ew = BND_CYCLIC, ns = BND_OPEN;
+  bool tripole() const { return ns == BND_TRIPOLE || ns == BND_TRIPOLET; }
+  int fold_rows() const { return ns == BND_TRIPOLET ? 3 : 2; }   // rows of the global fold buffer (tripoleRows, serial/ice_boundary.F90:199-204)
   // Test aid: route copies between DIFFERENT blocks of this rank through the message path
   // (send to / receive from the own rank), so that pack / RCCL / unpack run on a single GPU.
   bool self_comm = false;

@@ -2423,7 +2423,7 @@ bool Evp::can_fuse() const {
   if (dom.nbx != 1) return false;
   if (dom.overlap > 0) return dom.overlap % 2 == 0;
   // a tripole fold rewrites the top row and its ghost row after every subcycle
-  return dom.nby == 1 && dom.ns != BND_CYCLIC && dom.ns != BND_TRIPOLE && !halo.has_refresh();
+  return dom.nby == 1 && dom.ns != BND_CYCLIC && !dom.tripole() && !halo.has_refresh();
 }
 
 int Evp::fused_waves() const {
@@ -2709,7 +2709,7 @@ void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long pe
 bool Evp::can_reside_peer() const {
   if (!resident_on || resident_failed || !halo.multi_rank()) return false;
   if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold() || dom.nbx != 1 || dom.npx != 1) return false;
-  if (dom.ns == BND_TRIPOLE) return false;
+  if (dom.tripole()) return false;
   // every neighbour this slab has must be connected
   const Block& bl = dom.all[dom.local[0]];
   const bool has_s = bl.jb > 0 || dom.ns == BND_CYCLIC, has_n = bl.jb < dom.nby - 1 || dom.ns == BND_CYCLIC;

@@ -79,6 +79,7 @@ class Halo {
   std::vector<int> send_peer_, send_off_, send_cnt_, recv_peer_, recv_off_, recv_cnt_;
   int nsend_ = 0, nrecv_ = 0;
   // land-block fill list and tripole fold (domain.h)
+  int fold_rows_ = 2;   // rows of the global fold buffer (2: fold through U points, 3: through T points)
   int nfill_ = 0, nxg_ = 0, nfold_src_ = 0, nfold_out_[4] = {0, 0, 0, 0}, nfold_pair_[4] = {0, 0, 0, 0};
   bool fold_ = false;
   DevBuf<int32_t> fill_, fold_lsrc_, fold_bidx_, fold_send_addr_, fold_recv_addr_, fold_dst_[4], fold_src_[4],

@@ -410,6 +410,7 @@ void Halo::init(const Domain& d, hipStream_t s) {
   nfill_ = put(fill_, d.hfill);
   fold_ = d.fold;
   nxg_ = d.nxg;
+  fold_rows_ = d.fold_rows();
   nfold_src_ = put(fold_lsrc_, d.fold_lsrc);
   put(fold_bidx_, d.fold_bidx);
   for (int l = 0; l < 4; ++l) {
@@ -568,7 +569,7 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
     CICE_REQUIRE(loc >= LOC_CENTER && loc <= LOC_EFACE, "halo: field location unknown on a tripole grid");
     CICE_REQUIRE(kind >= KIND_SCALAR && kind <= KIND_ANGLE, "halo: field kind unknown on a tripole grid");
     const int sgn = kind == KIND_SCALAR ? 1 : -1;
-    const int bstride = 2 * nxg_;
+    const int bstride = fold_rows_ * nxg_;
     T* buf = nullptr;
     if (fold_) {
       if (fold_cap_ < nfields) {

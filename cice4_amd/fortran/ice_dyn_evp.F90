@@ -203,6 +203,7 @@
       case ('closed'); bnd_code = 2
       case ('open');   bnd_code = 0
       case ('tripole'); bnd_code = 3
+      case ('tripoleT'); bnd_code = 4
       case default
          write(nu_diag,*) 'boundary type not supported on the GPU path: ', trim(name)
          error stop 'bnd_code'

@@ -14,7 +14,7 @@
 ! (serial/ice_boundary.F90:705-869: fieldLoc / fieldKind decide offsets and sign at the fold); ANY
 ! block distribution create_distribution produced, land-block elimination included -- the block->task
 ! map is handed to the device as it is, ghost cells facing an eliminated block take fillValue
-! (mpi/ice_boundary.F90:5108-5111).  'tripoleT' stops with a message.
+! (mpi/ice_boundary.F90:5108-5111); 'tripoleT' (fold through T points) likewise.
 ! Ghost cells beyond an open or closed edge are left untouched, which is what the reference
 ! does for them (mpi/ice_boundary.F90: messages to a non-existent neighbour are never created).
 !
@@ -43,7 +43,7 @@ module ice_boundary
    type, public :: ice_halo
       integer (int_kind) :: communicator   ! kept for source compatibility (unused)
       integer (int_kind) :: numBlocks      ! local blocks the device domain was built for
-      integer (int_kind) :: ewBnd, nsBnd   ! 0 open, 1 cyclic, 2 closed, 3 tripole (north-south only)
+      integer (int_kind) :: ewBnd, nsBnd   ! 0 open, 1 cyclic, 2 closed, 3 tripole, 4 tripoleT (north-south only)
    end type
 
    public :: ice_HaloCreate, ice_HaloUpdate, ice_HaloExtrapolate
@@ -77,7 +77,7 @@ contains
       if (nxGlobal /= nx_global) call abort_ice('ice_HaloCreate: nxGlobal /= nx_global')
       halo%ewBnd = boundary_code(ewBoundaryType)
       halo%nsBnd = boundary_code(nsBoundaryType)
-      if (halo%ewBnd == 3) call abort_ice('ice_HaloCreate: tripole is a north-south boundary type')
+      if (halo%ewBnd >= 3) call abort_ice('ice_HaloCreate: tripole is a north-south boundary type')
 
       call ice_distributionGet(dist, nprocs=nprocs, communicator=halo%communicator, &
                                numLocalBlocks=numBlocks)
@@ -125,6 +125,7 @@ contains
       case ('cyclic'); boundary_code = 1
       case ('closed'); boundary_code = 2
       case ('tripole'); boundary_code = 3
+      case ('tripoleT'); boundary_code = 4
       case default
          call abort_ice('ice_HaloCreate: boundary type not supported on the GPU path: '//trim(name))
       end select

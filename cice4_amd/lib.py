@@ -261,7 +261,8 @@ class Context:
         lsrc, bidx = self.domain_list("fold_lsrc"), self.domain_list("fold_bidx")
         if len(lsrc):
             sgn = 1 if kind == 1 else -1
-            buf = np.full((v.shape[0], 2 * self.dinfo["nxg"]), fill, a.dtype)
+            rows = int(bidx.max()) // self.dinfo["nxg"] + 1     # 2: fold through U points, 3: through T points
+            buf = np.full((v.shape[0], rows * self.dinfo["nxg"]), fill, a.dtype)
             buf[:, bidx] = v[:, lsrc]
             lo, hi = self.domain_list("fold_lo", loc), self.domain_list("fold_hi", loc)
             if len(lo):

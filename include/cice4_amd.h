@@ -70,7 +70,10 @@ int cice_diag_stream_copy(cice_ctx *ctx, long long n_doubles, float *elapsed_ms)
 /* ---- domain: replaces init_domain_blocks + init_domain_distribution +
  * ice_HaloCreate (source/ice_domain.F90:96,258; mpi/ice_boundary.F90:153).
  * Host logic only -- usable without a GPU. boundary: 0 open, 1 cyclic, 2 closed; ns_boundary also 3 =
- * 'tripole' (U-fold, source/ice_blocks.F90:457-467; needs a cyclic e-w boundary and an even nx_global).
+ * 'tripole' (U-fold, source/ice_blocks.F90:457-467; needs a cyclic e-w boundary and an even nx_global) and 4 =
+ * 'tripoleT' (fold through T points, serial/ice_boundary.F90:725-776: three rows of the top block row in the fold
+ * buffer, which the update works on exactly as the serial reference leaves it -- its northeast / northwest messages
+ * overwrite two of the three rows, :3813-3826 -- so that a run agrees with that reference bit for bit).
  * Blocks are dealt to an (npx x npy) process grid in contiguous rectangles
  * (cartesian distribution, source/ice_distribution.F90:78). */
 int cice_domain_create(cice_ctx *ctx, int nx_global, int ny_global, int block_size_x,

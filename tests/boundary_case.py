@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 NDTE_EVP = 40
-BND = {"open": 0, "cyclic": 1, "closed": 2, "tripole": 3}
+BND = {"open": 0, "cyclic": 1, "closed": 2, "tripole": 3, "tripoleT": 4}
 GRID_FIELDS = ("HTN", "HTE", "dxt", "dyt", "dxu", "dyu", "dxhy", "dyhx", "cxp", "cyp", "cxm", "cym",
                "tarea", "uarea", "tarear", "uarear", "tinyarea", "ULAT", "ULON", "TLAT", "TLON",
                "ANGLE", "hm", "uvm", "tmask", "umask")
@@ -72,8 +72,8 @@ def main():
         else:
             plain = lib.Context().domain_create(nxg, nyg, bsx, bsy, ew=BND[ew], ns=BND[ns])   # cartesian map
             assert np.array_equal(plain["hsrc"], dom["hsrc"]) and np.array_equal(plain["hdst"], dom["hdst"])
-        locs = (1, 2, 3, 4) if ns == "tripole" else (1,)
-        kinds = (1, 2, 3) if ns == "tripole" else (1,)
+        locs = (1, 2, 3, 4) if ns.startswith("tripole") else (1,)
+        kinds = (1, 2, 3) if ns.startswith("tripole") else (1,)
         for dtype in (np.float64, np.float32, np.int32):
             for loc in locs:
                 for kind in kinds:

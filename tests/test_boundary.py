@@ -15,9 +15,15 @@ CASES = [("gx3b4", "cyclic", "open"), ("pad", "cyclic", "open"), ("pad", "open",
          ("pad", "open", "cyclic"), ("pad", "cyclic", "cyclic"), ("padx", "cyclic", "open"),   # padx: max_blocks > blocks
          # tripole (U-fold) north boundary, serial/ice_boundary.F90:705-869: every field location x kind x type
          ("small", "cyclic", "tripole"), ("pad", "cyclic", "tripole"),
+         # the fold through T points (serial/ice_boundary.F90:725-776: three buffer rows, other offsets and symmetric pairs)
+         # (2 x 2 blocks, and 10 x 12 blocks with a padded last column and six rows in the top block row; the 'pad'
+         #  configurations have two rows there: the reference itself stops, "not enough points in block for tripole")
+         ("small", "cyclic", "tripoleT"), ("gx3b4", "cyclic", "tripoleT"),
          # land-block elimination on the reference's own gx3 grid and land mask: 10 x 12 blocks, the 4 all-land ones dropped by
          # create_distribution; ghost cells facing them take the fill value (mpi/ice_boundary.F90:5108-5111)
-         ("gx3e", "cyclic", "open", "gx3")]
+         ("gx3e", "cyclic", "open", "gx3"),
+         # ... and the same block distribution under either fold
+         ("gx3e", "cyclic", "tripole", "gx3"), ("gx3e", "cyclic", "tripoleT", "gx3")]
 
 
 def run_case(mode, cfg, ew, ns, *extra):

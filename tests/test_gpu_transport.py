@@ -12,6 +12,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [("small", "cyclic", "open"), ("pad", "cyclic", "open"), ("pad", "open", "open"), ("small", "cyclic", "tripole"),
+         ("small", "cyclic", "tripoleT"),
          ("gx3", "cyclic", "open", "gx3"), ("gx3e", "cyclic", "open", "gx3")]
 
 

@@ -17,7 +17,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-BND = {"open": 0, "cyclic": 1, "closed": 2, "tripole": 3}
+BND = {"open": 0, "cyclic": 1, "closed": 2, "tripole": 3, "tripoleT": 4}
 NC, NI, NS, NT = 5, 4, 1, 5
 DT = 3600.0
 
