@@ -97,6 +97,7 @@ class Evp {
   bool res_dense = true;         // allow three 4-wavefront workgroups per CU
   int res_spin_us = 200000;      // bound of every wait inside the resident kernel
   int res_level = 0;             // 0: dense allowed, 1: one workgroup per CU only (after a dense time-out)
+  hipEvent_t res_done_ev = nullptr;   // end of the cross-rank loop, polled (run_resident)
   int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
   int res_occ[5][2][2] = {};     // workgroups of k_evp_resident<W, DAMP, PEER> one CU holds, 0 = not asked yet

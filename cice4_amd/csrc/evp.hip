@@ -17,7 +17,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
+#include <thread>
 
 namespace cice {
 
@@ -1453,10 +1455,15 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
             have = (int)(v - (r.epoch0 + 1u)) >= 0;
           }
           if (__all(have)) break;
+          const unsigned long long miss = __ballot(!have);
           if (lx == 0) {
             bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (!bad && wall_clock64() - t0 > r.spin_ticks) {
-              __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (__hip_atomic_exchange(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                // who gave up first, and on what (read by the host for its message): wait 1 = "the neighbour has begun"
+                r.abort_flag[1] = 1u; r.abort_flag[2] = (unsigned)tile; r.abort_flag[3] = 0u;
+                r.abort_flag[4] = (unsigned)miss; r.abort_flag[5] = (unsigned)(miss >> 32); r.abort_flag[6] = r.epoch0 + 1u;
+              }
               bad = 1;
             }
           }
@@ -1517,10 +1524,14 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
           have = (int)(v - target) >= 0;
         }
         if (__all(have)) break;
+        const unsigned long long miss = __ballot(!have);
         if (lx == 0) {
           bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (!bad && wall_clock64() - t0 > r.spin_ticks) {
-            __hip_atomic_store(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_exchange(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              r.abort_flag[1] = 2u; r.abort_flag[2] = (unsigned)tile; r.abort_flag[3] = (unsigned)k;   // wait 2 = (E)
+              r.abort_flag[4] = (unsigned)miss; r.abort_flag[5] = (unsigned)(miss >> 32); r.abort_flag[6] = target;
+            }
             bad = 1;
           }
         }
@@ -1941,7 +1952,10 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
-Evp::~Evp() { drop_graph(); }
+Evp::~Evp() {
+  drop_graph();
+  if (res_done_ev) (void)hipEventDestroy(res_done_ev);
+}
 
 void Evp::drop_graph() {
   if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -2651,9 +2665,23 @@ int Evp::resident_waves() const {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
-  if (halo.multi_rank()) ncu = std::max(1, ncu / std::max(1, res_peer_share));   // contexts sharing this device (tests)
+  const int ncu_dev = ncu;
+  const int share = halo.multi_rank() ? std::max(1, res_peer_share) : 1;   // contexts sharing this device (tests)
+  ncu = std::max(1, ncu / share);
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
-  auto tiles = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
+  auto tiles_raw = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
+  // Several ranks' loops on ONE device (tests only): every workgroup needs a CU of its own and the dispatcher deals the
+  // workgroups of a launch round-robin over 8 XCDs x 4 shader engines without moving them between engines afterwards --
+  // the `share` launches together must fit every engine (3 launches of 80 workgroups = 3 + 3 + 3 on an engine of 8 CUs
+  // did not: one workgroup never started, the loops timed out every few dozen calls; scripts/soak_peer.py)
+  auto tiles = [&](int w) -> long long {
+    const long long t = tiles_raw(w);
+    if (share > 1) {
+      const long long per_xcd = (t + 7) / 8, per_se = (per_xcd + 3) / 4;
+      if (per_se * share > std::max(1, ncu_dev / 32)) return (long long)ncu + 1;   // does not fit: as if too many tiles
+    }
+    return t;
+  };
   const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && !halo.multi_rank();
   if (res_w_opt) return (tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok)) && !(res_w_opt == 12 && halo.multi_rank()) ? res_w_opt : 0;
   int single = 0;
@@ -3033,10 +3061,41 @@ bool Evp::run_resident(int ksub0, int nsub) {
     return false;
   }
   unsigned aborted = 0;
+  if (peer) {
+    // This loop ends when the neighbours' loops have run: nothing here may block inside the runtime before they are
+    // launched.  Ranks that are threads of ONE process (the one-GPU tests) share the runtime's locks, and a blocking copy
+    // or synchronisation of this thread could hold up the launch of the very kernel it is waiting for: poll an event.
+    if (!res_done_ev) CICE_HIP(hipEventCreateWithFlags(&res_done_ev, hipEventDisableTiming));
+    CICE_HIP(hipEventRecord(res_done_ev, stream));
+    hipError_t q;
+    while ((q = hipEventQuery(res_done_ev)) == hipErrorNotReady) std::this_thread::sleep_for(std::chrono::microseconds(20));
+    CICE_HIP(q);
+  }
   if (peer && res_peer_agree) halo.all_max_u32(r.abort_flag);   // every rank falls back, or none does
-  CICE_HIP(hipMemcpyAsync(&aborted, r.abort_flag, 4, hipMemcpyDeviceToHost, stream));
+  unsigned why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  CICE_HIP(hipMemcpyAsync(why, r.abort_flag, sizeof(why), hipMemcpyDeviceToHost, stream));
   CICE_HIP(hipStreamSynchronize(stream));
+  aborted = why[0];
   res_epoch += (unsigned)nsub + (peer ? 3u : 0u);
+  if (aborted && why[1]) {   // this rank's own first time-out (none: the word came from another rank)
+    std::fprintf(stderr, "cice4_amd: rank %d: tile %u of %d gave up %s (subcycle %u of the launch, word wanted %u), producers "
+                         "not heard from: lanes %08x%08x of its dependency list:", dom.rank, why[2], res_tiles,
+                 why[1] == 1 ? "waiting for the neighbouring ranks' loops to begin" : "waiting for the producers of its halo",
+                 why[3], why[6], why[5], why[4]);
+    std::vector<int32_t> dl(RES_MAXDEP);
+    CICE_HIP(hipMemcpy(dl.data(), res_deps.p + (size_t)why[2] * RES_MAXDEP, RES_MAXDEP * 4, hipMemcpyDeviceToHost));
+    const unsigned long long ms = ((unsigned long long)why[5] << 32) | why[4];
+    for (int l = 0; l < RES_MAXDEP; ++l)
+      if ((ms >> l) & 1) {
+        unsigned seen = 0;
+        const int d = dl[l];
+        const unsigned* wp = d <= -2 ? res_rprog.p + (size_t)(-2 - d) * RES_STRIDE : res_prog.p + (size_t)d * RES_STRIDE;
+        CICE_HIP(hipMemcpy(&seen, wp, 4, hipMemcpyDeviceToHost));
+        std::fprintf(stderr, " [%d: %s %d, word now %u]", l, d <= -2 ? ((-2 - d) / RP_MAX ? "north rank's tile" : "south rank's tile") : "own tile",
+                     d <= -2 ? (-2 - d) % RP_MAX : d, seen);
+      }
+    std::fprintf(stderr, "\n");
+  }
   if (aborted) {
     std::fprintf(stderr, "cice4_amd: resident EVP loop timed out (not every tile was resident%s); this range runs as one "
                          "launch per pair of subcycles%s\n", peer ? ", here or on another rank" : "",
