@@ -111,6 +111,13 @@ def parse():
     p.add_argument("--peer-loop", action="store_true",
                    help="N > 1: one classic slab per rank and the cross-rank one-launch loop (device-initiated exchange through "
                         "IPC-mapped buffers of the neighbours) instead of wide-halo slabs; grids that fit the chip only (gx1, gx3)")
+    p.add_argument("--peer-verify", action="store_true",
+                   help="with --peer-loop: first run one step through the per-subcycle message exchange and one through the "
+                        "cross-rank loop from the same state and compare velocities and stresses bit for bit on every rank; "
+                        "exit 21 if they differ or the loop fell back (22: fell back during the timed steps)")
+    p.add_argument("--no-peer-try", action="store_true",
+                   help="N > 1, gx1: do not start the second set of rank processes that tries the cross-rank one-launch loop")
+    p.add_argument("--peer-try-timeout", type=float, default=240.0)
     p.add_argument("--host-only", action="store_true",
                    help="no GPU: launcher + rendezvous + slab decomposition + one ghost exchange over gloo, checked")
     p.add_argument("--comm-timeout", type=float, default=120.0,
@@ -216,6 +223,64 @@ def launch_ranks(args):
         while time.time() < t_end and any(p.poll() is None for p in procs):
             time.sleep(0.1)
     return rc if rc > 0 else 1
+
+
+def try_peer_loop(args, rank, world, dist):
+    """N > 1, gx1: after the main measurement every rank starts ONE child process; the children form their own job (own
+    rendezvous port, own RCCL communicator) and run `bench.py --peer-loop --peer-verify`: the cross-rank one-launch loop
+    with device-initiated exchange, which has to reproduce the per-subcycle exchange bit for bit in that run before it is
+    timed.  Whatever happens to the children -- no peer mapping between the devices, a time-out, a mismatch -- stays in
+    the children: the parents wait a bounded time, stop them, and keep their own result.  Returns rank 0's record of the
+    child job (None on the other ranks and whenever any child did not finish cleanly)."""
+    import signal
+    import socket
+    import subprocess
+    port = [None]
+    if rank == 0:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port[0] = s.getsockname()[1]
+        s.close()
+    dist.broadcast_object_list(port, src=0)
+    env = dict(os.environ, MASTER_PORT=str(port[0]), CICE4_AMD_BENCH_PEER_CHILD="1")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--peer-loop", "--peer-verify", "--no-peer-try",
+           "--steps", str(args.steps), "--warmup", str(args.warmup), "--ramp-seconds", str(args.ramp_seconds), "--no-tenth",
+           "--no-thermo", "--no-cpu-baseline", "--no-dropin-timing", "--comm-timeout", str(min(args.comm_timeout, 60.0))]
+    progress("gx1: trying the cross-rank one-launch loop in a second set of rank processes")
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, start_new_session=True)
+    out = b""
+    try:
+        out, _ = p.communicate(timeout=args.peer_try_timeout)
+    except subprocess.TimeoutExpired:
+        pass
+    if p.poll() is None:
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(p.pid, sig)
+            except (ProcessLookupError, PermissionError):
+                pass
+            try:
+                p.wait(5.0)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    rcs = [None] * world
+    with bounded(args.comm_timeout, "collecting the exit codes of the cross-rank-loop attempt"):
+        dist.all_gather_object(rcs, p.returncode)
+    if any(c != 0 for c in rcs):
+        progress(f"gx1: the cross-rank-loop attempt is not used (exit codes {rcs}: 21 = not bit-identical / fell back, "
+                 f"22 = fell back while timed, 14 = a wait on a peer ran out)")
+        return {"used": False, "exit_codes": rcs} if rank == 0 else None
+    if rank != 0:
+        return None
+    try:
+        rec = json.loads(out.decode().strip().splitlines()[-1])
+    except Exception:       # noqa: BLE001
+        return {"used": False, "exit_codes": rcs, "why": "no JSON line from the child job"}
+    if not rec.get("config", {}).get("peer_loop_verified"):
+        return {"used": False, "exit_codes": rcs, "why": "the child job did not verify the loop"}
+    return {"used": None, "value": rec["value"], "ms_per_step": rec["ms_per_step"], "timing": rec.get("timing"),
+            "config": rec["config"], "roofline": rec.get("roofline")}
 
 
 def init_dist(n_gpus, comm_timeout=120.0):
@@ -705,6 +770,28 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
                 f"(owns {rw - 1} rows x 63 columns), " + ("three workgroups per CU (every slot of the chip)" if dense
                                                           else "one workgroup per CU"))
+    peer_verified = None
+    if peer_loop and getattr(args, "peer_verify", False):
+        # the cross-rank loop has to earn its place in THIS run, on THIS hardware: one whole evp(dt) through the
+        # per-subcycle message exchange and one through the one-launch loop from the same state, bit for bit
+        progress(f"{wl}: verifying the cross-rank loop against the per-subcycle exchange")
+        keys = ("uvel", "vvel") + synth.SIG_NAMES
+        res = []
+        with bounded(args.comm_timeout, "verification of the cross-rank loop"):
+            for use_loop in (False, True):
+                ctx.evp_set_option("resident", 2 if use_loop else 0)
+                sg = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in state.items()}
+                ctx.evp(DT, sg)
+                res.append(sg)
+            same = all(np.array_equal(res[0][k][:, 1:-1], res[1][k][:, 1:-1]) for k in keys)
+            moved = float(np.abs(res[1]["uvel"]).max()) > 0.0
+            ok = torch.tensor([int(same and moved and ctx.evp_get_info("resident_peer") == 1)], dtype=torch.int64)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        del res
+        if int(ok[0]) != 1:
+            progress(f"{wl}: the cross-rank loop did NOT reproduce the per-subcycle exchange on every rank (or fell back)")
+            raise SystemExit(21)
+        peer_verified = True
     ctx.evp_upload(state)
     with bounded(args.comm_timeout if world > 1 else 0, "first ghost exchange (evp_prepare: RCCL send / receive)"):
         ctx.evp_prepare(DT)
@@ -774,6 +861,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     value = nsub_total / t_evp
     # dominant kernel: the subcycle kernel; HIP-event time of the launches on the library's stream / launches
     resident = resident and bool(ctx.evp_get_info("resident"))    # 0 if a launch timed out and the library fell back
+    if peer_verified and not (resident and ctx.evp_get_info("resident_peer") == 1):
+        progress(f"{wl}: the cross-rank loop fell back during the timed steps")
+        raise SystemExit(22)
     if resident and ctx.evp_get_info("resident_waves") != rw:     # dense shape gave way to one workgroup per CU
         rw = ctx.evp_get_info("resident_waves")
         tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
@@ -853,6 +943,10 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                   f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
               "tile": tile, "metrics_recomputed_from_HTN_HTE": derive,
               "active_T_cells": nt_all, "active_U_cells": nu_all, "cell_subcycles_per_s": value * nt_all}
+    if peer_verified:
+        config["peer_loop_verified"] = ("one evp(dt) through the per-subcycle message exchange and one through the cross-rank "
+                                        "one-launch loop from the same state: u, v and the 12 stresses bit-identical on every "
+                                        "rank, no fall-back before or during the timed steps")
     return dict(dom=dom, grid=grid, state=state, ndte=ndte, value=value, t_evp=t_evp, config=config,
                 roofline=roofline, steps=steps, warmup=warmup, timing=timing)
 
@@ -939,6 +1033,18 @@ def main():
     m = measure_evp(ctx, args, args.workload, rank, world, dist, torch, have_torch_gpu, args.steps, args.warmup,
                     args.ramp_seconds)
     dom, state, ndte = m["dom"], m["state"], m["ndte"]
+
+    # ---- N > 1, gx1: the cross-rank one-launch loop, tried and verified in a second set of processes (see try_peer_loop)
+    peer_try = None
+    if (world > 1 and args.workload == "gx1" and not args.peer_loop and not args.no_peer_try
+            and os.environ.get("CICE4_AMD_BENCH_PEER_CHILD") is None):
+        try:
+            peer_try = try_peer_loop(args, rank, world, dist)
+        except BaseException as e:      # noqa: BLE001 -- nothing of the attempt may take the main measurement down
+            if isinstance(e, (KeyboardInterrupt,)):
+                raise
+            progress(f"gx1: the cross-rank-loop attempt is not used ({e!r})")
+            peer_try = {"used": False, "why": repr(e)} if rank == 0 else None
 
     # ---- the drop-in form evp(dt) with host arrays on both sides (PCIe-inclusive; never `value`)
     pcie = None
@@ -1073,6 +1179,19 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic", "timing": m["timing"], "config": m["config"], "roofline": m["roofline"],
         }
+        if peer_try:
+            # two decompositions were measured; `value` is the faster one, the other stays in the line
+            slabs = {"value": out["value"], "ms_per_step": out["ms_per_step"], "timing": out["timing"], "config": out["config"]}
+            if peer_try.get("value") and peer_try["value"] > out["value"]:
+                peer_try["used"] = True
+                out.update(value=peer_try["value"], ms_per_step=peer_try["ms_per_step"], timing=peer_try["timing"],
+                           config=peer_try["config"], roofline=peer_try["roofline"] or out["roofline"])
+                out["other_decomposition"] = dict(slabs, what="wide-halo slabs, RCCL exchange every `overlap` subcycles")
+            else:
+                if peer_try.get("value"):
+                    peer_try["used"] = False
+                out["other_decomposition"] = dict(peer_try, what="classic slabs, cross-rank one-launch loop with device-initiated "
+                                                                 "exchange (second set of rank processes)")
         if thermo:
             out["thermo"] = thermo
         if tenth:

@@ -114,3 +114,27 @@ def test_bench_two_ranks_from_the_plain_command(extra):
     assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["value"] > 0 and d["scaling"] == "strong"
     if extra:
         assert "cross-rank one-launch loop" in d["config"]["decomposition"], d["config"]
+
+
+@pytest.mark.timeout(900)
+def test_bench_tries_and_verifies_the_cross_rank_loop_by_itself():
+    """`python bench.py --gpus 2` at gx1: after the main measurement (wide-halo slabs) every rank starts a child process;
+    the children form their own job, run one evp(dt) through the per-subcycle exchange and one through the cross-rank
+    one-launch loop, compare bit for bit on every rank, and only then time the loop.  The line carries both decompositions;
+    `value` is the faster one."""
+    env = dict(os.environ, CICE4_AMD_BENCH_DEVICE="0", CICE4_AMD_BENCH_LINK="shm")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-tenth", "--no-cpu-baseline", "--no-thermo"], capture_output=True, text=True, timeout=800, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["value"] > 0
+    other = d["other_decomposition"]
+    used_loop = "peer_loop_verified" in d["config"]
+    assert used_loop or other.get("config", {}).get("peer_loop_verified"), (d["config"], other)
+    assert d["value"] >= other["value"] > 0
+    print("two rank processes on one GPU: value %.0f (%s), other decomposition %.0f" %
+          (d["value"], "cross-rank loop" if used_loop else "wide-halo slabs", other["value"]))
