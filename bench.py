@@ -243,6 +243,8 @@ def try_peer_loop(args, rank, world, dist):
         s.close()
     dist.broadcast_object_list(port, src=0)
     env = dict(os.environ, MASTER_PORT=str(port[0]), CICE4_AMD_BENCH_PEER_CHILD="1")
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        del env[k]      # (under torchrun the parents use the agent's store; the children bring their own on their own port)
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--peer-loop", "--peer-verify", "--no-peer-try",
            "--steps", str(args.steps), "--warmup", str(args.warmup), "--ramp-seconds", str(args.ramp_seconds), "--no-tenth",
            "--no-thermo", "--no-cpu-baseline", "--no-dropin-timing", "--comm-timeout", str(min(args.comm_timeout, 60.0))]
