@@ -329,6 +329,39 @@ __global__ __launch_bounds__(256) void k_fold_out(T* __restrict__ base, int nfie
   base[(size_t)k * stride + dst[e]] = (T)sgn * buf[(size_t)k * bstride + src[e]];
 }
 
+// The whole fold of a rank that holds every top-row block in ONE workgroup: buffer in LDS, fill -> gather -> symmetry ->
+// copy out with barriers in between -- one launch instead of four inside every subcycle of a tripole grid (each of the
+// four is a few hundred elements).  Same lists, same arithmetic, same order per element.
+template <class T>
+__global__ __launch_bounds__(1024) void k_fold_one(T* __restrict__ base, int nfields, size_t stride,
+                                                   const int32_t* __restrict__ lsrc, const int32_t* __restrict__ bidx,
+                                                   int nsrc, const int32_t* __restrict__ lo, const int32_t* __restrict__ hi,
+                                                   int npair, const int32_t* __restrict__ dst,
+                                                   const int32_t* __restrict__ src, int nout, int bstride, int sgn, T fill) {
+  extern __shared__ unsigned char fold_lds[];
+  T* buf = reinterpret_cast<T*>(fold_lds);
+  const int nt = blockDim.x, t0 = threadIdx.x;
+  for (int t = t0; t < bstride * nfields; t += nt) buf[t] = fill;
+  __syncthreads();
+  for (int t = t0; t < nsrc * nfields; t += nt) {
+    const int k = t / nsrc, e = t - k * nsrc;
+    buf[(size_t)k * bstride + bidx[e]] = base[(size_t)k * stride + lsrc[e]];
+  }
+  __syncthreads();
+  for (int t = t0; t < npair * nfields; t += nt) {
+    const int k = t / npair, e = t - k * npair;
+    T* b = buf + (size_t)k * bstride;
+    const T xavg = fold_avg(b[lo[e]], b[hi[e]], sgn);
+    b[lo[e]] = xavg;
+    b[hi[e]] = (T)sgn * xavg;
+  }
+  __syncthreads();
+  for (int t = t0; t < nout * nfields; t += nt) {
+    const int k = t / nout, e = t - k * nout;
+    base[(size_t)k * stride + dst[e]] = (T)sgn * buf[(size_t)k * bstride + src[e]];
+  }
+}
+
 }  // namespace
 
 // meta arrays live right behind the address lists (one allocation each)
@@ -571,6 +604,14 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
     const int sgn = kind == KIND_SCALAR ? 1 : -1;
     const int bstride = fold_rows_ * nxg_;
     T* buf = nullptr;
+    if (fold_ && !nfsend_ && !nfrecv_ && (size_t)bstride * nfields * sizeof(T) <= 64 * 1024) {
+      const int l = loc - 1;
+      hipLaunchKernelGGL(k_fold_one<T>, dim3(1), dim3(1024), (size_t)bstride * nfields * sizeof(T), stream_, base, nfields,
+                         stride, fold_lsrc_.p, fold_bidx_.p, nfold_src_, fold_lo_[l].p, fold_hi_[l].p, nfold_pair_[l],
+                         fold_dst_[l].p, fold_src_[l].p, nfold_out_[l], bstride, sgn, fill);
+      CICE_HIP(hipGetLastError());
+      return;
+    }
     if (fold_) {
       if (fold_cap_ < nfields) {
         if (fold_cap_) CICE_HIP(hipStreamSynchronize(stream_));

@@ -1,0 +1,25 @@
+"""EVP subcycle rate on a gx1-size grid by north-south boundary type: what the fold costs the loop.
+usage: python scripts/tripole_rate.py"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from cice4_amd import lib, synth
+nxg, nyg, NDTE, DT = 320, 384, 120, 3600.0
+for name, ns in (("open", 0), ("tripole", 3), ("tripoleT", 4)):
+    ctx = lib.Context()
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8), dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=8, cover="full")
+    ctx.evp_init(grid, ndte=NDTE)
+    ctx.evp_upload(s); ctx.evp_prepare(DT)
+    for _ in range(10):
+        ctx.evp_subcycles(1, NDTE)
+    ctx.sync(); t0 = time.perf_counter()
+    n = 50
+    for _ in range(n):
+        ctx.evp_subcycles(1, NDTE)
+    ctx.sync(); t = (time.perf_counter() - t0) / n
+    print("%-9s %8.2f us per subcycle  (%.0f subcycles/s; resident %d fused %d skew %d)" %
+          (name, 1e6 * t / NDTE, NDTE / t, ctx.evp_get_info("resident"), ctx.evp_get_info("fused"), ctx.evp_get_info("skew")), flush=True)
+    ctx.close()
