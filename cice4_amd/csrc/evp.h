@@ -107,7 +107,12 @@ class Evp {
   DevBuf<int32_t> res_deps;
   DevBuf<unsigned> res_prog;     // [tiles * 32] progress words, then the abort word
   DevBuf<double> res_xu[2];      // exchange copies of (u, v)
+  bool res_fold_on = true;       // one-block tripole domains run the one-launch loop with the fold inside
   void build_resident(int W);
+  void build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W);   // tripole north boundary inside the loop
+  DevBuf<int32_t> res_ftab, res_deps2;
+  DevBuf<unsigned> res_prog2;
+  DevBuf<double> res_xraw[2];
   void build_resident_peer(int W);
   void peer_alloc();
   struct Peer { double* xu[2] = {nullptr, nullptr}; unsigned* rprog = nullptr; unsigned n = 0; } peers[2];

@@ -1240,7 +1240,18 @@ struct ResArgs {
   unsigned* prp[2];      // [side]: where this rank's tiles publish their progress on the neighbour ([tile * RES_STRIDE])
   const unsigned* rprog; // progress words the neighbours' tiles publish here: deps <= -2 index it (-2 - dep)
   const int32_t* pub;    // [tiles] bit 0 / 1: cells of this tile are mirrored on the rank to the south / north
+  // FOLD: a tripole north boundary on a one-block, one-rank domain (serial/ice_boundary.F90:705-869) for the velocity
+  // (NE-corner location, vector kind).  The ghost cells the fold fills mirror, up to the sign, the final value of an owned
+  // cell: they ride on rslot / rfwd (entries: (negate << 30) | address in THIS block).  The owned cells of the top row are
+  // changed by the fold itself -- symmetric average with the partner across the pole, or a mirror image, or a sign
+  // flip -- from the RAW values of the subcycle, which the tiles of the top row hand to each other in a phase of their
+  // own (xraw, prog2, deps2) before anything is published.
+  const int32_t* ftab;   // [2 * cells] owned top-row cells: partner address (-1: none) and mode bits (F_*)
+  double* xraw[2];       // [parity] raw top-row velocities (u at 0, v at a.n)
+  unsigned* prog2;       // [tiles * RES_STRIDE] raw top row of subcycle k published = epoch0 + k + 1
+  const int32_t* deps2;  // [tiles][4] tiles that hold the partners of this tile's top-row cells, -1 padded
 };
+enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
 
 // agent-scope (sc1) access at a uniform base + 32-bit byte offset: SGPR base + VGPR offset addressing, no 64-bit
 // address arithmetic per access (the exchange copies of a one-block domain are far below 4 GB)
@@ -1264,18 +1275,19 @@ __device__ __forceinline__ void st_sys(double* base, unsigned off, double v) {
 // after subcycle k; the LAST subcycle is exchanged as well, so that every tile ends up holding the final velocity of
 // its halo cells and writes the ghost cells owned by other ranks into the result itself (no halo update afterwards);
 // everything another rank writes or reads is a system-scope access.
-template <int W, bool DAMP, bool PEER>
+template <int W, bool DAMP, bool PEER, bool FOLD = false>
 // (second bound: wavefronts per SIMD.  W = 4 runs three workgroups per CU in the dense shape -- one rank only --, W = 11,
 // 12 put three wavefronts of one workgroup on a SIMD: both need the 168-register budget whatever the compiler would
 // like to use)
-__global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
+__global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
+  static_assert(!(PEER && FOLD), "the fold is handled on one-rank domains");
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
   __shared__ double s_edge[W][4][TX];
   __shared__ double s_x[W][8][TX];
   __shared__ double s_m[W][10][TX];             // nine metrics + strength
   __shared__ int s_fd[W][3][TX];
-  __shared__ int s_rfd[PEER ? W : 1][4][TX];    // PEER: ghost cells on other ranks mirroring this lane's cell
+  __shared__ int s_rfd[PEER || FOLD ? W : 1][4][TX];   // PEER: ghost cells on other ranks mirroring this lane's cell; FOLD: ghost cells the fold fills
   __shared__ int s_pub[2];                      // PEER: this tile publishes to the south / north rank
   __shared__ int s_abort;
   const int nt = a.tiles_x * a.tiles_y;
@@ -1358,9 +1370,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     }
     s_fd[w][0][lx] = fd0; s_fd[w][1][lx] = fd1; s_fd[w][2][lx] = fd2;
     edge = uact && (lx == 0 || lx == TX - 2 || w == 0 || w == W - 2 || i == ihi || j == jhi || fd0 >= 0);
-    if (PEER) {
+    if (PEER || FOLD) {
       int rf[4] = {-1, -1, -1, -1};
-      if (uact) {
+      if (FOLD ? uown : uact) {
         const int rs = r.rslot[q];
         if (rs >= 0) {
 #pragma unroll
@@ -1371,6 +1383,15 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
       for (int c = 0; c < 4; ++c) s_rfd[w][c][lx] = rf[c];
       edge = edge || rf[0] >= 0;
     }
+  }
+  // FOLD: the owned cells of the top row (with or without ice: the average with an ice-covered partner is not zero)
+  const bool topc = FOLD && uown && j == jhi;
+  const bool toptile = FOLD && j0 + (W - 2) >= jhi;          // this tile owns cells of the top row (uniform)
+  int fpad = -1, fmode = 0;
+  if (topc) {
+    fpad = r.ftab[2 * q];
+    fmode = r.ftab[2 * q + 1];
+    edge = true;
   }
   // PEER: a ghost cell of this block whose source lives on another rank: some tile has to write its final value
   const bool rghost = PEER && ok && !uown && r.rslot[q] == -2;
@@ -1435,6 +1456,66 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
       un = ro.u;
       vn = ro.v;
     }
+    if (FOLD && toptile) {
+      // (C') the fold changes the owned cells of the top row: the tiles of that row hand each other the raw velocities of
+      // this subcycle first (the halo update after stepu, ice_dyn_evp.F90:397-402, on the degenerate row)
+      double* xr = r.xraw[k & 1];
+      if (topc) {
+        st_agent(xr, qb, un);
+        st_agent(xr + a.n, qb, vn);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const unsigned target2 = r.epoch0 + (unsigned)k + 1u;
+      if (threadIdx.x == 0)
+        __hip_atomic_store(r.prog2 + (size_t)tile * RES_STRIDE, target2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (w == 0) {
+        const int dep = lx < 4 ? r.deps2[tile * 4 + lx] : -1;
+        bool have = dep < 0;
+        int bad = 0;
+        const long long t0 = wall_clock64();
+        while (true) {
+          if (!have)
+            have = (int)(__hip_atomic_load(r.prog2 + (size_t)dep * RES_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target2) >= 0;
+          if (__all(have)) break;
+          const unsigned long long miss = __ballot(!have);
+          if (lx == 0) {
+            bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!bad && wall_clock64() - t0 > r.spin_ticks) {
+              if (__hip_atomic_exchange(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                r.abort_flag[1] = 3u; r.abort_flag[2] = (unsigned)tile; r.abort_flag[3] = (unsigned)k;   // wait 3 = (C')
+                r.abort_flag[4] = (unsigned)miss; r.abort_flag[5] = 0u; r.abort_flag[6] = target2;
+              }
+              bad = 1;
+            }
+          }
+          bad = __shfl(bad, 0);
+          if (bad) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        if (lx == 0) s_abort = bad;
+      }
+      __syncthreads();
+      if (s_abort) return;
+      if (topc && fmode) {
+        if (fmode & F_SELF) {                   // unpaired point of the degenerate row: isign * itself (:861-863)
+          un = -un;
+          vn = -vn;
+        } else {
+          const double pu = ld_agent(xr, (unsigned)fpad * 8u), pv = ld_agent(xr + a.n, (unsigned)fpad * 8u);
+          if (fmode & F_MIRROR) {               // the image of the partner
+            un = (fmode & F_NEG) ? -pu : pu;
+            vn = (fmode & F_NEG) ? -pv : pv;
+          } else {                              // xavg = 0.5*(x1 + isign*x2), x1 = the pair's first member (:792-799)
+            const double u1 = (fmode & F_LO) ? un : pu, u2 = (fmode & F_LO) ? pu : un;
+            const double v1 = (fmode & F_LO) ? vn : pv, v2 = (fmode & F_LO) ? pv : vn;
+            const double xu_ = 0.5 * (u1 + (-u2)), xv_ = 0.5 * (v1 + (-v2));
+            un = (fmode & F_NEG) ? -xu_ : xu_;
+            vn = (fmode & F_NEG) ? -xv_ : xv_;
+          }
+        }
+      }
+    }
     if (!PEER && k + 1 == r.nsub) break;
     s_uv[w][0][lx] = un;     // read after (E); the reads of the previous values lie before (C)
     s_uv[w][1][lx] = vn;
@@ -1497,6 +1578,18 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
             double* pu = r.pxu[side][k & 1];
             st_sys(pu, ro, un);
             st_sys(pu + r.pn[side], ro, vn);
+          }
+        }
+      }
+      if (FOLD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int rf = s_rfd[w][c][lx];
+          if (rf >= 0) {                          // a ghost cell the fold fills: this cell's value, negated or not
+            const bool neg = (rf >> 30) & 1;
+            const unsigned ro = (unsigned)(rf & 0x3fffffff) * 8u;
+            st_agent(xu, ro, neg ? -un : un);
+            st_agent(xv, ro, neg ? -vn : vn);
           }
         }
       }
@@ -1589,6 +1682,19 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
       if (r.rslot[q - nx - 1] == -2) {
         a.u_out[q - nx - 1] = uswh;
         a.v_out[q - nx - 1] = vswh;
+      }
+    }
+  }
+  if (FOLD && (uact || topc)) {   // the ghost cells the fold fills, and top-row cells without ice (changed by the fold all the same)
+    a.u_out[q] = un;
+    a.v_out[q] = vn;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int rf = s_rfd[w][c][lx];
+      if (rf >= 0) {
+        const bool neg = (rf >> 30) & 1;
+        a.u_out[rf & 0x3fffffff] = neg ? -un : un;
+        a.v_out[rf & 0x3fffffff] = neg ? -vn : vn;
       }
     }
   }
@@ -1985,6 +2091,8 @@ void Evp::set_option(const char* key, int value) {
       res_level = 0;
       res_retry_in = 0;
     }
+  } else if (!std::strcmp(key, "resident_fold")) {          // a tripole north boundary inside the one-launch loop
+    res_fold_on = value != 0;
   } else if (!std::strcmp(key, "resident_retry_steps")) {   // evp(dt) calls until a time-out is forgiven, 0 = never
     CICE_REQUIRE(value >= 0, "resident_retry_steps must be >= 0");
     res_retry_steps = value;
@@ -2638,7 +2746,8 @@ bool Evp::can_reside() const {
   static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT"); return e && e[0] == '0'; }();
   if (!resident_on || resident_failed || env_off) return false;
   if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0) return false;
-  if (halo.has_refresh() || halo.has_fold() || halo.multi_rank()) return false;
+  if (halo.has_refresh() || halo.multi_rank()) return false;
+  if (halo.has_fold() && !res_fold_on) return false;   // the fold inside the loop: option "resident_fold"
   return resident_waves() > 0;
 }
 
@@ -2682,11 +2791,14 @@ int Evp::resident_waves() const {
     }
     return t;
   };
-  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && !halo.multi_rank();
-  if (res_w_opt) return (tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok)) && !(res_w_opt == 12 && halo.multi_rank()) ? res_w_opt : 0;
+  // (the cross-rank and the fold variants carry one more table in LDS and a few more registers: no 12-wavefront
+  //  workgroups, no three workgroups per CU)
+  const bool plain = !halo.multi_rank() && !halo.has_fold();
+  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && plain;
+  if (res_w_opt) return (tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok)) && !(res_w_opt == 12 && !plain) ? res_w_opt : 0;
   int single = 0;
   for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
-    if (tiles(w) <= ncu && !(w == 12 && halo.multi_rank())) {
+    if (tiles(w) <= ncu && !(w == 12 && !plain)) {
       single = w;
       break;
     }
@@ -2823,6 +2935,8 @@ void Evp::build_resident_peer(int W) {
     if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
     return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
   };
+  const bool folded = halo.has_fold();
+  if (folded) build_resident_fold(src_of, tiles_x, W);   // ghost cells the fold fills now have a source as well
   std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
   for (int t = 0; t < nt; ++t) {
     const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
@@ -2871,6 +2985,142 @@ void Evp::build_resident_peer(int W) {
 }
 
 // producer tiles of every tile's halo: the cells it re-reads each subcycle, traced through the on-rank ghost copies
+// The tripole fold (serial/ice_boundary.F90:705-869) inside the one-launch loop, for u and v (NE corner, vector).  From
+// the Domain's own fold lists -- buffer fill, symmetric pairs, copy-out with the location's offsets -- every cell the
+// fold writes gets its expression in the raw velocities of the subcycle: s * raw(A), or s * 0.5 * (raw(A) - raw(B)).
+//  * owned cells of the top row: the kernel evaluates the expression itself (ftab: partner + mode), the raw values of
+//    the partners come through xraw / prog2 from the tiles in deps2;
+//  * ghost cells: the same expression as some owned cell's final value, up to the sign -- that cell forwards its value
+//    to the ghost position (rslot / rfwd, bit 30 = negate) and becomes the ghost cell's source for the dependency lists.
+// Anything else (an expression no owned cell carries, more than four images of a cell) is not a domain for this loop.
+void Evp::build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W) {
+  const int nx = dom.nx_block, ny = dom.ny_block;
+  const Block& bl = dom.all[dom.local[0]];
+  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
+  const size_t np = (size_t)nx * ny;
+  const int l = LOC_NECORNER - 1, sgn = -1;
+  const size_t nbuf = (size_t)dom.fold_rows() * dom.nxg;
+  std::vector<int32_t> baddr(nbuf, -1), plo(nbuf, -1), phi(nbuf, -1);
+  for (size_t e = 0; e < dom.fold_lsrc.size(); ++e) baddr[dom.fold_bidx[e]] = dom.fold_lsrc[e];
+  for (size_t e = 0; e < dom.fold_lo[l].size(); ++e) {
+    const int32_t lo = dom.fold_lo[l][e], hi = dom.fold_hi[l][e];
+    plo[lo] = lo; phi[lo] = hi; plo[hi] = lo; phi[hi] = hi;
+  }
+  auto owned = [&](int32_t q) {
+    const int i = q % nx + 1, j = q / nx + 1;
+    return i >= ilo && i <= ihi && j >= jlo && j <= jhi;
+  };
+  struct Ex { int pair; int32_t A, B; int s; };   // pair: s * 0.5 * (raw(A) - raw(B)), else s * raw(A)
+  auto same = [](const Ex& x, const Ex& y) { return x.pair == y.pair && x.A == y.A && (!x.pair || x.B == y.B); };
+  const Domain::FoldOut& fo = dom.fold_out[l];
+  std::vector<Ex> ex(fo.dst.size());
+  for (size_t e = 0; e < fo.dst.size(); ++e) {
+    const int32_t b = fo.src[e];
+    CICE_REQUIRE(b >= 0 && (size_t)b < nbuf && baddr[b] >= 0, "resident EVP loop: the fold reads a buffer cell nobody fills");
+    if (plo[b] >= 0) {
+      CICE_REQUIRE(baddr[plo[b]] >= 0 && baddr[phi[b]] >= 0, "resident EVP loop: fold pair outside the buffer");
+      ex[e] = Ex{1, baddr[plo[b]], baddr[phi[b]], b == plo[b] ? sgn : 1};   // sgn * x, or sgn * (sgn * x)
+    } else {
+      ex[e] = Ex{0, baddr[b], -1, sgn};
+    }
+  }
+  // owned cells the fold writes: all in the top row; every other owned cell keeps its raw value
+  std::vector<int32_t> ftab(2 * np, 0);
+  for (size_t q = 0; q < np; ++q) ftab[2 * q] = -1;
+  std::vector<int> ex_of(np, -1);
+  for (size_t e = 0; e < fo.dst.size(); ++e) {
+    const int32_t d = fo.dst[e];
+    if (!owned(d)) continue;
+    CICE_REQUIRE(d / nx + 1 == jhi, "resident EVP loop: the fold writes an owned cell below the top row");
+    CICE_REQUIRE(ex_of[d] < 0, "resident EVP loop: the fold writes a cell twice");
+    ex_of[d] = (int)e;
+    const Ex& x = ex[e];
+    CICE_REQUIRE(owned(x.A) && (!x.pair || owned(x.B)), "resident EVP loop: the fold reads a cell this block does not own");
+    int mode;
+    int32_t partner = -1;
+    if (x.pair) {
+      CICE_REQUIRE(d == x.A || d == x.B, "resident EVP loop: a top-row cell averaged from two other cells");
+      mode = (d == x.A ? F_LO : F_HI) | (x.s < 0 ? F_NEG : 0);
+      partner = d == x.A ? x.B : x.A;
+    } else if (x.A == d) {
+      CICE_REQUIRE(x.s < 0, "resident EVP loop: identity in the fold");
+      mode = F_SELF;
+    } else {
+      mode = F_MIRROR | (x.s < 0 ? F_NEG : 0);
+      partner = x.A;
+    }
+    CICE_REQUIRE(partner < 0 || (int)(partner / nx) + 1 == jhi, "resident EVP loop: fold partner below the top row");
+    ftab[2 * d] = partner;
+    ftab[2 * d + 1] = mode;
+  }
+  // ghost cells: find the owned cell whose final value is the same expression
+  std::vector<std::vector<int32_t>> images(np);   // per owned cell: (neg << 30) | ghost address
+  for (size_t e = 0; e < fo.dst.size(); ++e) {
+    const int32_t g = fo.dst[e];
+    if (owned(g)) continue;
+    const Ex& x = ex[e];
+    int32_t src = -1;
+    int rel = 1;
+    if (!x.pair && owned(x.A) && ex_of[x.A] < 0) {     // an owned cell the fold leaves alone: final = raw
+      src = x.A;
+      rel = x.s;
+    } else {                                             // a cell of the top row with the same expression
+      for (int32_t c : {x.A, x.pair ? x.B : x.A}) {
+        if (c < 0 || !owned(c) || ex_of[c] < 0) continue;
+        // candidates: the members themselves and, for a mirror image, the partner that mirrors this member
+        for (int32_t cand : {c, ftab[2 * c]}) {
+          if (cand < 0 || ex_of[cand] < 0) continue;
+          const Ex& y = ex[ex_of[cand]];
+          if (same(x, y)) { src = cand; rel = x.s * y.s; }
+        }
+      }
+    }
+    CICE_REQUIRE(src >= 0, "resident EVP loop: a ghost cell of the fold mirrors no owned cell's value");
+    // a regular copy into the same ghost cell (east-west wrap of the top row) is overwritten by the fold in the reference;
+    // here both producers store: they have to store the same value
+    if (src_of[g] >= 0 && src_of[g] != src) {
+      const int32_t o = src_of[g];
+      bool eq = false;
+      if (ex_of[o] >= 0) eq = same(x, ex[ex_of[o]]) && x.s == ex[ex_of[o]].s;
+      else eq = !x.pair && x.A == o && x.s > 0;
+      CICE_REQUIRE(eq, "resident EVP loop: wrap and fold disagree on a ghost cell");
+      continue;                                         // the wrap's producer already forwards exactly this value
+    }
+    src_of[g] = src;
+    images[src].push_back((rel < 0 ? (1 << 30) : 0) | g);
+  }
+  std::vector<int32_t> rslot(np, -1), rfwd;
+  for (size_t q = 0; q < np; ++q) {
+    if (images[q].empty()) continue;
+    CICE_REQUIRE(images[q].size() <= 4, "resident EVP loop: a cell with more than four images across the fold");
+    rslot[q] = (int32_t)(rfwd.size() / 4);
+    for (int c = 0; c < 4; ++c) rfwd.push_back(c < (int)images[q].size() ? images[q][c] : -1);
+  }
+  if (rfwd.empty()) rfwd.assign(4, -1);
+  // tiles holding the partners of a tile's top-row cells
+  const int tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1), nt = tiles_x * tiles_y;
+  auto tile_of = [&](int32_t q) { return ((int)(q / nx) + 1 - jlo) / (W - 1) * tiles_x + ((int)(q % nx) + 1 - ilo) / (TX - 1); };
+  std::vector<int32_t> deps2((size_t)nt * 4, -1);
+  for (int i = ilo; i <= ihi; ++i) {
+    const int32_t d = (int32_t)((jhi - 1) * nx + (i - 1));
+    if (ftab[2 * d] < 0) continue;
+    const int t = tile_of(d), o = tile_of(ftab[2 * d]);
+    if (o == t) continue;
+    int k = 0;
+    while (k < 4 && deps2[(size_t)t * 4 + k] >= 0 && deps2[(size_t)t * 4 + k] != o) ++k;
+    CICE_REQUIRE(k < 4, "resident EVP loop: a top-row tile with partners in more than four tiles");
+    deps2[(size_t)t * 4 + k] = o;
+  }
+  res_ftab.alloc(ftab.size()); res_ftab.upload(ftab.data(), stream);
+  res_rslot.alloc(rslot.size()); res_rslot.upload(rslot.data(), stream);
+  res_rfwd.alloc(rfwd.size()); res_rfwd.upload(rfwd.data(), stream);
+  res_deps2.alloc(deps2.size()); res_deps2.upload(deps2.data(), stream);
+  res_prog2.alloc((size_t)nt * RES_STRIDE); res_prog2.zero(stream);
+  for (int k = 0; k < 2; ++k)
+    if (res_xraw[k].n < 2 * n) { res_xraw[k].alloc(2 * n); res_xraw[k].zero(stream); }
+  CICE_HIP(hipStreamSynchronize(stream));   // the host vectors go out of scope
+}
+
 void Evp::build_resident(int W) {
   const int nx = dom.nx_block, ny = dom.ny_block;
   const Block& bl = dom.all[dom.local[0]];
@@ -2929,6 +3179,13 @@ static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream
       else hipLaunchKernelGGL((k_evp_resident<W, false, true>), g, dim3(64 * W), 0, s, r);
     } else {
       throw Error{CICE_EINVAL, "resident EVP loop across ranks: at most 11 wavefronts per workgroup"};
+    }
+  } else if (r.ftab) {
+    if constexpr (W <= 11) {   // (as above)
+      if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false, true>), g, dim3(64 * W), 0, s, r);
+      else hipLaunchKernelGGL((k_evp_resident<W, false, false, true>), g, dim3(64 * W), 0, s, r);
+    } else {
+      throw Error{CICE_EINVAL, "resident EVP loop with a tripole fold: at most 11 wavefronts per workgroup"};
     }
   } else {
     if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false>), g, dim3(64 * W), 0, s, r);
@@ -2997,6 +3254,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
   if (res_epoch > 0x70000000u) {
     CICE_REQUIRE(!peer, "resident EVP loop across ranks: progress epoch exhausted (re-create the context)");
     res_prog.zero(stream);
+    if (res_prog2.p) res_prog2.zero(stream);
     res_epoch = 0;
   }
   ResArgs r{};
@@ -3012,6 +3270,15 @@ bool Evp::run_resident(int ksub0, int nsub) {
   r.xu[0] = res_xu[0].p;
   r.xu[1] = res_xu[1].p;
   r.spin_ticks = (long long)res_spin_us * 100;   // wall_clock64() runs at 100 MHz
+  if (!peer && halo.has_fold()) {
+    r.rslot = res_rslot.p;
+    r.rfwd = res_rfwd.p;
+    r.ftab = res_ftab.p;
+    r.xraw[0] = res_xraw[0].p;
+    r.xraw[1] = res_xraw[1].p;
+    r.prog2 = res_prog2.p;
+    r.deps2 = res_deps2.p;
+  }
   if (peer) {
     r.rslot = res_rslot.p;
     r.rfwd = res_rfwd.p;
@@ -3106,6 +3373,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
     // ranks agreed on the time-out, so that they also agree on the retry)
     res_retry_in = (!peer || res_peer_agree) ? res_retry_steps : 0;
     res_prog.zero(stream);
+    if (res_prog2.p) res_prog2.zero(stream);
     if (!peer) res_epoch = 0;   // (across ranks the neighbours hold words about us: the epoch only ever grows)
     return false;
   }

@@ -752,6 +752,38 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
         assert np.array_equal(b[k], ref[k]), ("ranges", k)
 
 
+@pytest.mark.parametrize("nxg,nyg", [(96, 70), (320, 384), (130, 27), (64, 40), (20, 33)])
+@pytest.mark.parametrize("ns", [3, 4], ids=["tripole", "tripoleT"])
+def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
+    """A tripole north boundary inside the one-launch loop: the tiles of the top row hand each other the raw velocities of
+    the subcycle, form the symmetric averages / mirror images of the degenerate row themselves, and forward the values of
+    the ghost row across the pole -- against one launch per subcycle followed by the halo update with its fold (which
+    tests/test_boundary.py pins to the reference's ice_HaloUpdate and evp): bit for bit.  Both folds, every workgroup
+    height that fits, damping, short and long loops, patchy ice (top-row cells without ice take their partner's average)."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    for ndte, damping in ((NDTE, False), (7, True), (2, False)):
+        ref, _ = _evp_with(ctx, grid, s, ndte, damping, resident=0, resident_fold=0)
+        assert np.abs(ref["uvel"]).max() > 0.01
+        tried = 0
+        for W in (0, 4, 6, 8, 11):
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+            ctx.evp_set_option("resident_fold", 1); ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
+            if not ctx.evp_get_info("resident"):
+                continue                      # this height does not give every tile a CU
+            ctx.evp(DT, sg)
+            assert ctx.evp_get_info("resident") == 1, ("fell back", W)
+            for k in keys:
+                assert np.array_equal(sg[k], ref[k]), (ns, ndte, damping, W, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+            tried += 1
+        assert tried >= 1
+    ctx.evp_set_option("resident_waves", 0)
+
+
 def test_resident_loop_is_repeatable(ctx):
     """300 one-launch loops (36,000 subcycles, 768 tiles, ~90 exchanged velocities per tile and subcycle) from the same
     state: every call must return the bits of the first one, which are those of the launch-per-pair loop.  A hand-off
