@@ -784,6 +784,19 @@ def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
     ctx.evp_set_option("resident_waves", 0)
 
 
+@pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
+def test_tripole_fold_inside_the_loop_against_the_compiled_reference(ns):
+    """the same against `call evp(dt)` of the reference itself on a one-block 100 x 116 domain (own process)"""
+    import os, subprocess, sys
+    from oracle import refapi
+    if not refapi.available("gx3"):
+        pytest.skip("oracle/_ref/libcice_ref_gx3.so not built")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "tripole_evp_case.py"), ns], capture_output=True,
+                       text=True, timeout=600)
+    assert p.returncode == 0 and "TRIPOLE-EVP-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
 def test_resident_loop_is_repeatable(ctx):
     """300 one-launch loops (36,000 subcycles, 768 tiles, ~90 exchanged velocities per tile and subcycle) from the same
     state: every call must return the bits of the first one, which are those of the launch-per-pair loop.  A hand-off
