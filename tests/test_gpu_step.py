@@ -159,6 +159,38 @@ def test_whole_model_with_upwind_advection():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
+def test_whole_model_with_a_tripole_north_boundary(ns):
+    """namelist ns_boundary_type = 'tripole' / 'tripoleT' on the gx3 grid: every ice_HaloUpdate of the model (grid set-up
+    with extrapolation, bound_state, the scalar and vector fields of the dynamics and the transport at their four
+    locations) goes through the fold of the drop-in boundary module, evp(dt) runs the one-launch loop with the fold
+    inside.  25 steps, pure reference and drop-in modules on this host, all records of the restart dump."""
+    exe = {k: os.path.join(ROOT, "oracle", "_ref", "cice_%s_gx3" % k) for k in ("ref", "dropin")}
+    for e in exe.values():
+        if not os.path.exists(e):
+            pytest.skip("%s not built" % e)
+    dirs = {k: tempfile.mkdtemp(prefix="cice_tri_%s_" % k) for k in ("ref", "dropin")}
+    try:
+        rec = {}
+        for kind in ("ref", "dropin"):
+            driver.write_rundir(dirs[kind], npt=25, overrides={"domain_nml": dict(ns_boundary_type=ns)})
+            log = driver.run(exe[kind], dirs[kind])
+            rec[kind] = driver.read_restart(driver.restart_path(dirs[kind]), 100, 116)
+        assert "EVP dynamics on the GPU" in log
+        assert rec["ref"][0] == rec["dropin"][0]
+        for k in rec["ref"][1]:
+            a, g = rec["dropin"][1][k], rec["ref"][1][k]
+            if TOL_EXP == 0.0:
+                assert np.array_equal(a, g), (ns, k, np.abs(a - g).max())
+            else:
+                assert np.abs(a - g).max() <= TOL_EXP * max(np.abs(g).max(), 1e-300), k
+        assert np.abs(rec["ref"][1]["uvel"]).max() > 0.05
+    finally:
+        for d in dirs.values():
+            shutil.rmtree(d, ignore_errors=True)
+
+
+@pytest.mark.gpu
 def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
     """The whole model on the real gx3 grid cut into 10 x 12 blocks of 10 x 10 cells (max_blocks = 120), the four
     all-land blocks eliminated by the reference's own create_distribution: multi-block EVP (per-subcycle halo updates
