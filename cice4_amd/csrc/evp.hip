@@ -218,6 +218,7 @@ __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu,
 struct SubArgs {
   EvpScalars sc;
   int nx, ny, tiles_x, tiles_y, nblocks;
+  int carry_top;   // tripole fold: the fold changes top-row cells WITHOUT ice too; the kernel carries their value into the new copy
   int ew_cyclic;  // k_subcycle2: columns of a block form a ring
   size_t n;  // nblocks*ny*nx
   // no two of these arrays overlap (inputs and outputs of the double-buffered fields are
@@ -397,6 +398,16 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
   const bool u_lane = lx < TX - 1 && i <= ihi;
   const int jfirst = j0 + w * R;
 
+  // A tripole fold (applied by the halo update after this kernel) changes the owned cells of the top row whether they
+  // carry ice or not, and u, v are double-buffered: what the fold of the previous subcycle left in a cell this kernel does
+  // not write has to be carried over, or the next fold averages a stale value (the reference has one array).
+  if (a.carry_top && w == 0 && u_lane && jhi >= j0 && jhi <= j0 + TROWS - 2) {
+    const size_t qt = base + (size_t)(jhi - 1) * nx + (i - 1);
+    if (!a.iceumask[qt]) {
+      a.u_out[qt] = a.u_in[qt];
+      a.v_out[qt] = a.v_in[qt];
+    }
+  }
   // carried row below the first T-row of this wavefront
   double us = c0, vs = c0, usw = c0, vsw = c0, hn_s = c0;
   {
@@ -2456,6 +2467,7 @@ SubArgs Evp::make_args() const {
   a.ew_cyclic = dom.ew == BND_CYCLIC ? 1 : 0;
   const bool fwd = halo.fwd_ok();
   a.ring_slot = fwd ? halo.d_ring_slot() : nullptr; a.fwd = halo.d_fwd();
+  a.carry_top = halo.has_fold() ? 1 : 0;
   a.blk = blk.p; a.icetmask = icetmask.p; a.iceumask = iceumask.p;
   a.u_in = uv[cur].p; a.v_in = uv[cur].p + n; a.u_out = uv[1 - cur].p; a.v_out = uv[1 - cur].p + n;
   a.sig_in = sig[cur].p; a.sig_out = sig[1 - cur].p;
@@ -2935,8 +2947,6 @@ void Evp::build_resident_peer(int W) {
     if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
     return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
   };
-  const bool folded = halo.has_fold();
-  if (folded) build_resident_fold(src_of, tiles_x, W);   // ghost cells the fold fills now have a source as well
   std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
   for (int t = 0; t < nt; ++t) {
     const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
@@ -3137,6 +3147,7 @@ void Evp::build_resident(int W) {
     if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
     return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
   };
+  if (halo.has_fold()) build_resident_fold(src_of, tiles_x, W);   // ghost cells the fold fills now have a source as well
   std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
   for (int t = 0; t < nt; ++t) {
     const int tyi = t / tiles_x, txi = t - tyi * tiles_x;

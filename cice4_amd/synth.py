@@ -93,10 +93,12 @@ def _ext(g, ew_cyclic=True):
     return np.concatenate([a[:1], a[:1], a, a[-1:], a[-1:]], axis=0)
 
 
-def block_fields(gg, dom, ew_cyclic=True):
+def block_fields(gg, dom, ew_cyclic=True, north_ocean=False):
     """Per-block grid arrays (nblocks, ny_block, nx_block) for the blocks described by
     `dom` (dict with nx, ny, nblocks, ilo, ihi, jlo, jhi, i0, j0: 0-based global index of
-    local cell ilo / jlo).  Metrics follow init_grid2 (ice_grid.F90:332-363)."""
+    local cell ilo / jlo).  Metrics follow init_grid2 (ice_grid.F90:332-363).
+    north_ocean: the cells beyond the northern edge are ocean where the top row is (a tripole grid continues across
+    the fold), so that the U points ON the edge are ocean too; otherwise land surrounds the domain north and south."""
     nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
     E = {k: _ext(gg[k], ew_cyclic) for k in ("HTN", "HTE", "ULAT", "hm")}
     # dxu, dxt, dyu, dyt on the extended global grid (ice_grid.F90:1139-1289)
@@ -110,7 +112,8 @@ def block_fields(gg, dom, ew_cyclic=True):
         hm[:, :2] = 0.0
         hm[:, -2:] = 0.0
     hm[:2, :] = 0.0
-    hm[-2:, :] = 0.0
+    if not north_ocean:
+        hm[-2:, :] = 0.0
     uvm = np.minimum(np.minimum(hm, np.roll(hm, -1, axis=1)),
                      np.minimum(np.roll(hm, -1, axis=0), np.roll(np.roll(hm, -1, axis=0), -1, axis=1)))
     G = dict(HTN=HTN, HTE=HTE, dxu=dxu, dxt=dxt, dyu=dyu, dyt=dyt, ULAT=E["ULAT"], hm=hm, uvm=uvm)

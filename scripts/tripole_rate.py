@@ -9,7 +9,7 @@ nxg, nyg, NDTE, DT = 320, 384, 120, 3600.0
 for name, ns in (("open", 0), ("tripole", 3), ("tripoleT", 4)):
     ctx = lib.Context()
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
-    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8), dom, ew_cyclic=True)
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8, land_rows=0), dom, ew_cyclic=True, north_ocean=(ns != 0))
     s = synth.evp_state(grid, dom, seed=8, cover="full")
     ctx.evp_init(grid, ndte=NDTE)
     ctx.evp_upload(s); ctx.evp_prepare(DT)

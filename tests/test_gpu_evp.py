@@ -761,13 +761,19 @@ def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
     tests/test_boundary.py pins to the reference's ice_HaloUpdate and evp): bit for bit.  Both folds, every workgroup
     height that fits, damping, short and long loops, patchy ice (top-row cells without ice take their partner's average)."""
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
-    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg, land_rows=0)   # ocean up to the fold
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True)
     s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
     keys = EVP_OUT_FIELDS + ("iceumask",)
+    # the fold has to matter in this case: the same loop with an open north boundary gives other velocities in the top rows
+    domo = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    opn, _ = _evp_with(ctx, grid, s, NDTE, False, resident=0)
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
     for ndte, damping in ((NDTE, False), (7, True), (2, False)):
         ref, _ = _evp_with(ctx, grid, s, ndte, damping, resident=0, resident_fold=0)
-        assert np.abs(ref["uvel"]).max() > 0.01
+        assert np.abs(ref["uvel"]).max() > 0.01 and np.abs(ref["uvel"][0, -3:]).max() > 1e-4
+        if ndte == NDTE and not damping:
+            assert not np.array_equal(ref["uvel"][0, -4:-1], opn["uvel"][0, -4:-1]) and np.abs(ref["uvel"][0, -2]).max() > 1e-4
         tried = 0
         for W in (0, 4, 6, 8, 11):
             sg = {k: v.copy() for k, v in s.items()}
@@ -782,6 +788,19 @@ def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
             tried += 1
         assert tried >= 1
     ctx.evp_set_option("resident_waves", 0)
+    # the same grid cut into blocks (fold after every subcycle through the halo update, ghost rows between blocks):
+    # the owned cells must come out as on one block
+    if nxg % 2 == 0 and nyg % 2 == 0 and nyg // 2 >= 3:
+        ref, _ = _evp_with(ctx, grid, s, NDTE, False, resident=0, resident_fold=0)
+        dom2 = ctx.domain_create(nxg, nyg, nxg // 2, nyg // 2, ew=1, ns=ns)
+        grid2 = synth.block_fields(gg, dom2, ew_cyclic=True, north_ocean=True)
+        s2 = synth.evp_state(grid2, dom2, seed=nxg, cover="patchy")
+        got, _ = _evp_with(ctx, grid2, s2, NDTE, False)
+        for k in ("uvel", "vvel", "stressp_1", "stress12_4", "strintx"):
+            for b in range(dom2["nblocks"]):
+                i0, j0 = int(dom2["i0"][b]), int(dom2["j0"][b])
+                ni, nj = int(dom2["ihi"][b] - dom2["ilo"][b] + 1), int(dom2["jhi"][b] - dom2["jlo"][b] + 1)
+                assert np.array_equal(got[k][b, 1:1 + nj, 1:1 + ni], ref[k][0, 1 + j0:1 + j0 + nj, 1 + i0:1 + i0 + ni]), (ns, k, b)
 
 
 @pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
