@@ -85,22 +85,25 @@ def global_grid(nxg, nyg, perturb=0.0, seed=20261003, dx=30.0e3, dy=30.0e3, land
     return dict(HTN=HTN, HTE=HTE, ULAT=ULAT, hm=hm, nxg=nxg, nyg=nyg)
 
 
-def _ext(g, ew_cyclic=True):
+def _ext(g, ew_cyclic=True, ns_cyclic=False):
     """Extend a global (nyg,nxg) array by 2 cells on each side: wrap (cyclic) or
-    replicate in i, replicate in j."""
+    replicate in i, and in j."""
     a = np.concatenate([g[:, -2:], g, g[:, :2]], axis=1) if ew_cyclic else \
         np.concatenate([g[:, :1], g[:, :1], g, g[:, -1:], g[:, -1:]], axis=1)
+    if ns_cyclic:
+        return np.concatenate([a[-2:], a, a[:2]], axis=0)
     return np.concatenate([a[:1], a[:1], a, a[-1:], a[-1:]], axis=0)
 
 
-def block_fields(gg, dom, ew_cyclic=True, north_ocean=False):
+def block_fields(gg, dom, ew_cyclic=True, north_ocean=False, ns_cyclic=False):
     """Per-block grid arrays (nblocks, ny_block, nx_block) for the blocks described by
     `dom` (dict with nx, ny, nblocks, ilo, ihi, jlo, jhi, i0, j0: 0-based global index of
     local cell ilo / jlo).  Metrics follow init_grid2 (ice_grid.F90:332-363).
     north_ocean: the cells beyond the northern edge are ocean where the top row is (a tripole grid continues across
-    the fold), so that the U points ON the edge are ocean too; otherwise land surrounds the domain north and south."""
+    the fold), so that the U points ON the edge are ocean too; otherwise land surrounds the domain north and south.
+    ns_cyclic: the grid wraps north-south as well (nothing closes the domain there)."""
     nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
-    E = {k: _ext(gg[k], ew_cyclic) for k in ("HTN", "HTE", "ULAT", "hm")}
+    E = {k: _ext(gg[k], ew_cyclic, ns_cyclic) for k in ("HTN", "HTE", "ULAT", "hm")}
     # dxu, dxt, dyu, dyt on the extended global grid (ice_grid.F90:1139-1289)
     HTN, HTE = E["HTN"], E["HTE"]
     dxu = 0.5 * (HTN + np.roll(HTN, -1, axis=1))
@@ -111,9 +114,10 @@ def block_fields(gg, dom, ew_cyclic=True, north_ocean=False):
     if not ew_cyclic:
         hm[:, :2] = 0.0
         hm[:, -2:] = 0.0
-    hm[:2, :] = 0.0
-    if not north_ocean:
-        hm[-2:, :] = 0.0
+    if not ns_cyclic:
+        hm[:2, :] = 0.0
+        if not north_ocean:
+            hm[-2:, :] = 0.0
     uvm = np.minimum(np.minimum(hm, np.roll(hm, -1, axis=1)),
                      np.minimum(np.roll(hm, -1, axis=0), np.roll(np.roll(hm, -1, axis=0), -1, axis=1)))
     G = dict(HTN=HTN, HTE=HTE, dxu=dxu, dxt=dxt, dyu=dyu, dyt=dyt, ULAT=E["ULAT"], hm=hm, uvm=uvm)

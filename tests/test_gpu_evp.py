@@ -482,8 +482,9 @@ def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm
     nxg, nyg, nb = 96, 72, 4
     c1 = lib.Context()
     dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
-    grid1 = synth.block_fields(gg, dom1)
+    # (cyclic north-south: ocean and ice across the seam, or the wrap carries nothing)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31, land_rows=0 if ns == 1 else 2)
+    grid1 = synth.block_fields(gg, dom1, ns_cyclic=(ns == 1))
     s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
     orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     orc.evp(orc.make_domain(dom1, grid1), s1)
@@ -555,7 +556,7 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                 dom = c.domain_create(nxg, nyg, nxg, nyg // R, ew=1, ns=ns, rank=r, npx=1, npy=R)
             assert dom["nblocks"] == 1 and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
-            grid = synth.block_fields(gg, dom)
+            grid = synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
             s = synth.evp_state(grid, dom, seed=31, cover="patchy")
             c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
             if mode.startswith("peer"):
@@ -710,9 +711,12 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
     2-subcycle loops (2 = one hand-off), odd counts, and a loop cut into ranges (the stepwise API); gx1 size (768
     four-wavefront tiles: three on every CU) and 250 x 200 (268 tiles: one or two per CU)."""
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=ew, ns=ns)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg)
-    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1))
+    # (a cyclic north-south boundary only matters if nothing closes the domain there: ocean and ice across the seam)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg, land_rows=0 if ns == 1 else 2)
+    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1), ns_cyclic=(ns == 1))
     s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    if ns == 1:
+        assert grid["umask"][0, -2].sum() > 10 and grid["umask"][0, 1].sum() > 10
     keys = EVP_OUT_FIELDS + ("iceumask",)
     big = nxg * nyg >= 50000                 # more 4-wavefront tiles than CUs: the dense shape
     for ndte, damping in (((NDTE, False),) if big else ((NDTE, False), (7, True), (2, False), (3, False))):
