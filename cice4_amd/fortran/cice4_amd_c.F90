@@ -296,6 +296,16 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          real(c_double), value :: chio
       end function
+      integer(c_int) function cice_comm_init_shm(ctx, name, rank, nranks, box_bytes) bind(C, name='cice_comm_init_shm')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: name(*)
+         integer(c_int), value :: rank, nranks
+         integer(c_long_long), value :: box_bytes
+      end function
+      integer(c_int) function cice_getpid() bind(C, name='getpid')
+         import
+      end function
       integer(c_int) function cice_comm_init_local(ctx, link_id, rank, nranks) bind(C, name='cice_comm_init_local')
          import
          type(c_ptr), value :: ctx
@@ -467,7 +477,26 @@ contains
       integer, intent(in) :: my_task, nprocs, comm
       include 'mpif.h'
       character(kind=c_char) :: uid(128)
-      integer :: ierr
+      integer :: ierr, pid0, k
+      character(len=32) :: link
+      character(len=48) :: txt
+      character(kind=c_char) :: cname(49)
+      ! CICE4_AMD_LINK=shm: the tasks are processes of ONE host and talk through a file under /dev/shm instead of RCCL --
+      ! the way to run an MPI job of the model on a box with fewer GPUs than tasks (RCCL refuses two ranks on one device)
+      call get_environment_variable('CICE4_AMD_LINK', link)
+      if (trim(link) == 'shm') then
+         pid0 = 0
+         if (my_task == 0) pid0 = cice_getpid()
+         call MPI_BCAST(pid0, 1, MPI_INTEGER, 0, comm, ierr)
+         write(txt,'(a,i0)') '/cice4_amd_mpi_', pid0
+         cname = c_null_char
+         do k = 1, len_trim(txt)
+            cname(k) = txt(k:k)
+         enddo
+         call cice_gpu_check(cice_comm_init_shm(cice_gpu_ctx, cname, my_task, nprocs, 67108864_c_long_long), &
+                             'cice_comm_init_shm')
+         return
+      endif
       uid = c_null_char
       if (my_task == 0) call cice_gpu_check(cice_comm_unique_id(uid), 'cice_comm_unique_id')
       call MPI_BCAST(uid, 128, MPI_CHARACTER, 0, comm, ierr)

@@ -138,3 +138,22 @@ def test_bench_tries_and_verifies_the_cross_rank_loop_by_itself():
     assert d["value"] >= other["value"] > 0
     print("two rank processes on one GPU: value %.0f (%s), other decomposition %.0f" %
           (d["value"], "cross-rank loop" if used_loop else "wide-halo slabs", other["value"]))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("nprocs,shape", [(2, "slenderX1"), (2, "slenderX2"), (4, "square-ice")])
+def test_mpi_job_of_the_fortran_dropin_on_one_gpu(nprocs, shape):
+    """`mpiexec -n P`: the reference's MPI build with our ice_dyn_evp and boundary modules, P tasks on the one GPU joined by
+    the shared-memory link (CICE4_AMD_LINK=shm; RCCL would refuse them): block distribution by the reference's own
+    create_distribution, ghost cells between tasks after every subcycle, `call evp(dt)` = the single-domain checker."""
+    import shutil
+    from oracle import refapi
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec")
+    if not refapi.available("gx3b4", "dropinmpi"):
+        pytest.skip("oracle/_ref/libcice_dropinmpi_gx3b4.so not built")
+    p = subprocess.run([mpiexec, "-n", str(nprocs), sys.executable, os.path.join(ROOT, "tests", "mpi_evp_case.py"), "gx3b4",
+                        str(nprocs), shape], capture_output=True, text=True, timeout=500, cwd="/tmp")
+    ok = [l for l in p.stdout.splitlines() if l.startswith("MPI-EVP-OK")]
+    assert p.returncode == 0 and len(ok) == nprocs, p.stdout[-2500:] + p.stderr[-2500:]
