@@ -22,7 +22,11 @@
 # is written to disk.  source/dump_field.F90 (unconditional `use netcdf`, not used by this driver) is
 # left out.  The reference's build system (comp_ice, bld/) is not run.
 #
-# usage: oracle/build_driver.sh <cfg> <NXGLOB> <NYGLOB> <BLCKX> <BLCKY> <MXBLCKS>     (env: DROPIN=0|1)
+# MPI=1: the reference's mpi/ backend (MPICH of the image) instead of serial/ -> cice_refmpi_<cfg> / cice_dropinmpi_<cfg>:
+# the model as an MPI user builds it; the drop-in boundary module then also creates the device communicator
+# (-DCICE4_AMD_MPI).
+#
+# usage: oracle/build_driver.sh <cfg> <NXGLOB> <NYGLOB> <BLCKX> <BLCKY> <MXBLCKS>     (env: DROPIN=0|1, MPI=0|1)
 set -euo pipefail
 REF=${CICE_REFERENCE_ROOT:-/root/reference}
 HERE=$(cd "$(dirname "$0")" && pwd)
@@ -34,8 +38,15 @@ if [ ! -d "$REF/source" ]; then
   echo "build_driver: $REF not present (GPU box?) -- using prebuilt files in $OUT" >&2
   exit 0
 fi
+MPI=${MPI:-0}
+MPIROOT=${MPIROOT:-/opt/conda}
 KIND=ref
 [ "$DROPIN" = "1" ] && KIND=dropin
+BACKEND=serial
+if [ "$MPI" = "1" ]; then
+  KIND=${KIND}mpi
+  BACKEND=mpi
+fi
 OBJ=$OUT/drv_${CFG}_$KIND
 TARGET=$OUT/cice_${KIND}_$CFG
 OURS=$HERE/../cice4_amd/fortran
@@ -45,11 +56,12 @@ fi
 rm -rf "$OBJ"; mkdir -p "$OBJ"
 FFLAGS="-O2 -w -cpp -fdefault-real-8 -fconvert=big-endian -ffp-contract=off \
  -DLINUX -DNXGLOB=$NXG -DNYGLOB=$NYG -DBLCKX=$BX -DBLCKY=$BY -DMXBLCKS=$MXB -J $OBJ -I $OBJ"
+[ "$MPI" = "1" ] && FFLAGS="$FFLAGS -I$MPIROOT/include -DCICE4_AMD_MPI"
 
 # the source list: the reference's files, with ours substituted for the drop-in build
-LIST=$(ls $REF/drivers/cice4/*.F90 $REF/source/*.F90 $REF/serial/*.F90 $REF/csm_share/*.F90 | grep -v dump_field.F90)
+LIST=$(ls $REF/drivers/cice4/*.F90 $REF/source/*.F90 $REF/$BACKEND/*.F90 $REF/csm_share/*.F90 | grep -v dump_field.F90)
 if [ "$DROPIN" = "1" ]; then
-  LIST=$(echo "$LIST" | grep -v -e source/ice_dyn_evp.F90 -e source/ice_therm_vertical.F90 -e serial/ice_boundary.F90 \
+  LIST=$(echo "$LIST" | grep -v -e source/ice_dyn_evp.F90 -e source/ice_therm_vertical.F90 -e $BACKEND/ice_boundary.F90 \
          -e source/ice_transport_driver.F90)
   LIST="$LIST $OURS/cice4_amd_c.F90 $OURS/ice_dyn_evp.F90 $OURS/ice_therm_vertical.F90 $OURS/rccl/ice_boundary.F90 \
         $OURS/ice_transport_driver.F90"
@@ -97,5 +109,6 @@ LINK=""
 if [ "$DROPIN" = "1" ]; then
   LINK="-L$HERE/../cice4_amd -lcice4_amd -Wl,-rpath,\$ORIGIN/../../cice4_amd"
 fi
+[ "$MPI" = "1" ] && LINK="$LINK -L$MPIROOT/lib -lmpifort -lmpi -Wl,-rpath,$MPIROOT/lib"
 $FC -o "$TARGET" $OBJS $LINK
 echo "built $TARGET"

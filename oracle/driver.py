@@ -108,9 +108,12 @@ def write_rundir(path, grid="gx3", npt=25, istep0=0, nprocs=1, overrides=None):
     return path
 
 
-def run(exe, rundir, timeout=1200, env=None):
-    """Run the model; returns its log.  Large automatic arrays need an unlimited stack."""
-    cmd = "ulimit -s unlimited; exec %s" % os.path.abspath(exe)
+def run(exe, rundir, timeout=1200, env=None, nprocs=1):
+    """Run the model (nprocs > 1: under mpiexec, the MPI builds of build_driver.sh); returns its log.  Large automatic
+    arrays need an unlimited stack."""
+    import shutil
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    cmd = "ulimit -s unlimited; exec %s%s" % ("%s -n %d " % (mpiexec, nprocs) if nprocs > 1 else "", os.path.abspath(exe))
     p = subprocess.run(["bash", "-c", cmd], cwd=rundir, capture_output=True, text=True, timeout=timeout,
                        env=dict(os.environ, **(env or {})))
     log = p.stdout + p.stderr

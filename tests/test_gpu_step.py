@@ -191,6 +191,32 @@ def test_whole_model_with_a_tripole_north_boundary(ns):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nprocs", [2, 4])
+def test_whole_model_as_an_mpi_job_on_one_gpu(nprocs):
+    """The reference's whole model in its MPI build (mpi/ modules, MPICH) with the four drop-in modules, `mpiexec -n P` on
+    the real gx3 grid in 2 x 2 blocks: the P tasks share the one GPU and exchange through the shared-memory link
+    (CICE4_AMD_LINK=shm; RCCL refuses two ranks on one device).  Block distribution by the reference's create_distribution,
+    ghost cells between tasks in every ice_HaloUpdate of the model and after every EVP subcycle, transport and
+    thermodynamics per task, the restart dump gathered by the reference's own MPI gather: the dump after 25 steps equals
+    the pure serial reference's (which the pure MPI reference reproduces bit for bit on the CPU)."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_gx3b4")
+    if not os.path.exists(exe):
+        pytest.skip("%s not built (MPI=1 DROPIN=1 oracle/build_driver.sh gx3b4 100 116 50 58 4)" % exe)
+    rd = tempfile.mkdtemp(prefix="cice_mpi_")
+    try:
+        driver.write_rundir(rd, npt=25, nprocs=nprocs)
+        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm"}, nprocs=nprocs)
+        hdr, rec = driver.read_restart(driver.restart_path(rd), 100, 116)
+    finally:
+        shutil.rmtree(rd, ignore_errors=True)
+    assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+    gold = np.load(os.path.join(GOLD, "step_gx3_default25.npz"))
+    assert hdr["istep1"] == int(gold["istep1"]) and hdr["time"] == float(gold["time"])
+    worst = _compare(rec, gold, 1, TOL_EXP)
+    print("whole model, MPI job of %d tasks on one GPU: worst field-relative difference" % nprocs, worst)
+
+
+@pytest.mark.gpu
 def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
     """The whole model on the real gx3 grid cut into 10 x 12 blocks of 10 x 10 cells (max_blocks = 120), the four
     all-land blocks eliminated by the reference's own create_distribution: multi-block EVP (per-subcycle halo updates
