@@ -26,6 +26,7 @@ const char* Domain::create(int nx_global, int ny_global, int block_size_x, int b
   nby = (nyg - 1) / bsy + 1;
   npx = npx_; npy = npy_; nranks = npx * npy; rank = rank_;
   ew = ew_bnd; ns = ns_bnd;
+  from_map = false; map_owner.clear(); map_lid.clear();
   if (rank < 0 || rank >= nranks) return "rank out of range";
   if (npx > nbx || npy > nby) return "more ranks than blocks along an axis";
   // contiguous rectangles of blocks per rank, dealt the way create_distrb_cart does
@@ -64,6 +65,9 @@ const char* Domain::create_map(int nx_global, int ny_global, int block_size_x, i
   }
   for (size_t g = 0; g < nb; ++g)   // local ids of a rank must be a permutation of 0 .. n-1
     if (owner[g] >= 0 && (lid[g] < 0 || lid[g] >= nlocal[owner[g]])) return "block map: local id out of range";
+  from_map = true;
+  map_owner = owner;
+  map_lid = lid;
   return build(owner, lid);
 }
 
@@ -244,6 +248,7 @@ const char* Domain::create_slabs(int nx_global, int ny_global, int nblocks_y, in
   nx_block = bsx + 2; ny_block = bsy + 2 * overlap + 2;
   nbx = 1; nby = nblocks_y; npx = 1; npy = nranks_; nranks = nranks_; rank = rank_;
   ew = ew_bnd; ns = ns_bnd;
+  from_map = false; map_owner.clear(); map_lid.clear();
   all.clear(); local.clear(); hsrc.clear(); hdst.clear(); send.clear(); recv.clear();
   rsrc.clear(); rdst.clear();
   const int per_rank = nby / nranks;

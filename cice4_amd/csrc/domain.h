@@ -41,6 +41,8 @@ struct Domain {
   int nxg = 0, nyg = 0, bsx = 0, bsy = 0;
   int nx_block = 0, ny_block = 0;
   int nbx = 0, nby = 0, npx = 1, npy = 1, rank = 0, nranks = 1;
+  bool from_map = false;               // created from an explicit block -> task map (create_map): kept for rebuilding a
+  std::vector<int> map_owner, map_lid; // neighbour's view of the same decomposition
   int ew = BND_CYCLIC, ns = BND_OPEN;
   bool tripole() const { return ns == BND_TRIPOLE || ns == BND_TRIPOLET; }
   int fold_rows() const { return ns == BND_TRIPOLET ? 3 : 2; }   // rows of the global fold buffer (tripoleRows, serial/ice_boundary.F90:199-204)

@@ -2860,10 +2860,18 @@ void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long pe
 
 bool Evp::can_reside_peer() const {
   if (!resident_on || resident_failed || !halo.multi_rank()) return false;
-  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold() || dom.nbx != 1 || dom.npx != 1) return false;
+  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold() || dom.nbx != 1) return false;
   if (dom.tripole()) return false;
-  // every neighbour this slab has must be connected
   const Block& bl = dom.all[dom.local[0]];
+  if (dom.from_map) {
+    // a block -> task map (the Fortran boundary module hands over the model's own distribution): full-width slabs stacked
+    // in task order, one per task -- the neighbours the caller connected as "south" / "north" are the tasks rank -+ 1
+    for (const Block& b : dom.all)
+      if (b.owner != b.jb) return false;
+  } else if (dom.npx != 1) {
+    return false;
+  }
+  // every neighbour this slab has must be connected
   const bool has_s = bl.jb > 0 || dom.ns == BND_CYCLIC, has_n = bl.jb < dom.nby - 1 || dom.ns == BND_CYCLIC;
   if ((has_s && !peers[0].rprog) || (has_n && !peers[1].rprog)) return false;
   return resident_waves() > 0;
@@ -2884,7 +2892,10 @@ void Evp::build_resident_peer(int W) {
     auto it = pd.find(prank);
     if (it == pd.end()) {
       Domain d;
-      const char* msg = d.create(dom.nxg, dom.nyg, dom.bsx, dom.bsy, dom.ew, dom.ns, prank, dom.npx, dom.npy);
+      const char* msg = dom.from_map
+                            ? d.create_map(dom.nxg, dom.nyg, dom.bsx, dom.bsy, dom.ew, dom.ns, prank, dom.nranks,
+                                           dom.map_owner.data(), dom.map_lid.data())
+                            : d.create(dom.nxg, dom.nyg, dom.bsx, dom.bsy, dom.ew, dom.ns, prank, dom.npx, dom.npy);
       CICE_REQUIRE(!msg[0], "resident EVP loop across ranks: cannot rebuild a neighbour's decomposition");
       it = pd.emplace(prank, std::move(d)).first;
     }

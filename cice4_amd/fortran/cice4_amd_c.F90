@@ -312,6 +312,18 @@ module cice4_amd_c
          integer(c_int), value :: link_id, rank, nranks
       end function
       ! the one-launch subcycle loop across tasks: exchange copies / progress words of the neighbours (DESIGN.md section 7)
+      integer(c_int) function cice_evp_set_option(ctx, key, value) bind(C, name='cice_evp_set_option')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: key(*)
+         integer(c_int), value :: value
+      end function
+      integer(c_int) function cice_evp_get_info(ctx, key, value) bind(C, name='cice_evp_get_info')
+         import
+         type(c_ptr), value :: ctx
+         character(kind=c_char), intent(in) :: key(*)
+         integer(c_int), intent(out) :: value
+      end function
       integer(c_int) function cice_evp_peer_export_ipc(ctx, handles, plane) bind(C, name='cice_evp_peer_export_ipc')
          import
          type(c_ptr), value :: ctx
@@ -502,6 +514,49 @@ contains
       call MPI_BCAST(uid, 128, MPI_CHARACTER, 0, comm, ierr)
       call cice_gpu_check(cice_comm_init(cice_gpu_ctx, uid, my_task, nprocs), 'cice_comm_init')
    end subroutine cice_gpu_comm_setup
+
+   ! The one-launch subcycle loop ACROSS tasks (DESIGN.md section 7): where every task holds one full-width slab, the tasks
+   ! hand each other the IPC handles of their exchange copies / progress words (control plane: MPI on the model's
+   ! communicator) and the library maps them -- after that the two ice_HaloUpdate calls per subcycle of evp need no message.
+   ! Called after cice_evp_init by the drop-in ice_dyn_evp; where the decomposition is another one the library simply keeps
+   ! the message path.  CICE4_AMD_PEER_LOOP=0 in the environment skips it; CICE4_AMD_PEER_SHARE=n tells the library that n
+   ! tasks share one device (tests on a one-GPU box, with CICE4_AMD_LINK=shm).
+   subroutine cice_gpu_peer_setup(my_task, nprocs, comm, nblocks_local, full_width)
+      integer, intent(in) :: my_task, nprocs, comm, nblocks_local
+      logical, intent(in) :: full_width
+      include 'mpif.h'
+      character(kind=c_char) :: mine(64,3), south(64,3), north(64,3)
+      integer(c_long_long) :: plane(1), plane_s(1), plane_n(1)
+      integer :: ierr, stat(MPI_STATUS_SIZE), ok, allok, share
+      character(len=16) :: txt
+      call get_environment_variable('CICE4_AMD_PEER_LOOP', txt)
+      if (trim(txt) == '0') return
+      ok = 0
+      if (nprocs > 1 .and. nblocks_local == 1 .and. full_width) ok = 1
+      call MPI_ALLREDUCE(ok, allok, 1, MPI_INTEGER, MPI_MIN, comm, ierr)
+      if (allok /= 1) return
+      call get_environment_variable('CICE4_AMD_PEER_SHARE', txt)
+      if (len_trim(txt) > 0) then
+         read(txt,*) share
+         call cice_gpu_check(cice_evp_set_option(cice_gpu_ctx, 'resident_peer_share'//c_null_char, share), 'resident_peer_share')
+      endif
+      call cice_gpu_check(cice_evp_peer_export_ipc(cice_gpu_ctx, mine, plane(1)), 'cice_evp_peer_export_ipc')
+      ! slabs are stacked south to north in task order (cartesian distribution with one task column)
+      if (my_task < nprocs-1) call MPI_SEND(mine, 192, MPI_CHARACTER, my_task+1, 71, comm, ierr)
+      if (my_task > 0)        call MPI_RECV(south, 192, MPI_CHARACTER, my_task-1, 71, comm, stat, ierr)
+      if (my_task < nprocs-1) call MPI_SEND(plane, 1, MPI_INTEGER8, my_task+1, 72, comm, ierr)
+      if (my_task > 0)        call MPI_RECV(plane_s, 1, MPI_INTEGER8, my_task-1, 72, comm, stat, ierr)
+      if (my_task > 0)        call MPI_SEND(mine, 192, MPI_CHARACTER, my_task-1, 73, comm, ierr)
+      if (my_task < nprocs-1) call MPI_RECV(north, 192, MPI_CHARACTER, my_task+1, 73, comm, stat, ierr)
+      if (my_task > 0)        call MPI_SEND(plane, 1, MPI_INTEGER8, my_task-1, 74, comm, ierr)
+      if (my_task < nprocs-1) call MPI_RECV(plane_n, 1, MPI_INTEGER8, my_task+1, 74, comm, stat, ierr)
+      if (my_task > 0) &
+         call cice_gpu_check(cice_evp_peer_connect_ipc(cice_gpu_ctx, 0_c_int, south, plane_s(1)), 'cice_evp_peer_connect_ipc')
+      if (my_task < nprocs-1) &
+         call cice_gpu_check(cice_evp_peer_connect_ipc(cice_gpu_ctx, 1_c_int, north, plane_n(1)), 'cice_evp_peer_connect_ipc')
+      call MPI_BARRIER(comm, ierr)
+      if (my_task == 0) write(*,*) 'EVP subcycling as one launch per task: exchange buffers of the neighbouring tasks connected'
+   end subroutine cice_gpu_peer_setup
 #endif
 
 end module cice4_amd_c

@@ -21,7 +21,11 @@
 
       use ice_kinds_mod
       use ice_fileunits, only: nu_diag
+#ifdef CICE4_AMD_MPI
+      use ice_communicate, only: my_task, master_task, MPI_COMM_ICE, get_num_procs
+#else
       use ice_communicate, only: my_task, master_task
+#endif
       use ice_domain_size
       use ice_constants
       use iso_c_binding
@@ -194,6 +198,10 @@
       cfg%kstrength = kstrength; cfg%krdg_partic = krdg_partic; cfg%krdg_redist = krdg_redist
       cfg%mu_rdg = mu_rdg
       call cice_gpu_check(cice_evp_init(cice_gpu_ctx, cfg, g), 'cice_evp_init')
+#ifdef CICE4_AMD_MPI
+      ! one full-width slab per task: connect the neighbours' exchange buffers (the one-launch loop across tasks)
+      call cice_gpu_peer_setup(my_task, get_num_procs(), MPI_COMM_ICE, nblocks, block_size_x == nx_global)
+#endif
       end subroutine evp_gpu_setup
 
       integer (c_int) function bnd_code(name)

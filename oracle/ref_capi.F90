@@ -441,6 +441,17 @@ contains
    end subroutine ref_evp_gpu_setup
 #endif
 
+#ifdef DROPIN
+   integer(c_int) function ref_evp_info(ckey) bind(C, name='ref_evp_info')
+      use cice4_amd_c, only: cice_evp_get_info, cice_gpu_ctx
+      character(kind=c_char), intent(in) :: ckey(*)
+      integer(c_int) :: v, rc
+      v = -1
+      rc = cice_evp_get_info(cice_gpu_ctx, ckey, v)
+      ref_evp_info = v
+   end function ref_evp_info
+#endif
+
    subroutine ref_evp(dt) bind(C, name='ref_evp')
       use ice_dyn_evp, only: evp
       real(c_double), value :: dt

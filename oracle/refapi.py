@@ -269,6 +269,11 @@ class Ref:
     def evp(self, dt):
         self.lib.ref_evp(C.c_double(dt))
 
+    def evp_info(self, key):
+        """drop-in builds: cice_evp_get_info of the library behind the Fortran modules"""
+        self.lib.ref_evp_info.restype = C.c_int
+        return int(self.lib.ref_evp_info(key.encode() + b"\0"))
+
     def evp_gpu_setup(self):
         self.lib.ref_evp_gpu_setup()
 

@@ -1,7 +1,9 @@
 """One rank of `mpiexec -n P python tests/mpi_evp_case.py <cfg> <P> <processor_shape>` on a box with ONE GPU:
 the reference's MPI build (mpi/ modules, MPICH) with OUR ice_dyn_evp and boundary modules; the P tasks share device 0 and
 exchange through the shared-memory link (CICE4_AMD_LINK=shm) instead of RCCL.  `call evp(dt)` on every task's own blocks
-must reproduce the single-domain checker bit for bit.  Prints 'MPI-EVP-OK <rank> <blocks>'."""
+must reproduce the single-domain checker bit for bit.  With one full-width slab per task (cfg gx3s2) the drop-in connects
+the neighbours' exchange buffers through IPC handles sent over MPI and the subcycling runs as ONE launch per task with
+device-initiated exchange (argument `loop`: that it did is checked).  Prints 'MPI-EVP-OK <rank> <blocks>'."""
 import os
 import sys
 import tempfile
@@ -9,6 +11,8 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ["CICE4_AMD_LINK"] = "shm"
+if len(sys.argv) > 2:
+    os.environ["CICE4_AMD_PEER_SHARE"] = sys.argv[2]      # the tasks share one device
 
 import numpy as np  # noqa: E402
 
@@ -69,6 +73,8 @@ def main():
     ref.set("aicen", mine(s1["aicen"].reshape(-1, ny, nx), ncat)); ref.set("vicen", mine(s1["vicen"].reshape(-1, ny, nx), ncat))
     ref.set_evp_parameters(DT, NDTE, False)
     ref.evp(DT)
+    if len(sys.argv) > 4 and sys.argv[4] == "loop":
+        assert ref.evp_info("resident_peer") == 1, "the cross-task one-launch loop was not used (or fell back)"
     for k in OUT:
         got = ref.get(k)
         for l, g in enumerate(gids):

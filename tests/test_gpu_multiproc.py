@@ -141,19 +141,23 @@ def test_bench_tries_and_verifies_the_cross_rank_loop_by_itself():
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("nprocs,shape", [(2, "slenderX1"), (2, "slenderX2"), (4, "square-ice")])
-def test_mpi_job_of_the_fortran_dropin_on_one_gpu(nprocs, shape):
+@pytest.mark.parametrize("cfg,nprocs,shape", [("gx3b4", 2, "slenderX1"), ("gx3b4", 2, "slenderX2"), ("gx3b4", 4, "square-ice"),
+                                              ("gx3s2", 2, "slenderX1")])
+def test_mpi_job_of_the_fortran_dropin_on_one_gpu(cfg, nprocs, shape):
     """`mpiexec -n P`: the reference's MPI build with our ice_dyn_evp and boundary modules, P tasks on the one GPU joined by
     the shared-memory link (CICE4_AMD_LINK=shm; RCCL would refuse them): block distribution by the reference's own
-    create_distribution, ghost cells between tasks after every subcycle, `call evp(dt)` = the single-domain checker."""
+    create_distribution, ghost cells between tasks after every subcycle, `call evp(dt)` = the single-domain checker.
+    cfg gx3s2: one full-width slab per task -- the drop-in hands the IPC handles of the exchange buffers to the neighbouring
+    task over MPI and the whole subcycling is one launch per task (checked: the loop was used and did not fall back)."""
     import shutil
     from oracle import refapi
     mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
     if not os.path.exists(mpiexec):
         pytest.skip("no mpiexec")
-    if not refapi.available("gx3b4", "dropinmpi"):
-        pytest.skip("oracle/_ref/libcice_dropinmpi_gx3b4.so not built")
-    p = subprocess.run([mpiexec, "-n", str(nprocs), sys.executable, os.path.join(ROOT, "tests", "mpi_evp_case.py"), "gx3b4",
-                        str(nprocs), shape], capture_output=True, text=True, timeout=500, cwd="/tmp")
+    if not refapi.available(cfg, "dropinmpi"):
+        pytest.skip(f"oracle/_ref/libcice_dropinmpi_{cfg}.so not built")
+    p = subprocess.run([mpiexec, "-n", str(nprocs), sys.executable, os.path.join(ROOT, "tests", "mpi_evp_case.py"), cfg,
+                        str(nprocs), shape] + (["loop"] if cfg == "gx3s2" else []), capture_output=True, text=True, timeout=500,
+                       cwd="/tmp")
     ok = [l for l in p.stdout.splitlines() if l.startswith("MPI-EVP-OK")]
     assert p.returncode == 0 and len(ok) == nprocs, p.stdout[-2500:] + p.stderr[-2500:]

@@ -191,29 +191,33 @@ def test_whole_model_with_a_tripole_north_boundary(ns):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nprocs", [2, 4])
-def test_whole_model_as_an_mpi_job_on_one_gpu(nprocs):
+@pytest.mark.parametrize("cfg,nprocs", [("gx3b4", 2), ("gx3b4", 4), ("gx3s2", 2)])
+def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     """The reference's whole model in its MPI build (mpi/ modules, MPICH) with the four drop-in modules, `mpiexec -n P` on
     the real gx3 grid in 2 x 2 blocks: the P tasks share the one GPU and exchange through the shared-memory link
     (CICE4_AMD_LINK=shm; RCCL refuses two ranks on one device).  Block distribution by the reference's create_distribution,
     ghost cells between tasks in every ice_HaloUpdate of the model and after every EVP subcycle, transport and
     thermodynamics per task, the restart dump gathered by the reference's own MPI gather: the dump after 25 steps equals
-    the pure serial reference's (which the pure MPI reference reproduces bit for bit on the CPU)."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_gx3b4")
+    the pure serial reference's (which the pure MPI reference reproduces bit for bit on the CPU).
+    cfg gx3s2: two full-width slabs, one per task -- the drop-in dynamics connect the neighbouring task's exchange buffers
+    (IPC handles over MPI) and evp(dt) subcycles in ONE launch per task with device-initiated exchange."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_%s" % cfg)
     if not os.path.exists(exe):
-        pytest.skip("%s not built (MPI=1 DROPIN=1 oracle/build_driver.sh gx3b4 100 116 50 58 4)" % exe)
+        pytest.skip("%s not built (MPI=1 DROPIN=1 oracle/build_driver.sh)" % exe)
     rd = tempfile.mkdtemp(prefix="cice_mpi_")
     try:
         driver.write_rundir(rd, npt=25, nprocs=nprocs)
-        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm"}, nprocs=nprocs)
+        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(nprocs)}, nprocs=nprocs)
         hdr, rec = driver.read_restart(driver.restart_path(rd), 100, 116)
     finally:
         shutil.rmtree(rd, ignore_errors=True)
     assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+    assert ("EVP subcycling as one launch per task" in log) == (cfg == "gx3s2")
+    assert "resident EVP loop timed out" not in log
     gold = np.load(os.path.join(GOLD, "step_gx3_default25.npz"))
     assert hdr["istep1"] == int(gold["istep1"]) and hdr["time"] == float(gold["time"])
     worst = _compare(rec, gold, 1, TOL_EXP)
-    print("whole model, MPI job of %d tasks on one GPU: worst field-relative difference" % nprocs, worst)
+    print("whole model (%s), MPI job of %d tasks on one GPU: worst field-relative difference" % (cfg, nprocs), worst)
 
 
 @pytest.mark.gpu
