@@ -482,9 +482,8 @@ def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm
     nxg, nyg, nb = 96, 72, 4
     c1 = lib.Context()
     dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
-    # (cyclic north-south: ocean and ice across the seam, or the wrap carries nothing)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31, land_rows=0 if ns == 1 else 2)
-    grid1 = synth.block_fields(gg, dom1, ns_cyclic=(ns == 1))
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
+    grid1 = synth.block_fields(gg, dom1)
     s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
     orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     orc.evp(orc.make_domain(dom1, grid1), s1)
@@ -535,8 +534,9 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
     ns = 1 if mode == "peer-cyclic" else 0
     c1 = lib.Context()
     dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
-    grid1 = synth.block_fields(gg, dom1)
+    # (cyclic north-south: ocean and ice across the seam, or the wrap carries nothing)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31, land_rows=0 if ns == 1 else 2)
+    grid1 = synth.block_fields(gg, dom1, ns_cyclic=(ns == 1))
     s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
     orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     orc.evp(orc.make_domain(dom1, grid1), s1)
