@@ -159,12 +159,15 @@ def test_whole_model_with_upwind_advection():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
-def test_whole_model_with_a_tripole_north_boundary(ns):
+@pytest.mark.parametrize("ns,ocean_at_fold", [("tripole", False), ("tripoleT", False), ("tripole", True), ("tripoleT", True)])
+def test_whole_model_with_a_tripole_north_boundary(ns, ocean_at_fold):
     """namelist ns_boundary_type = 'tripole' / 'tripoleT' on the gx3 grid: every ice_HaloUpdate of the model (grid set-up
     with extrapolation, bound_state, the scalar and vector fields of the dynamics and the transport at their four
     locations) goes through the fold of the drop-in boundary module, evp(dt) runs the one-launch loop with the fold
-    inside.  25 steps, pure reference and drop-in modules on this host, all records of the restart dump."""
+    inside.  25 steps, pure reference and drop-in modules on this host, all records of the restart dump.
+    ocean_at_fold: the gx3 land mask has land along the northern edge, so the fold moves nothing; with the last eight rows
+    of kmt opened the initial ice reaches the fold and drifts across it (|u| ~ 0.1 m/s in the top rows): the symmetric
+    averages of the degenerate row, the mirrored ghost row, the transport through the fold all carry real values."""
     exe = {k: os.path.join(ROOT, "oracle", "_ref", "cice_%s_gx3" % k) for k in ("ref", "dropin")}
     for e in exe.values():
         if not os.path.exists(e):
@@ -174,10 +177,17 @@ def test_whole_model_with_a_tripole_north_boundary(ns):
         rec = {}
         for kind in ("ref", "dropin"):
             driver.write_rundir(dirs[kind], npt=25, overrides={"domain_nml": dict(ns_boundary_type=ns)})
+            if ocean_at_fold:
+                kmt = np.load(os.path.join(GOLD, "gx3_grid_kmt.npz"))["kmt"].copy()
+                kmt[-8:, :] = np.maximum(kmt[-8:, :], 1)
+                with open(os.path.join(dirs[kind], "kmt"), "wb") as f:
+                    f.write(kmt.astype(">i4").tobytes())
             log = driver.run(exe[kind], dirs[kind])
             rec[kind] = driver.read_restart(driver.restart_path(dirs[kind]), 100, 116)
         assert "EVP dynamics on the GPU" in log
         assert rec["ref"][0] == rec["dropin"][0]
+        if ocean_at_fold:
+            assert np.abs(rec["ref"][1]["uvel"][-3:]).max() > 0.01, "no ice moves at the fold"
         for k in rec["ref"][1]:
             a, g = rec["dropin"][1][k], rec["ref"][1][k]
             if TOL_EXP == 0.0:
