@@ -231,6 +231,40 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns,nprocs", [("tripole", 2), ("tripole", 4), ("tripoleT", 4)])
+def test_whole_model_as_an_mpi_job_across_a_tripole_fold(ns, nprocs):
+    """The same MPI job with a tripole north boundary and ocean up to the fold: the top rows of the two blocks of the top
+    block row travel between tasks into every task's fold buffer (one more message pair per ice_HaloUpdate), the fold is
+    applied after every EVP subcycle.  Against the pure SERIAL reference (one block) with the same namelist and mask."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_gx3b4")
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "cice_ref_gx3")
+    for e in (exe, ref_exe):
+        if not os.path.exists(e):
+            pytest.skip("%s not built" % e)
+    kmt = np.load(os.path.join(GOLD, "gx3_grid_kmt.npz"))["kmt"].copy()
+    kmt[-8:, :] = np.maximum(kmt[-8:, :], 1)
+    rec = {}
+    for kind, e, n in (("ref", ref_exe, 1), ("mpi", exe, nprocs)):
+        rd = tempfile.mkdtemp(prefix="cice_mpitri_")
+        try:
+            driver.write_rundir(rd, npt=25, nprocs=n, overrides={"domain_nml": dict(ns_boundary_type=ns)})
+            with open(os.path.join(rd, "kmt"), "wb") as f:
+                f.write(kmt.astype(">i4").tobytes())
+            driver.run(e, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(n)}, nprocs=n)
+            rec[kind] = driver.read_restart(driver.restart_path(rd), 100, 116)
+        finally:
+            shutil.rmtree(rd, ignore_errors=True)
+    assert rec["ref"][0] == rec["mpi"][0]
+    assert np.abs(rec["ref"][1]["uvel"][-3:]).max() > 0.01
+    for k in rec["ref"][1]:
+        a, g = rec["mpi"][1][k], rec["ref"][1][k]
+        if TOL_EXP == 0.0:
+            assert np.array_equal(a, g), (ns, nprocs, k, np.abs(a - g).max())
+        else:
+            assert np.abs(a - g).max() <= TOL_EXP * max(np.abs(g).max(), 1e-300), k
+
+
+@pytest.mark.gpu
 def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
     """The whole model on the real gx3 grid cut into 10 x 12 blocks of 10 x 10 cells (max_blocks = 120), the four
     all-land blocks eliminated by the reference's own create_distribution: multi-block EVP (per-subcycle halo updates
