@@ -843,7 +843,8 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "rows_per_wave")) *value = c_->evp->tile_rows();
   else if (!std::strcmp(key, "fused")) *value = c_->evp->can_fuse() ? 1 : 0;
   else if (!std::strcmp(key, "fused_waves")) *value = c_->evp->fused_waves();
-  else if (!std::strcmp(key, "skew")) *value = c_->evp->can_skew() ? 1 : 0;
+  else if (!std::strcmp(key, "skew")) *value = c_->evp->can_skew() || c_->evp->can_skew_fold() ? 1 : 0;
+  else if (!std::strcmp(key, "skew_fold")) *value = !c_->evp->can_skew() && c_->evp->can_skew_fold() ? 1 : 0;
   else if (!std::strcmp(key, "skew_levels")) *value = c_->evp->skew_levels();
   else if (!std::strcmp(key, "skew_seg_rows")) *value = c_->evp->skew_seg_rows(c_->evp->skew_levels());
   else if (!std::strcmp(key, "resident")) *value = (c_->evp->can_reside() || c_->evp->can_reside_peer()) ? 1 : 0;

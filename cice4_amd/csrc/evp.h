@@ -46,6 +46,7 @@ class Evp {
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
+  bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
   int skew_blocks(int K) const;    // workgroups per CU it is built for
@@ -107,6 +108,12 @@ class Evp {
   DevBuf<int32_t> res_deps;
   DevBuf<unsigned> res_prog;     // [tiles * 32] progress words, then the abort word
   DevBuf<double> res_xu[2];      // exchange copies of (u, v)
+  bool skew_fold_on = true;      // one-block tripole grids of sweep size: sweeps + a band of top rows (launch_subcycle_skew_fold)
+  void launch_subcycle_skew_fold(int ksub, int K);
+  void ensure_band(int K);       // buffers and block table of the band (allocations: outside any capture)
+  DevBuf<double> band[2];        // the band's two copies of u, v, 12 sigma (full planes; only the top rows are used)
+  DevBuf<int32_t> blk_band;
+  int band_k = 0;
   bool res_fold_on = true;       // one-block tripole domains run the one-launch loop with the fold inside
   void build_resident(int W);
   void build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W);   // tripole north boundary inside the loop
@@ -154,7 +161,7 @@ class Evp {
 
   void launch_subcycle(int ksub);
   void launch_subcycle_pair(int ksub);
-  void launch_subcycle_skew(int ksub, int K);
+  void launch_subcycle_skew(int ksub, int K, bool flip_and_halo = true);
   void launch_range(int ksub0, int nsub);
   void after_subcycle(int ksub);
   SubArgs make_args() const;

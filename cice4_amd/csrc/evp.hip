@@ -218,6 +218,7 @@ __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu,
 struct SubArgs {
   EvpScalars sc;
   int nx, ny, tiles_x, tiles_y, nblocks;
+  int diag_jmin;   // rows below it keep their diagnostics (a band of rows computed beside a sweep: its lower rows are scratch)
   int carry_top;   // tripole fold: the fold changes top-row cells WITHOUT ice too; the kernel carries their value into the new copy
   int ew_cyclic;  // k_subcycle2: columns of a block form a ring
   size_t n;  // nblocks*ny*nx
@@ -331,7 +332,7 @@ __device__ __forceinline__ void stepu_store(const SubArgs& a, const UIn& x, size
              x.fm, x.uarear, sx, sy, r);
   a.u_out[q] = r.u;
   a.v_out[q] = r.v;
-  if (LAST) {
+  if (LAST && j >= a.diag_jmin) {
     a.strintx[q] = r.strintx;
     a.strinty[q] = r.strinty;
     a.strocnx[q] = r.taux;
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(64 * W, 4) void k_subcycle(const SubArgs a) {
       if (own_i && (min(j, jhi) - j0) < (TROWS - 1)) {
 #pragma unroll
         for (int c = 0; c < 12; ++c) a.sig_out[(size_t)c * a.n + q] = s[c];
-        if (LAST) {
+        if (LAST && j >= a.diag_jmin) {
           a.divu[q] = o.divu;
           a.rdg_conv[q] = o.rdg_conv;
           a.rdg_shear[q] = o.rdg_shear;
@@ -2102,6 +2103,8 @@ void Evp::set_option(const char* key, int value) {
       res_level = 0;
       res_retry_in = 0;
     }
+  } else if (!std::strcmp(key, "skew_fold")) {              // sweeps on a tripole grid (a band of top rows beside them)
+    skew_fold_on = value != 0;
   } else if (!std::strcmp(key, "resident_fold")) {          // a tripole north boundary inside the one-launch loop
     res_fold_on = value != 0;
   } else if (!std::strcmp(key, "resident_retry_steps")) {   // evp(dt) calls until a time-out is forgiven, 0 = never
@@ -2707,7 +2710,7 @@ static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hip
 }
 
 // subcycles ksub .. ksub+K-1
-void Evp::launch_subcycle_skew(int ksub, int K) {
+void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
   SkewArgs sa{};
   sa.a = make_args();
   const int ownl = 62 - 2 * K;
@@ -2747,7 +2750,101 @@ void Evp::launch_subcycle_skew(int ksub, int K) {
     case 82: launch_skew_kb<8, 2>(sa, last, damp, g, stream); break;
     default: throw Error{CICE_EINVAL, "unsupported (skew_levels, skew_blocks) combination"};
   }
-  after_subcycle(ksub + K - 1);
+  if (flip_and_halo) after_subcycle(ksub + K - 1);
+}
+
+// ---- K subcycles per sweep on a grid with a tripole fold ----------------------------------------------------------
+// The fold couples the two halves of the top row after EVERY subcycle; a sweep has no subcycle finished anywhere before
+// its end.  But the north boundary only reaches K rows down in K subcycles.  So: the sweep runs as on an open boundary
+// (rows above jhi - K come out wrong), and beside it a BAND of the top 2K + 1 rows runs the K subcycles one at a time,
+// k_subcycle + the halo update with its fold, on buffers of its own.  The band's lower rows see a stale row below them
+// and go wrong from the other side, one row per subcycle -- after K subcycles its rows above jhi - K are right.  They
+// replace the sweep's.  Per sweep: 2 + 2K small launches beside one large one.
+__global__ __launch_bounds__(256) void k_band_rows(double* __restrict__ dst, double* __restrict__ dst2,
+                                                   const double* __restrict__ src, size_t n, size_t off, size_t len) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // 14 planes x len cells starting at `off` in each
+  if (t >= 14 * len) return;
+  const size_t p = t / len, q = off + (t - p * len);
+  const double v = src[p * n + q];
+  dst[p * n + q] = v;
+  if (dst2) dst2[p * n + q] = v;
+}
+
+bool Evp::can_skew_fold() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW"); return e && e[0] == '0'; }();
+  if (!skew_on || !skew_fold_on || env_off || !fuse_on || !halo.fwd_ok() || !(derive_ok && derive_on)) return false;
+  if (!halo.has_fold() || halo.multi_rank() || halo.has_refresh() || dom.nblocks() != 1 || dom.overlap > 0) return false;
+  if (n * 8 * 14 >= (1ull << 32)) return false;
+  const Block& bl = dom.all[dom.local[0]];
+  if (bl.jhi - bl.jlo + 1 < 4 * skew_levels() + 4) return false;
+  const long long cells = (long long)(dom.nx_block - 2) * (dom.ny_block - 2);
+  return cells >= skew_min_cells;
+}
+
+void Evp::ensure_band(int K) {
+  const Block& bl = dom.all[dom.local[0]];
+  for (int k = 0; k < 2; ++k)
+    if (band[k].n < 14 * n) band[k].alloc(14 * n);
+  if (blk_band.n == 0 || band_k != K) {
+    std::vector<int32_t> hb = {bl.ilo, bl.ihi, bl.jhi - 2 * K, bl.jhi, 0, 0};
+    blk_band.alloc(hb.size());
+    blk_band.upload(hb.data(), stream);
+    CICE_HIP(hipStreamSynchronize(stream));
+    band_k = K;
+  }
+}
+
+void Evp::launch_subcycle_skew_fold(int ksub, int K) {
+  const Block& bl = dom.all[dom.local[0]];
+  const int nx = dom.nx_block;
+  const int jb = bl.jhi - 2 * K, jm = bl.jhi - K + 1;       // first row of the band, first row taken from it
+  CICE_REQUIRE(band[0].n >= 14 * n && band_k == K, "sweep with a fold: the band has not been set up");
+  // 1. the band's two copies start as the state of rows jb-1 .. jhi+1
+  {
+    const size_t off = (size_t)(jb - 2) * nx, len = (size_t)(bl.jhi + 1 - (jb - 1) + 1) * nx;
+    hipLaunchKernelGGL(k_band_rows, dim3((unsigned)((14 * len + 255) / 256)), dim3(256), 0, stream, band[0].p, band[1].p,
+                       (const double*)st[cur].p, n, off, len);
+  }
+  // 2. the sweep, as on an open north boundary (no halo update after it: the band brings the top rows)
+  launch_subcycle_skew(ksub, K, /*flip_and_halo=*/false);
+  // 3. the band, one subcycle at a time
+  for (int s = 0; s < K; ++s) {
+    SubArgs a = make_args();
+    double* in = band[s & 1].p;
+    double* out = band[(s + 1) & 1].p;
+    a.u_in = in; a.v_in = in + n; a.sig_in = in + 2 * n;
+    a.u_out = out; a.v_out = out + n; a.sig_out = out + 2 * n;
+    a.blk = blk_band.p;
+    a.diag_jmin = jm;
+    const int trows = waves * rows_per_wave;
+    a.tiles_x = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
+    a.tiles_y = ((bl.jhi - jb + 1) + (trows - 1) - 1) / (trows - 1);
+    const int nt = a.tiles_x * a.tiles_y;
+    const dim3 g(8 * ((nt + 7) / 8));
+    const bool last = (ksub + s == sc.ndte), damp = sc.evp_damping != 0;
+    switch (waves * 100 + rows_per_wave) {
+      case 801: launch_wr<8, 1>(a, last, damp, g, stream); break;
+      case 802: launch_wr<8, 2>(a, last, damp, g, stream); break;
+      case 804: launch_wr<8, 4>(a, last, damp, g, stream); break;
+      case 401: launch_wr<4, 1>(a, last, damp, g, stream); break;
+      case 402: launch_wr<4, 2>(a, last, damp, g, stream); break;
+      case 404: launch_wr<4, 4>(a, last, damp, g, stream); break;
+      case 408: launch_wr<4, 8>(a, last, damp, g, stream); break;
+      case 1601: launch_wr<16, 1>(a, last, damp, g, stream); break;
+      case 1602: launch_wr<16, 2>(a, last, damp, g, stream); break;
+      default: throw Error{CICE_EINVAL, "unsupported (waves, rows_per_wave) combination"};
+    }
+    halo.update_r8(out, 2, n, /*wrap=*/false, LOC_NECORNER, KIND_VECTOR);   // the fold (:397-402)
+  }
+  // 4. rows jm .. jhi+1 of the band replace the sweep's
+  {
+    const size_t off = (size_t)(jm - 1) * nx, len = (size_t)(bl.jhi + 1 - jm + 1) * nx;
+    hipLaunchKernelGGL(k_band_rows, dim3((unsigned)((14 * len + 255) / 256)), dim3(256), 0, stream, st[1 - cur].p,
+                       (double*)nullptr, (const double*)band[K & 1].p, n, off, len);
+  }
+  cur = 1 - cur;
+  ++flips;
+  CICE_HIP(hipGetLastError());
 }
 
 // ---- resident loop ------------------------------------------------------------------------------------------------
@@ -3407,7 +3504,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
 // subcycles ksub0 .. ksub0+nsub-1: K per sweep where possible, else pairs, else one by one
 void Evp::launch_range(int ksub0, int nsub) {
   const bool fuse = can_fuse();
-  const bool skew = can_skew();
+  const bool skew = can_skew(), skew_fold = !skew && can_skew_fold();
   const int K = skew_levels();
   const int end = ksub0 + nsub - 1;
   for (int k = ksub0; k <= end;) {
@@ -3422,6 +3519,9 @@ void Evp::launch_range(int ksub0, int nsub) {
     };
     if (skew && clear(K)) {
       launch_subcycle_skew(k, K);
+      k += K;
+    } else if (skew_fold && clear(K)) {
+      launch_subcycle_skew_fold(k, K);
       k += K;
     } else if (fuse && clear(2)) {
       launch_subcycle_pair(k);
@@ -3449,7 +3549,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   // CICE4_AMD_COMM_GRAPH=1 once a multi-GPU parity run has passed.
   static const bool env_comm_graph = std::getenv("CICE4_AMD_COMM_GRAPH") != nullptr;
   const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
-  if (can_skew() && skew_gen_pct > 0 && skew_seg_opt == 0) {   // the segment table of the sweep kernel, outside any capture
+  if (!can_skew() && can_skew_fold()) ensure_band(skew_levels());
+  if ((can_skew() || can_skew_fold()) && skew_gen_pct > 0 && skew_seg_opt == 0) {   // the segment table of the sweep kernel, outside any capture
     const int K = skew_levels(), ownl = 62 - 2 * K, seg = skew_seg_rows(K);
     build_skew_rows(K, ((dom.nx_block - 2) + 1 + ownl - 1) / ownl, ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
@@ -3458,7 +3559,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +
-                         (can_skew() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};   // (set_option drops the graph anyway)
+                         (can_skew() || can_skew_fold() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};   // (set_option drops the graph anyway)
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();

@@ -807,6 +807,36 @@ def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
                 assert np.array_equal(got[k][b, 1:1 + nj, 1:1 + ni], ref[k][0, 1 + j0:1 + j0 + nj, 1 + i0:1 + i0 + ni]), (ns, k, b)
 
 
+@pytest.mark.parametrize("nxg,nyg", [(300, 120), (96, 70), (130, 48), (20, 64)])
+@pytest.mark.parametrize("ns", [3, 4], ids=["tripole", "tripoleT"])
+def test_sweeps_on_a_tripole_grid(ctx, nxg, nyg, ns):
+    """K subcycles per sweep where a fold couples the two halves of the top row after every subcycle: the sweep runs as on
+    an open boundary and a band of the top 2K + 1 rows runs the K subcycles one at a time beside it (k_subcycle + the halo
+    update with the fold, on buffers of its own); the band's rows above jhi - K replace the sweep's.  Against one launch
+    per subcycle (pinned to the reference on such a grid): bit for bit, every K, subcycle counts that are no multiple of
+    K, damping, graph and eager, ocean and patchy ice up to the fold."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg, land_rows=0)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True)
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    for ndte, damping in ((NDTE, False), (13, True), (7, False)):
+        ref, _ = _evp_with(ctx, grid, s, ndte, damping, resident=0, skew=0, skew_fold=0)
+        assert np.abs(ref["uvel"][0, -3:]).max() > 1e-4
+        for K, graph in ((4, 1), (3, 1), (2, 0), (6, 1)):
+            if nyg < 4 * K + 6:
+                continue
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+            for key, v in (("resident", 0), ("skew", 1), ("skew_fold", 1), ("skew_min_cells", 0), ("skew_levels", K),
+                           ("use_graph", graph)):
+                ctx.evp_set_option(key, v)
+            assert ctx.evp_get_info("skew_fold") == 1, (K, "the sweep path should apply")
+            ctx.evp(DT, sg)
+            for k in keys:
+                assert np.array_equal(sg[k], ref[k]), (ns, ndte, damping, K, graph, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+
+
 @pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
 def test_tripole_fold_inside_the_loop_against_the_compiled_reference(ns):
     """the same against `call evp(dt)` of the reference itself on a one-block 100 x 116 domain (own process)"""
