@@ -187,3 +187,25 @@ def test_tenth_degree_thermo_sample(ctx, orc):
             cpu = {"Tsfc": a["trcrn"][0], "eicen3": a["eicen"][2], "esnon": a["esnon"][0]}.get(k, a.get(k))
             d = np.abs(gpu[jj, ii] - cpu[jj, ii]).max(); den = max(np.abs(cpu[jj, ii]).max(), 1e-4)
             assert d / den <= TOL_EXP, (n, k, d / den)
+
+
+@pytest.mark.parametrize("ns", [3, 4], ids=["tripole", "tripoleT"])
+def test_tenth_degree_width_with_a_tripole_fold(ctx, ns):
+    """A 3600-wide grid with a tripole north boundary, ocean and ice up to the fold (COSIMA's 0.1-degree grid folds there):
+    K = 4 subcycles per sweep + the band of top rows that carries the fold, against one launch per subcycle followed by the
+    halo update with its fold (the path pinned to the reference on such grids, tests/tripole_evp_case.py): bit for bit."""
+    nxg, nyg, ndte = 3600, 320, 24
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.03, land_rows=0), dom, north_ocean=True)
+    s = synth.evp_state(grid, dom, cover="patchy")
+    out = []
+    for sweep in (0, 1):
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp_init(grid, ndte=ndte, krdg_partic=0, krdg_redist=0)
+        ctx.evp_set_option("resident", 0); ctx.evp_set_option("skew", sweep); ctx.evp_set_option("skew_fold", sweep)
+        assert ctx.evp_get_info("skew_fold") == sweep
+        ctx.evp(DT, sg)
+        out.append(sg)
+    assert np.abs(out[0]["uvel"][0, -3:]).max() > 1e-3
+    for k in PRIMARY + ("strintx", "strocnx", "divu", "shear", "prs_sig"):
+        assert np.array_equal(out[0][k], out[1][k]), (ns, k, np.argwhere(out[0][k] != out[1][k])[:5].tolist())
