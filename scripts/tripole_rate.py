@@ -14,6 +14,8 @@ for name, ns in (("open", 0), ("tripole", 3), ("tripoleT", 4)):
     grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8, land_rows=0), dom, ew_cyclic=True, north_ocean=(ns != 0))
     s = synth.evp_state(grid, dom, seed=8, cover="full")
     ctx.evp_init(grid, ndte=NDTE)
+    if os.environ.get("SKEW_MIN_CELLS"):
+        ctx.evp_set_option("skew_min_cells", int(os.environ["SKEW_MIN_CELLS"]))
     ctx.evp_upload(s); ctx.evp_prepare(DT)
     for _ in range(10 if nxg * nyg < 1000000 else 1):
         ctx.evp_subcycles(1, NDTE)
