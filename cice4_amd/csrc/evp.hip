@@ -2777,8 +2777,10 @@ bool Evp::can_skew_fold() const {
   if (n * 8 * 14 >= (1ull << 32)) return false;
   const Block& bl = dom.all[dom.local[0]];
   if (bl.jhi - bl.jlo + 1 < 4 * skew_levels() + 4) return false;
+  // (the band's ten small launches per sweep cost more on a small grid: 1000 x 800 50 us per subcycle against 54 through
+  //  one launch per subcycle, 720 x 600 38 against 34)
   const long long cells = (long long)(dom.nx_block - 2) * (dom.ny_block - 2);
-  return cells >= skew_min_cells;
+  return cells >= std::max(skew_min_cells, skew_min_cells ? 800000LL : 0LL);
 }
 
 void Evp::ensure_band(int K) {
