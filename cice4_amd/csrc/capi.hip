@@ -110,7 +110,7 @@ struct cice_ctx {
   // thermo
   ThermoParams tp{};
   bool have_thermo = false;
-  DevBuf<unsigned long long> tkey;  // [0] error key, [1] update counter
+  DevBuf<unsigned long long> tkey;  // THERMO_STATUS_WORDS: [0] error key, then the update counters (therm.h)
   // batched thermo state
   struct Batch {
     int nx = 0, ny = 0, nb = 0;
@@ -1156,9 +1156,9 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
     if (!c_->tp.calc_Tsfc) { gather(A_OUT + 0, fsurfn); gather(A_OUT + 1, fcondtopn); gather(A_OUT + 3, flatn); }
     CICE_HIP(hipMemcpyAsync(d.p, hp, (size_t)A_END * m * 8, hipMemcpyHostToDevice, s));
     CICE_HIP(hipMemcpyAsync(li.p, hl, 2 * m * 4, hipMemcpyHostToDevice, s));
-    c_->tkey.alloc(2);
+    c_->tkey.alloc(THERMO_STATUS_WORDS);
     CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
-    CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+    CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, (THERMO_STATUS_WORDS - 1) * 8, s));
     ThermoArgs a{};
     a.p = c_->tp; a.nx = (int)m; a.ny = 1; a.ncat = 1; a.nblocks = 1; a.dt = dt; a.yday = yday;
     a.icells = icells; a.indxi = li.p; a.indxj = li.p + m; a.blk = nullptr;
@@ -1173,7 +1173,7 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
                          &a.snoice};
     for (int k = 0; k < 15; ++k) *outs[k] = P(A_OUT + k);
     a.mlt_onset = P(A_MLT); a.frz_onset = P(A_FRZ);
-    a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+    a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + THERMO_COUNT_STRIDE;
     thermo_launch_list(a, s);
     CICE_HIP(hipMemcpyAsync(hp, d.p, (size_t)A_END * m * 8, hipMemcpyDeviceToHost, s));
     unsigned long long key = 0;
@@ -1219,9 +1219,9 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
     CICE_HIP(hipMemcpyAsync(li.p + np, indxj, (size_t)icells * 4, hipMemcpyHostToDevice, c_->cs()));
   }
   c_->fan.join();
-  c_->tkey.alloc(2);
+  c_->tkey.alloc(THERMO_STATUS_WORDS);
   CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
-  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, (THERMO_STATUS_WORDS - 1) * 8, s));
   ThermoArgs a{};
   a.p = c_->tp; a.nx = nx; a.ny = ny; a.ncat = 1; a.nblocks = 1; a.dt = dt; a.yday = yday;
   a.icells = icells; a.indxi = li.p; a.indxj = li.p + np; a.blk = nullptr;
@@ -1236,7 +1236,7 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
                        &a.snoice};
   for (int k = 0; k < 15; ++k) *outs[k] = P(A_OUT + k);
   a.mlt_onset = P(A_MLT); a.frz_onset = P(A_FRZ);
-  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + THERMO_COUNT_STRIDE;
   thermo_launch_list(a, s);
   c_->fan.fork(s);
   auto down = [&](int plane, double* h, int planes = 1) {
@@ -1287,7 +1287,7 @@ int cice_thermo_batch_alloc(cice_ctx* ctx, int nx, int ny, int nb) {
   t.Sswabs.alloc(nc * NSLYR); t.Iswabs.alloc(nc * NILYR);
   t.out15.alloc(nc * 15);
   t.out15.zero(c_->stream);
-  c_->tkey.alloc(2);
+  c_->tkey.alloc(THERMO_STATUS_WORDS);
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
 }
@@ -1334,9 +1334,16 @@ int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
   CICE_CATCH
 }
 
-// launches the dense kernel; the 16-byte status (error key, update count) lands in `status` once the
+// number of columns updated: the sum of the kernel's counters (therm.h)
+static long long status_count(const unsigned long long* h) {
+  long long n = 0;
+  for (int k = 0; k < THERMO_COUNT_SLOTS; ++k) n += (long long)h[THERMO_COUNT_STRIDE * (1 + k)];
+  return n;
+}
+
+// launches the dense kernel; the status words (error key, update counters) land in `status` once the
 // stream has been synchronised
-static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long status[2], float* elapsed_ms,
+static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long status[THERMO_STATUS_WORDS], float* elapsed_ms,
                        hipEvent_t* ev) {
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
@@ -1344,7 +1351,7 @@ static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long 
   hipStream_t s = c_->stream;
   const size_t nc = (size_t)t.nx * t.ny * t.nb * NCAT;
   CICE_HIP(hipMemsetAsync(c_->tkey.p, 0xff, 8, s));
-  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, 8, s));
+  CICE_HIP(hipMemsetAsync(c_->tkey.p + 1, 0, (THERMO_STATUS_WORDS - 1) * 8, s));
   ThermoArgs a{};
   a.p = c_->tp; a.nx = t.nx; a.ny = t.ny; a.ncat = NCAT; a.nblocks = t.nb; a.dt = dt; a.yday = yday;
   a.icells = 0; a.indxi = nullptr; a.indxj = nullptr; a.blk = t.blk.p;
@@ -1358,7 +1365,7 @@ static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long 
                        &a.snoice};
   for (int k = 0; k < 15; ++k) *outs[k] = t.out15.p + (size_t)k * nc;
   a.mlt_onset = t.mlt_onset.p; a.frz_onset = t.frz_onset.p;
-  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + 1;
+  a.errkey = c_->tkey.p; a.nupdates = c_->tkey.p + THERMO_COUNT_STRIDE;
   if (t.niter.n != nc) {
     t.niter.alloc(nc);
     t.niter.zero(s);
@@ -1384,7 +1391,7 @@ static void batch_step(cice_ctx* c_, double dt, double yday, unsigned long long 
     thermo_launch_dense(a, s);
   }
   if (elapsed_ms) CICE_HIP(hipEventRecord(ev[1], s));
-  CICE_HIP(hipMemcpyAsync(status, c_->tkey.p, 16, hipMemcpyDeviceToHost, s));
+  CICE_HIP(hipMemcpyAsync(status, c_->tkey.p, THERMO_STATUS_WORDS * 8, hipMemcpyDeviceToHost, s));
 }
 
 const char* cice_build_flavour(void) {
@@ -1445,7 +1452,7 @@ int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_u
                            int32_t* bstop, float* elapsed_ms) {
   CICE_TRY(ctx)
   CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
-  unsigned long long h[2];
+  unsigned long long h[THERMO_STATUS_WORDS];
   hipEvent_t ev[2] = {nullptr, nullptr};
   batch_step(c_, dt, yday, h, elapsed_ms, ev);
   CICE_HIP(hipStreamSynchronize(c_->stream));
@@ -1454,7 +1461,7 @@ int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_u
     (void)hipEventDestroy(ev[0]);
     (void)hipEventDestroy(ev[1]);
   }
-  if (n_updates) *n_updates = (long long)h[1];
+  if (n_updates) *n_updates = status_count(h);
   decode_err(h[0], c_->tb.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
   CICE_CATCH
 }
@@ -1598,7 +1605,7 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
   }
   // aicen_init of merge_fluxes = the concentrations before the column update (CICE_RunMod.F90:342-355)
   CICE_HIP(hipMemcpyAsync(t.mrg_in.p, t.aicen.p, nc * 8, hipMemcpyDeviceToDevice, s));
-  unsigned long long h[2];
+  unsigned long long h[THERMO_STATUS_WORDS];
   batch_step(c_, dt, yday, h, nullptr, nullptr);
   batch_merge(c_, mg, t.mrg_in.p, atm != nullptr, MRG_RUN);
   c_->fan.fork(s);   // ... and every download after the last kernel
@@ -1616,7 +1623,7 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
   if (fz->rside) CICE_HIP(hipMemcpyAsync(fz->rside, t.fz_in.p + 6 * n2, n2 * 8, hipMemcpyDeviceToHost, c_->cs()));
   c_->fan.join();
   CICE_HIP(hipStreamSynchronize(s));
-  if (n_updates) *n_updates = (long long)h[1];
+  if (n_updates) *n_updates = status_count(h);
   decode_err(h[0], t.nx, NCAT, nullptr, nullptr, l_stop, istop, jstop, nstop, bstop);
 }
 

@@ -19,6 +19,16 @@ struct ThermoParams {  // module state of ice_therm_vertical (:45-79) after init
 //   Sswabs / Iswabs:    (((b*ncat + n)*NSLYR + k)*np + q)       (NILYR for Iswabs)
 //   forcing, onsets:    (b*np + q)
 // The single-call form uses ncat = 1, nblocks = 1 and an index list.
+
+// The batched kernels count the columns they update.  One counter for the whole launch costs one atomic per
+// wavefront on ONE address, and the memory side takes those one at a time: 9,715 of them at gx1 size = 132 us, the
+// whole kernel's duration with nothing else in it (measured on a build that only loads and stores: 132 us with the
+// counter, 56 us without).  So the counter is THERMO_COUNT_SLOTS words on different cache lines, picked by workgroup
+// index; the host adds them up after the download of the status words.
+constexpr int THERMO_COUNT_SLOTS = 64;
+constexpr int THERMO_COUNT_STRIDE = 16;                                            // words (128 B)
+constexpr int THERMO_STATUS_WORDS = THERMO_COUNT_STRIDE * (1 + THERMO_COUNT_SLOTS);  // [0] error key, [16 + 16 i] counters
+
 struct ThermoArgs {
   ThermoParams p;
   int nx, ny, ncat, nblocks;
@@ -33,7 +43,8 @@ struct ThermoArgs {
   double *fsurfn, *fcondtopn, *fsensn, *flatn, *fswabsn, *flwoutn, *evapn, *freshn, *fsaltn, *fhocnn,
       *meltt, *melts, *meltb, *congel, *snoice, *mlt_onset, *frz_onset;
   unsigned long long* errkey;   // atomicMin target, initialised to ~0
-  unsigned long long* nupdates; // dense mode: number of columns updated
+  unsigned long long* nupdates; // dense mode: THERMO_COUNT_SLOTS counters, THERMO_COUNT_STRIDE words apart; their sum =
+                                // the number of columns updated
   unsigned char* niter;         // dense mode (may be NULL): iterations the implicit solve of every column took
 };
 

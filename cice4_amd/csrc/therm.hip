@@ -656,13 +656,9 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
 #pragma unroll
   for (int k = 0; k < NS; ++k) es[k] = a.esnon[sq + (size_t)k * np];
   const double aic = a.aicen[c2d];
-  const unsigned stage0 = init_profile(P, aic, a.vicen[c2d], a.vsnon[c2d], a.trcrn[tq], ei, es, c);
-  if (stage0) {
-    atomicMin(a.errkey, ((unsigned long long)cb << 44) | ((unsigned long long)stage0 << 40) | order);
-    if (ZERO) zero_outputs<CALC>(a, c2d);
-    return;
-  }
-  const double worki = c.hin, works = c.hsn;
+  // the forcing and shortwave terms are fetched together with the state, ahead of the branch on the profile's
+  // validity (the compiler may not move a load above it): one wait for memory instead of two (no measurable
+  // difference: the kernel is bound by its arithmetic)
   f.rhoa = a.rhoa[f2d]; f.flw = a.flw[f2d]; f.potT = a.potT[f2d]; f.Qa = a.Qa[f2d];
   f.Tbot = a.Tbot[f2d];
   f.shcoef = a.shcoef[c2d]; f.lhcoef = a.lhcoef[c2d];
@@ -671,6 +667,29 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
   for (int k = 0; k < NS; ++k) f.Sswabs[k] = a.Sswabs[ssq + (size_t)k * np];
 #pragma unroll
   for (int k = 0; k < NI; ++k) f.Iswabs[k] = a.Iswabs[iq + (size_t)k * np];
+#ifdef THERMO_FLOOR   // timing-only build (scripts/build_ab_therm.sh floor -DTHERMO_FLOOR): the column's loads and stores
+  {                    // without its arithmetic -- what the access pattern alone costs (wrong results)
+    const double t = aic + a.vicen[c2d] + a.vsnon[c2d] + a.trcrn[tq] + f.rhoa + f.flw + f.potT + f.Qa + f.Tbot + f.shcoef +
+                     f.lhcoef + f.fswthrun + a.fbot[f2d] + a.fsnow[f2d] + a.mlt_onset[f2d] + a.frz_onset[f2d];
+    a.fswsfc[c2d] = f.fswsfc + t; a.fswint[c2d] = f.fswint + t;
+    for (int k = 0; k < NS; ++k) a.Sswabs[ssq + (size_t)k * np] = f.Sswabs[k] + t;
+    for (int k = 0; k < NI; ++k) a.Iswabs[iq + (size_t)k * np] = f.Iswabs[k] + t;
+    double* const outs[15] = {a.fsurfn, a.fcondtopn, a.fsensn, a.flatn, a.fswabsn, a.flwoutn, a.fhocnn, a.evapn,
+                              a.meltt, a.melts, a.meltb, a.congel, a.snoice, a.freshn, a.fsaltn};
+    for (int k = 0; k < 15; ++k) outs[k][c2d] = t + k;
+    a.vicen[c2d] = t + 15; a.vsnon[c2d] = t + 16; a.trcrn[tq] = t + 17;
+    for (int k = 0; k < NI; ++k) a.eicen[eq + (size_t)k * np] = ei[k] + t;
+    for (int k = 0; k < NS; ++k) a.esnon[sq + (size_t)k * np] = es[k] + t;
+    return;
+  }
+#endif
+  const unsigned stage0 = init_profile(P, aic, a.vicen[c2d], a.vsnon[c2d], a.trcrn[tq], ei, es, c);
+  if (stage0) {
+    atomicMin(a.errkey, ((unsigned long long)cb << 44) | ((unsigned long long)stage0 << 40) | order);
+    if (ZERO) zero_outputs<CALC>(a, c2d);
+    return;
+  }
+  const double worki = c.hin, works = c.hsn;
   f.fsurfn = f.fcondtopn = f.fsensn = f.flatn = f.fswabsn = f.flwoutn = c0;
   if (!CALC) {  // intent(in) when calc_Tsfc = F (:213-217)
     f.fsurfn = a.fsurfn[c2d]; f.fcondtopn = a.fcondtopn[c2d]; f.flatn = a.flatn[c2d];
@@ -694,8 +713,8 @@ __device__ __forceinline__ void column(const ThermoArgs& a, size_t q, int n, int
     return;
   }
   g.fbot = a.fbot[f2d]; g.fsnow = a.fsnow[f2d];
-  g.meltt = g.melts = g.meltb = g.congel = g.snoice = c0;
   g.mlt_onset = a.mlt_onset[f2d]; g.frz_onset = a.frz_onset[f2d];
+  g.meltt = g.melts = g.meltb = g.congel = g.snoice = c0;
   const double mlt0 = g.mlt_onset, frz0 = g.frz_onset;
   thickness_changes(P, a.dt, a.yday, c, f, g);
   a.fhocnn[c2d] = g.fhocnn; a.evapn[c2d] = g.evapn; a.meltt[c2d] = g.meltt; a.melts[c2d] = g.melts;
@@ -777,7 +796,7 @@ __global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_dense(co
   if (active) column<CALC, true>(a, q, n, b, (unsigned long long)q);
   else zero_outputs<CALC>(a, c2d);
   unsigned long long cnt = __popcll(__ballot(active));
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates + (size_t)(blockIdx.x % THERMO_COUNT_SLOTS) * THERMO_COUNT_STRIDE, cnt);
 }
 
 // ---- homogeneous wavefronts: columns sorted by the work they are expected to take ---------------------------------
@@ -888,7 +907,7 @@ __global__ __launch_bounds__(256, CICE_THERMO_MIN_BLOCKS) void k_thermo_perm(con
   if (active) column<CALC, true>(a, q, n, b, (unsigned long long)q);
   else zero_outputs<CALC>(a, cb * np + q);
   unsigned long long cnt = __popcll(__ballot(active));
-  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates, cnt);
+  if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(a.nupdates + (size_t)(blockIdx.x % THERMO_COUNT_SLOTS) * THERMO_COUNT_STRIDE, cnt);
 }
 
 // merge_fluxes (ice_flux.F90:730-760): one lane per cell accumulates the categories in order
