@@ -2043,7 +2043,7 @@ __global__ __launch_bounds__(256) void k_finish(const PrepArgs a) {
   a.strocnyT[t] = yT;
 }
 
-__global__ __launch_bounds__(256) void k_count_active(const PrepArgs a) {
+__global__ __launch_bounds__(1024) void k_count_active(const PrepArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
   unsigned long long nt = 0, nu = 0;
@@ -2059,9 +2059,16 @@ __global__ __launch_bounds__(256) void k_count_active(const PrepArgs a) {
     nt += __shfl_down(nt, off);
     nu += __shfl_down(nu, off);
   }
-  if ((threadIdx.x & 63) == 0) {
-    if (nt) atomicAdd(&a.counters[0], nt);
-    if (nu) atomicAdd(&a.counters[1], nu);
+  // one pair of atomics per workgroup of 1,024, not per wavefront: atomics on one address are served one at a time
+  // (13.6 ns each, therm.h), which made this kernel 3.2 ms at 0.1 degree
+  __shared__ unsigned long long s_n[2][16];
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_n[0][w] = nt; s_n[1][w] = nu; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    unsigned long long sum = 0;
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) sum += s_n[threadIdx.x][k];
+    if (sum) atomicAdd(&a.counters[threadIdx.x], sum);
   }
 }
 
@@ -2435,7 +2442,7 @@ void Evp::active_cells(long long* nt, long long* nu) {
     a.nx = dom.nx_block; a.ny = dom.ny_block; a.nblocks = dom.nblocks(); a.n = n; a.blk = blk.p;
     a.icetmask = icetmask.p; a.iceumask = iceumask.p; a.counters = counters.p;
     counters.zero(stream);
-    hipLaunchKernelGGL(k_count_active, grid1(n), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_count_active, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, stream, a);
     CICE_HIP(hipGetLastError());
     counted = true;
   }

@@ -82,7 +82,9 @@ def main():
                 bad = np.argwhere(got[l] != so[k][g])
                 raise AssertionError((k, "local block", l, "global", g, len(bad), bad[:5].tolist()))
     assert np.abs(so["uvel"]).max() > 0.01
-    print("MPI-EVP-OK", int(os.environ.get("PMI_RANK", "-1")), gids, flush=True)
+    # one write per task: the tasks share the pipe, and the pieces of a multi-argument print can interleave
+    sys.stdout.write("MPI-EVP-OK %d %s\n" % (int(os.environ.get("PMI_RANK", "-1")), gids))
+    sys.stdout.flush()
     ref.lib.ref_end_run()
 
 

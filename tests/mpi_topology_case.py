@@ -37,7 +37,7 @@ def main():
     # the same map from the product's host logic, independently of the Fortran check
     dom = lib.Context().domain_create(nxg, nyg, bsx, bsy, ew=1, ns=0, rank=rank, npx=npx, npy=npy)
     assert [int(g) for g in dom["gid"]] == gids, (rank, dom["gid"], gids)
-    print("TOPO-OK", rank, f"{npx}x{npy}", gids, flush=True)
+    print(f"TOPO-OK {rank} {npx}x{npy} {gids}\n", end="", flush=True)   # one write: the tasks share the pipe
     ref.lib.ref_end_run()
 
 

@@ -159,5 +159,5 @@ def test_mpi_job_of_the_fortran_dropin_on_one_gpu(cfg, nprocs, shape):
     p = subprocess.run([mpiexec, "-n", str(nprocs), sys.executable, os.path.join(ROOT, "tests", "mpi_evp_case.py"), cfg,
                         str(nprocs), shape] + (["loop"] if cfg == "gx3s2" else []), capture_output=True, text=True, timeout=500,
                        cwd="/tmp")
-    ok = [l for l in p.stdout.splitlines() if l.startswith("MPI-EVP-OK")]
-    assert p.returncode == 0 and len(ok) == nprocs, p.stdout[-2500:] + p.stderr[-2500:]
+    # counted, not matched line by line: the tasks write to one pipe and two of their lines can run together
+    assert p.returncode == 0 and p.stdout.count("MPI-EVP-OK") == nprocs, p.stdout[-2500:] + p.stderr[-2500:]
