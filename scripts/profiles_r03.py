@@ -11,9 +11,17 @@ commit = open(os.path.join(O, "commit.txt")).read().strip()
 WANT = ("k_evp_resident", "k_subcycle", "k_thermo", "k_diag_copy8")
 
 
+def fresh(files):
+    """gpurun merges a run's files into what earlier runs left in gpurun_out/: only the files of the newest run count."""
+    if not files:
+        return files
+    newest = max(os.path.getmtime(f) for f in files)
+    return [f for f in files if os.path.getmtime(f) > newest - 1800]
+
+
 def collect(d):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0, 0.0]))
-    for f in glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True):
+    for f in fresh(glob.glob(os.path.join(O, d, "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
             a = acc[r["Kernel_Name"]][r["Counter_Name"]]
             a[0] += 1; a[1] += float(r["Counter_Value"]); a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
@@ -73,7 +81,7 @@ with open(os.path.join(P, "r03_sq_counters.csv"), "w", newline="") as f:
     w.writerows(rows)
 # ---- kernel statistics
 for src, dst in (("stats_default", "r03_default_bench_kernel_stats.csv"), ("model", "r03_whole_model_gx1_kernel_stats.csv")):
-    fs = glob.glob(os.path.join(O, src, "**", "*kernel_stats.csv"), recursive=True)
+    fs = fresh(glob.glob(os.path.join(O, src, "**", "*kernel_stats.csv"), recursive=True))
     if fs:
         with open(fs[0]) as fi, open(os.path.join(P, dst), "w") as fo:
             fo.write(f"# rocprofv3 --kernel-trace --stats, commit {commit}\n")
