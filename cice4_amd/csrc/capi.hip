@@ -615,7 +615,8 @@ int cice_domain_list(const cice_ctx* ctx, const char* name, int loc, int* n, int
 int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int ew, int ns, int rank,
                              int nranks, int overlap) {
   CICE_TRY(ctx)
-  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 2, "boundary type must be 0 (open), 1 (cyclic) or 2 (closed)");
+  CICE_REQUIRE(ew >= 0 && ew <= 2 && ns >= 0 && ns <= 4,
+               "boundary type must be 0 (open), 1 (cyclic), 2 (closed) or, north-south only, 3 (tripole) / 4 (tripoleT)");
   c_->dom.self_comm = std::getenv("CICE4_AMD_SELF_COMM") != nullptr;
   const char* msg = c_->dom.create_slabs(nxg, nyg, nblocks_y, ew, ns, rank, nranks, overlap);
   if (msg[0]) throw Error{CICE_EINVAL, std::string("cice_domain_create_slabs: ") + msg};

@@ -71,6 +71,91 @@ const char* Domain::create_map(int nx_global, int ny_global, int block_size_x, i
   return build(owner, lid);
 }
 
+// Tripole fold lists of the blocks as they stand in `all` / `local` (block map or slabs).
+void Domain::build_fold() {
+  fold = false; fold_lsrc.clear(); fold_bidx.clear(); fold_send.clear(); fold_recv.clear();
+  for (int l = 0; l < 4; ++l) {
+    fold_out[l].dst.clear(); fold_out[l].src.clear(); fold_lo[l].clear(); fold_hi[l].clear();
+  }
+  if (!tripole()) return;
+  const long long np = (long long)nx_block * ny_block;
+  auto addr = [&](const Block& b, int i, int j) {  // 1-based (i,j)
+    return (int32_t)((long long)b.local_id * np + (long long)(j - 1) * nx_block + (i - 1));
+  };
+  // The fold buffer holds the top R physical rows of the whole grid: R = 2 for a fold through U points, 3 for one
+  // through T points (tripoleRows).  Ranks that own a block of the top block row each assemble the whole buffer.
+  const int R = fold_rows();
+  const bool tfold = ns == BND_TRIPOLET;
+  std::vector<char> top_rank(nranks, 0);
+  for (const Block& b : all)
+    if (b.jb == nby - 1 && b.owner >= 0) top_rank[b.owner] = 1;
+  fold = top_rank[rank] != 0;
+  std::map<int, HaloMsg> fs, fr;
+  for (const Block& s : all) {   // 1. top R physical rows of every top-row block -> buffer (:3702-3722)
+    if (s.jb != nby - 1 || s.owner < 0) continue;
+    for (int r = 0; r < R; ++r)
+      for (int i = s.ilo; i <= s.ihi; ++i) {
+        const int32_t b = (int32_t)(r * nxg + s.i0 + (i - s.ilo));
+        // U-fold: rows jhi-1, jhi.  T-fold: the 'north' message fills the three buffer rows with jhi-2, jhi-1, jhi
+        // (:3702-3722), then the 'northeast' / 'northwest' messages of the same block, which kept the U-fold's two
+        // rows, overwrite rows 1 and 2 with jhi-1, jhi (:3813-3826, :3859-3872): what the update works on is
+        // jhi-1, jhi, jhi -- reproduced here as the reference runs, not as its comments describe it
+        const int j = tfold ? s.jhi - 1 + std::min(r, 1) : s.jhi - 1 + r;
+        if (s.owner == rank) {
+          fold_lsrc.push_back(addr(s, i, j));
+          fold_bidx.push_back(b);
+          for (int p = 0; p < nranks; ++p)
+            if (p != rank && top_rank[p]) {
+              HaloMsg& m = fs[p]; m.peer = p; m.addr.push_back(addr(s, i, j));
+            }
+        } else if (fold) {
+          HaloMsg& m = fr[s.owner]; m.peer = s.owner; m.addr.push_back(b);
+        }
+      }
+  }
+  for (auto& kv : fs) fold_send.push_back(std::move(kv.second));
+  for (auto& kv : fr) fold_recv.push_back(std::move(kv.second));
+  if (fold) {
+    // 2. symmetry of the degenerate top row of the buffer (serial/ice_boundary.F90:725-823); 1-based i as there.
+    // U-fold: NE-corner and N-face fields lie on the fold; T-fold: centre and E-face fields do.
+    const int top = (R - 1) * nxg;
+    auto pair = [&](int loc, int i, int idst) {
+      fold_lo[loc - 1].push_back(top + i - 1);
+      fold_hi[loc - 1].push_back(top + idst - 1);
+    };
+    if (tfold) {
+      for (int i = 2; i <= nxg / 2; ++i) pair(LOC_CENTER, i, nxg - i + 2);      // :735-743
+      for (int i = 1; i <= nxg / 2; ++i) pair(LOC_EFACE, i, nxg + 1 - i);       // :757-765
+    } else {
+      for (int i = 1; i <= nxg / 2 - 1; ++i) pair(LOC_NECORNER, i, nxg - i);    // :792-800
+      for (int i = 1; i <= nxg / 2; ++i) pair(LOC_NFACE, i, nxg + 1 - i);       // :814-822
+    }
+    // 3. copy out (:3726-3750 list, :831-866 offsets): rows jhi (jj = 1) and jhi+1 (jj = 2) of every
+    // top-row block of this rank, columns 1 .. ihi+1.  Offsets in the order centre, NE corner, N face, E face.
+    const int ioffU[4] = {0, 1, 0, 1}, joffU[4] = {0, 1, 1, 0};
+    const int ioffT[4] = {-1, 0, -1, 0}, joffT[4] = {0, 1, 1, 0};
+    const int* ioff = tfold ? ioffT : ioffU;
+    const int* joff = tfold ? joffT : joffU;
+    for (int gid : local) {
+      const Block& d = all[gid];
+      if (d.jb != nby - 1) continue;
+      for (int jj = 1; jj <= 2; ++jj)
+        for (int i = 1; i <= d.ihi + 1; ++i) {
+          const int ig1 = ((d.i0 + (i - d.ilo)) % nxg + nxg) % nxg + 1;  // i_glob(i), cyclic
+          for (int l = 0; l < 4; ++l) {
+            int iSrc = nxg - ig1 + 1 - ioff[l];
+            const int jSrc = 4 - jj - joff[l];
+            if (iSrc == 0) iSrc = nxg;
+            if (iSrc > nxg) iSrc -= nxg;
+            if (jSrc > R || jSrc < 1) continue;
+            fold_out[l].dst.push_back(addr(d, i, d.jhi + jj - 1));
+            fold_out[l].src.push_back((int32_t)((jSrc - 1) * nxg + iSrc - 1));
+          }
+        }
+    }
+  }
+}
+
 const char* Domain::build(const std::vector<int>& owner, const std::vector<int>& lid) {
   nx_block = bsx + 2; ny_block = bsy + 2;
   if (ew < 0 || ew > BND_CLOSED) return "east-west boundary must be open, cyclic or closed";
@@ -83,10 +168,6 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
   }
   all.clear(); local.clear(); hsrc.clear(); hdst.clear(); hfill.clear(); send.clear(); recv.clear();
   rsrc.clear(); rdst.clear(); overlap = 0;
-  fold = false; fold_lsrc.clear(); fold_bidx.clear(); fold_send.clear(); fold_recv.clear();
-  for (int l = 0; l < 4; ++l) {
-    fold_out[l].dst.clear(); fold_out[l].src.clear(); fold_lo[l].clear(); fold_hi[l].clear();
-  }
 
   for (int jb = 0; jb < nby; ++jb)
     for (int ib = 0; ib < nbx; ++ib) {
@@ -157,80 +238,7 @@ const char* Domain::build(const std::vector<int>& owner, const std::vector<int>&
   for (auto& kv : smap) send.push_back(std::move(kv.second));
   for (auto& kv : rmap) recv.push_back(std::move(kv.second));
 
-  if (tripole()) {
-    // The fold buffer holds the top R physical rows of the whole grid: R = 2 for a fold through U points, 3 for one
-    // through T points (tripoleRows).  Ranks that own a block of the top block row each assemble the whole buffer.
-    const int R = fold_rows();
-    const bool tfold = ns == BND_TRIPOLET;
-    std::vector<char> top_rank(nranks, 0);
-    for (const Block& b : all)
-      if (b.jb == nby - 1 && b.owner >= 0) top_rank[b.owner] = 1;
-    fold = top_rank[rank] != 0;
-    std::map<int, HaloMsg> fs, fr;
-    for (const Block& s : all) {   // 1. top R physical rows of every top-row block -> buffer (:3702-3722)
-      if (s.jb != nby - 1 || s.owner < 0) continue;
-      for (int r = 0; r < R; ++r)
-        for (int i = s.ilo; i <= s.ihi; ++i) {
-          const int32_t b = (int32_t)(r * nxg + s.i0 + (i - s.ilo));
-          // U-fold: rows jhi-1, jhi.  T-fold: the 'north' message fills the three buffer rows with jhi-2, jhi-1, jhi
-          // (:3702-3722), then the 'northeast' / 'northwest' messages of the same block, which kept the U-fold's two
-          // rows, overwrite rows 1 and 2 with jhi-1, jhi (:3813-3826, :3859-3872): what the update works on is
-          // jhi-1, jhi, jhi -- reproduced here as the reference runs, not as its comments describe it
-          const int j = tfold ? s.jhi - 1 + std::min(r, 1) : s.jhi - 1 + r;
-          if (s.owner == rank) {
-            fold_lsrc.push_back(addr(s, i, j));
-            fold_bidx.push_back(b);
-            for (int p = 0; p < nranks; ++p)
-              if (p != rank && top_rank[p]) {
-                HaloMsg& m = fs[p]; m.peer = p; m.addr.push_back(addr(s, i, j));
-              }
-          } else if (fold) {
-            HaloMsg& m = fr[s.owner]; m.peer = s.owner; m.addr.push_back(b);
-          }
-        }
-    }
-    for (auto& kv : fs) fold_send.push_back(std::move(kv.second));
-    for (auto& kv : fr) fold_recv.push_back(std::move(kv.second));
-    if (fold) {
-      // 2. symmetry of the degenerate top row of the buffer (serial/ice_boundary.F90:725-823); 1-based i as there.
-      // U-fold: NE-corner and N-face fields lie on the fold; T-fold: centre and E-face fields do.
-      const int top = (R - 1) * nxg;
-      auto pair = [&](int loc, int i, int idst) {
-        fold_lo[loc - 1].push_back(top + i - 1);
-        fold_hi[loc - 1].push_back(top + idst - 1);
-      };
-      if (tfold) {
-        for (int i = 2; i <= nxg / 2; ++i) pair(LOC_CENTER, i, nxg - i + 2);      // :735-743
-        for (int i = 1; i <= nxg / 2; ++i) pair(LOC_EFACE, i, nxg + 1 - i);       // :757-765
-      } else {
-        for (int i = 1; i <= nxg / 2 - 1; ++i) pair(LOC_NECORNER, i, nxg - i);    // :792-800
-        for (int i = 1; i <= nxg / 2; ++i) pair(LOC_NFACE, i, nxg + 1 - i);       // :814-822
-      }
-      // 3. copy out (:3726-3750 list, :831-866 offsets): rows jhi (jj = 1) and jhi+1 (jj = 2) of every
-      // top-row block of this rank, columns 1 .. ihi+1.  Offsets in the order centre, NE corner, N face, E face.
-      const int ioffU[4] = {0, 1, 0, 1}, joffU[4] = {0, 1, 1, 0};
-      const int ioffT[4] = {-1, 0, -1, 0}, joffT[4] = {0, 1, 1, 0};
-      const int* ioff = tfold ? ioffT : ioffU;
-      const int* joff = tfold ? joffT : joffU;
-      for (int gid : local) {
-        const Block& d = all[gid];
-        if (d.jb != nby - 1) continue;
-        for (int jj = 1; jj <= 2; ++jj)
-          for (int i = 1; i <= d.ihi + 1; ++i) {
-            const int ig1 = ((d.i0 + (i - d.ilo)) % nxg + nxg) % nxg + 1;  // i_glob(i), cyclic
-            for (int l = 0; l < 4; ++l) {
-              int iSrc = nxg - ig1 + 1 - ioff[l];
-              const int jSrc = 4 - jj - joff[l];
-              if (iSrc == 0) iSrc = nxg;
-              if (iSrc > nxg) iSrc -= nxg;
-              if (jSrc > R || jSrc < 1) continue;
-              fold_out[l].dst.push_back(addr(d, i, d.jhi + jj - 1));
-              fold_out[l].src.push_back((int32_t)((jSrc - 1) * nxg + iSrc - 1));
-            }
-          }
-      }
-    }
-  }
+  build_fold();
   return "";
 }
 
@@ -242,8 +250,16 @@ const char* Domain::create_slabs(int nx_global, int ny_global, int nblocks_y, in
   if (rank_ < 0 || rank_ >= nranks_) return "rank out of range";
   if (overlap_rows < 0) return "overlap < 0";
   if (ns_bnd == BND_CYCLIC) return "cyclic north-south boundary is not supported with slabs";
+  if (ns_bnd < 0 || ns_bnd > BND_TRIPOLET) return "unknown north-south boundary";
   nxg = nx_global; nyg = ny_global; bsx = nxg; bsy = nyg / nblocks_y;
   if (overlap_rows > bsy) return "overlap larger than a slab";
+  if (ns_bnd == BND_TRIPOLE || ns_bnd == BND_TRIPOLET) {
+    // the fold works on the top rows of the top slab, every subcycle; no other slab's extension may reach them
+    if (ew_bnd != BND_CYCLIC) return "a tripole north boundary needs a cyclic east-west boundary";
+    if (nxg % 2) return "a tripole north boundary needs an even nx_global";
+    if (bsy < 4) return "tripole: slabs of fewer than 4 rows";
+    if (nblocks_y > 1 && overlap_rows > bsy - 4) return "tripole: the overlap must leave the top 4 rows of the top slab alone";
+  }
   overlap = overlap_rows;
   nx_block = bsx + 2; ny_block = bsy + 2 * overlap + 2;
   nbx = 1; nby = nblocks_y; npx = 1; npy = nranks_; nranks = nranks_; rank = rank_;
@@ -305,6 +321,7 @@ const char* Domain::create_slabs(int nx_global, int ny_global, int nblocks_y, in
     }
   for (auto& kv : smap) send.push_back(std::move(kv.second));
   for (auto& kv : rmap) recv.push_back(std::move(kv.second));
+  build_fold();
   return "";
 }
 

@@ -76,6 +76,7 @@ struct Domain {
 
   int nblocks() const { return (int)local.size(); }
   const char* build(const std::vector<int>& owner, const std::vector<int>& lid);  // lists for the block map
+  void build_fold();                                                             // tripole fold lists of the blocks in `all`
   // Returns empty string on success, else an error message.
   const char* create(int nx_global, int ny_global, int block_size_x, int block_size_y, int ew_bnd,
                      int ns_bnd, int rank_, int npx_, int npy_);

@@ -2382,7 +2382,10 @@ void Evp::prepare(double dt) {
   hipLaunchKernelGGL(k_prep2, g, blk256, 0, stream, a);                       // :280-316
   hipLaunchKernelGGL(k_strength, g, blk256, 0, stream, a);                    // :322-332
   halo.update_r8(strength.p, 1, n, true, LOC_CENTER, KIND_SCALAR);            // :337
-  if (dom.overlap > 0) halo.update_r8(st[cur].p, 14, n);   // overlap rows of u, v AND sigma from their owners
+  if (dom.overlap > 0) {   // overlap rows of u, v AND sigma from their owners; a tripole fold only ever touches u, v
+    halo.update_r8(st[cur].p, 14, n, true, LOC_CENTER, KIND_SCALAR, 0.0, HALO_COPIES);
+    if (halo.has_fold()) halo.update_r8(uv[cur].p, 2, n, false, LOC_NECORNER, KIND_VECTOR, 0.0, HALO_FOLD);
+  }
   else halo.update_r8(uv[cur].p, 2, n, true, LOC_NECORNER, KIND_VECTOR);      // :340-343
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
@@ -2532,8 +2535,11 @@ void Evp::after_subcycle(int ksub) {
   // `overlap` subcycles and after the last one (the overlap rows are recomputed in between and
   // lose one valid row per side per subcycle).
   if (dom.overlap > 0) {
-    if (ksub % dom.overlap == 0 || ksub == sc.ndte) halo.update_r8(st[cur].p, 14, n, /*wrap=*/!fwd);
-    else if (!fwd) halo.update_r8(uv[cur].p, 2, n, true);
+    // (a tripole fold on the top slab: the refresh moves whole rows of all 14 planes and folds nothing; the fold of
+    //  u, v follows it, after every subcycle, as on any tripole grid)
+    if (ksub % dom.overlap == 0 || ksub == sc.ndte) halo.update_r8(st[cur].p, 14, n, /*wrap=*/!fwd, LOC_CENTER, KIND_SCALAR, 0.0, HALO_COPIES);
+    else if (!fwd) halo.update_r8(uv[cur].p, 2, n, true, LOC_CENTER, KIND_SCALAR, 0.0, HALO_COPIES);
+    if (halo.has_fold()) halo.update_r8(uv[cur].p, 2, n, false, LOC_NECORNER, KIND_VECTOR, 0.0, HALO_FOLD);
   } else if (halo.has_refresh() || !fwd || halo.has_fold()) {
     halo.update_r8(uv[cur].p, 2, n, /*wrap=*/!fwd, LOC_NECORNER, KIND_VECTOR);   // :397-402
   }
@@ -2565,7 +2571,7 @@ static void launch2_w(const SubArgs& a, bool last, bool damp, dim3 g, hipStream_
 bool Evp::can_fuse() const {
   if (!fuse_on || !halo.fwd_ok()) return false;
   if (dom.nbx != 1) return false;
-  if (dom.overlap > 0) return dom.overlap % 2 == 0;
+  if (dom.overlap > 0) return dom.overlap % 2 == 0 && !halo.has_fold();   // (the top slab of a tripole grid folds after every subcycle)
   // a tripole fold rewrites the top row and its ghost row after every subcycle
   return dom.nby == 1 && dom.ns != BND_CYCLIC && !dom.tripole() && !halo.has_refresh();
 }
@@ -2780,7 +2786,10 @@ __global__ __launch_bounds__(256) void k_band_rows(double* __restrict__ dst, dou
 bool Evp::can_skew_fold() const {
   static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW"); return e && e[0] == '0'; }();
   if (!skew_on || !skew_fold_on || env_off || !fuse_on || !halo.fwd_ok() || !(derive_ok && derive_on)) return false;
-  if (!halo.has_fold() || halo.multi_rank() || halo.has_refresh() || dom.nblocks() != 1 || dom.overlap > 0) return false;
+  if (!halo.has_fold() || dom.nblocks() != 1) return false;
+  // one block of the whole grid, or the top slab of a wide-halo domain (its overlap rows are refreshed between sweeps)
+  if (dom.overlap == 0 && (halo.multi_rank() || halo.has_refresh())) return false;
+  if (dom.overlap > 0 && dom.overlap % skew_levels()) return false;
   if (n * 8 * 14 >= (1ull << 32)) return false;
   const Block& bl = dom.all[dom.local[0]];
   if (bl.jhi - bl.jlo + 1 < 4 * skew_levels() + 4) return false;
@@ -2843,7 +2852,7 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
       case 1602: launch_wr<16, 2>(a, last, damp, g, stream); break;
       default: throw Error{CICE_EINVAL, "unsupported (waves, rows_per_wave) combination"};
     }
-    halo.update_r8(out, 2, n, /*wrap=*/false, LOC_NECORNER, KIND_VECTOR);   // the fold (:397-402)
+    halo.update_r8(out, 2, n, /*wrap=*/false, LOC_NECORNER, KIND_VECTOR, 0.0, HALO_FOLD);   // the fold (:397-402)
   }
   // 4. rows jm .. jhi+1 of the band replace the sweep's
   {
@@ -2853,6 +2862,11 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
   }
   cur = 1 - cur;
   ++flips;
+  if (dom.overlap > 0) {   // top slab of a wide-halo domain: the refresh that is due after this sweep's last subcycle
+    const int last = ksub + K - 1;
+    if (last % dom.overlap == 0 || last == sc.ndte)
+      halo.update_r8(st[cur].p, 14, n, /*wrap=*/false, LOC_CENTER, KIND_SCALAR, 0.0, HALO_COPIES);
+  }
   CICE_HIP(hipGetLastError());
 }
 

@@ -24,6 +24,8 @@ LocalLink* local_link_get(int link_id, int nranks);   // the link of that id (cr
 LocalLink* shm_link_open(const char* name, int rank, int nranks, size_t box_bytes);
 void link_close(LocalLink* l);
 
+enum HaloParts { HALO_COPIES = 1, HALO_FOLD = 2, HALO_ALL = 3 };
+
 class Halo {
  public:
   Halo() = default;
@@ -41,8 +43,10 @@ class Halo {
   // the caller -- the subcycle kernel -- has written those ghosts itself.
   // loc / kind (FieldLoc, FieldKind) and fill only matter on a tripole north boundary / next to eliminated
   // land blocks (domain.h); the defaults are right for every other domain.
+  // parts: HALO_COPIES = everything but the tripole fold, HALO_FOLD = the fold alone (a wide-halo slab domain folds u, v
+  // after every subcycle but refreshes its overlap rows -- all 14 planes of the state, no fold -- only now and then).
   void update_r8(double* base, int nfields, size_t stride, bool wrap = true, int loc = LOC_CENTER,
-                 int kind = KIND_SCALAR, double fill = 0.0);
+                 int kind = KIND_SCALAR, double fill = 0.0, int parts = HALO_ALL);
   void update_i4(int32_t* base, int nfields, size_t stride, int loc = LOC_CENTER, int kind = KIND_SCALAR,
                  int32_t fill = 0);
   void update_r4(float* base, int nfields, size_t stride, int loc = LOC_CENTER, int kind = KIND_SCALAR,
@@ -66,7 +70,11 @@ class Halo {
 
  private:
   template <class T>
-  void update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill);
+  void update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill, int parts);
+  template <class T>
+  void update_copies(T* base, int nfields, size_t stride, bool wrap, T fill);
+  template <class T>
+  void update_fold(T* base, int nfields, size_t stride, int loc, int kind, T fill);
   template <class T>
   void exchange(const T* src_base, size_t src_stride, T* dst_base, size_t dst_stride, int nfields,
                 const DevBuf<int32_t>& saddr, const std::vector<int>& speer, const std::vector<int>& soff,

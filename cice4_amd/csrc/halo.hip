@@ -545,8 +545,15 @@ void Halo::exchange(const T* src_base, size_t src_stride, T* dst_base, size_t ds
 }
 
 template <class T>
-void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill) {
+void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int kind, T fill, int parts) {
   CICE_REQUIRE(nfields >= 1, "halo: no field");
+  if (parts & HALO_COPIES) update_copies<T>(base, nfields, stride, wrap, fill);
+  if (parts & HALO_FOLD) update_fold<T>(base, nfields, stride, loc, kind, fill);
+  CICE_HIP(hipGetLastError());
+}
+
+template <class T>
+void Halo::update_copies(T* base, int nfields, size_t stride, bool wrap, T fill) {
   if (remote_) reserve(nfields);    // any number of levels in one message per neighbour
   // The wrap list goes first: a wide-halo refresh copies whole rows INCLUDING their E/W ghost
   // columns, so the owner's ghost columns must be current before they are packed or copied.
@@ -598,6 +605,10 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
                        stride, recv_addr_.p, total_r, reinterpret_cast<const T*>(recvbuf_.p), meta,
                        nrecv_);
   }
+}
+
+template <class T>
+void Halo::update_fold(T* base, int nfields, size_t stride, int loc, int kind, T fill) {
   if (fold_ || nfsend_) {   // tripole north boundary, after all regular copies (serial/ice_boundary.F90:705)
     CICE_REQUIRE(loc >= LOC_CENTER && loc <= LOC_EFACE, "halo: field location unknown on a tripole grid");
     CICE_REQUIRE(kind >= KIND_SCALAR && kind <= KIND_ANGLE, "halo: field kind unknown on a tripole grid");
@@ -645,7 +656,6 @@ void Halo::update(T* base, int nfields, size_t stride, bool wrap, int loc, int k
       }
     }
   }
-  CICE_HIP(hipGetLastError());
 }
 
 void Halo::all_max_u32(unsigned* dev_word) {
@@ -662,14 +672,14 @@ void Halo::all_max_u32(unsigned* dev_word) {
   CICE_NCCL(ncclAllReduce(dev_word, dev_word, 1, ncclUint32, ncclMax, (ncclComm_t)comm_, stream_));
 }
 
-void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap, int loc, int kind, double fill) {
-  update<double>(base, nfields, stride, wrap, loc, kind, fill);
+void Halo::update_r8(double* base, int nfields, size_t stride, bool wrap, int loc, int kind, double fill, int parts) {
+  update<double>(base, nfields, stride, wrap, loc, kind, fill, parts);
 }
 void Halo::update_i4(int32_t* base, int nfields, size_t stride, int loc, int kind, int32_t fill) {
-  update<int32_t>(base, nfields, stride, true, loc, kind, fill);
+  update<int32_t>(base, nfields, stride, true, loc, kind, fill, HALO_ALL);
 }
 void Halo::update_r4(float* base, int nfields, size_t stride, int loc, int kind, float fill) {
-  update<float>(base, nfields, stride, true, loc, kind, fill);
+  update<float>(base, nfields, stride, true, loc, kind, fill, HALO_ALL);
 }
 
 }  // namespace cice

@@ -96,7 +96,9 @@ int cice_domain_list(const cice_ctx *ctx, const char *name, int loc, int *n, int
  * and refreshed from their owner (u, v and the 12 stresses in ONE message per neighbour) only
  * every `overlap` subcycles instead of after every subcycle: results on the owned rows are
  * bit-identical, the number of exchanges drops by that factor.  Host arrays then describe the
- * EXTENDED blocks (cice_domain_block gives the owned rows).  overlap = 0: plain slabs. */
+ * EXTENDED blocks (cice_domain_block gives the owned rows).  overlap = 0: plain slabs.
+ * ns_boundary may be a tripole fold (3, 4; east-west cyclic, nx_global even, overlap <= slab height - 4): the rank with
+ * the top slab folds u, v after every subcycle as on any tripole grid, everything else is as above. */
 int cice_domain_create_slabs(cice_ctx *ctx, int nx_global, int ny_global, int nblocks_y,
                              int ew_boundary, int ns_boundary, int rank, int nranks, int overlap);
 /* info: nx_block, ny_block, nblocks(local), nblocks_tot, n_local_copies, n_send_msgs,

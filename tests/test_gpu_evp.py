@@ -615,6 +615,79 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                     assert np.array_equal(s["uvel"][0, gj, 1:-1], s1["uvel"][0, jg + 1, 1:-1]), (mode, r, gj)
 
 
+@pytest.mark.parametrize("ns", [3, 4])
+@pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
+                                       ("slabs6-sweep", 3, 144)])
+def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
+    """Wide-halo slabs under a tripole north boundary (ns 3: fold through U points, 4: through T points), R ranks = R
+    contexts of this process: the rank with the top slab folds u, v after every subcycle (its overlap rows come with the
+    refresh like everybody's); it runs one launch per subcycle or, "sweep", K subcycles per sweep with the band of top
+    rows beside it, while the ranks below keep their pairs / plain sweeps.  slabs0: no overlap, ghost rows and the fold
+    after every subcycle.  Against the one-block domain through one launch per subcycle (pinned to the compiled reference
+    on such a grid), bit for bit on every owned cell; ocean and patchy ice up to the fold."""
+    import threading
+    nxg = 96
+    dom1 = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31 + ns, land_rows=0)
+    grid1 = synth.block_fields(gg, dom1, ew_cyclic=True, north_ocean=True)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    s1, _ = _evp_with(ctx, grid1, s1, NDTE, False, resident=0, skew=0, skew_fold=0)
+    assert np.abs(s1["uvel"][0, -3:]).max() > 1e-4
+    H = int(mode[5])
+    _LINK[0] += 1
+    link = _LINK[0]
+    bar = threading.Barrier(R)
+    out, errs = [None] * R, []
+
+    def rank_fn(r):
+        try:
+            c = lib.Context(device=0); c.sync()
+            dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=ns, rank=r, nranks=R, overlap=H)
+            assert dom["nblocks"] == 1 and dom["nsend"] >= 1
+            c.comm_init_local(link, r, R)
+            grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True)
+            s = synth.evp_state(grid, dom, seed=31, cover="patchy")
+            c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+            c.evp_set_option("resident", 0)
+            if mode.endswith("sweep"):
+                c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", 3)
+                assert c.evp_get_info("skew_fold" if r == R - 1 else "skew") == 1, r
+            else:
+                c.evp_set_option("skew", 0); c.evp_set_option("skew_fold", 0)
+            c.evp(DT, s)
+            out[r] = (dom, s)
+            bar.wait(timeout=120)
+        except BaseException as e:       # noqa: BLE001 -- reported by the main thread
+            errs.append((r, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errs, errs
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
+        want = _owned(one, s1[k])
+        got = np.zeros_like(want)
+        for r in range(R):
+            dom, s = out[r]
+            part = _owned(dom, s[k])
+            rows = slice(int(dom["j0"][0] + dom["own_jlo"][0] - dom["jlo"][0]),
+                         int(dom["j0"][0] + dom["own_jhi"][0] - dom["jlo"][0]) + 1)
+            got[rows] = part[rows]
+        assert np.array_equal(got, want), (ns, mode, R, k, np.argwhere(got != want)[:5])
+    # the ghost row beyond the fold, as the last halo update of the loop leaves it (a wide-halo domain hands back its
+    # owned rows only)
+    if H == 0:
+        dom, s = out[R - 1]
+        for k in ("uvel", "vvel"):
+            a, b = s[k][0, -1], s1[k][0, -1]
+            assert np.array_equal(a, b), (k, np.argwhere(a != b)[:8].ravel().tolist())
+
+
 def _evp_with(ctx, grid, s, ndte, damping, **opts):
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)

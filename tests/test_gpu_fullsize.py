@@ -209,3 +209,55 @@ def test_tenth_degree_width_with_a_tripole_fold(ctx, ns):
     assert np.abs(out[0]["uvel"][0, -3:]).max() > 1e-3
     for k in PRIMARY + ("strintx", "strocnx", "divu", "shear", "prs_sig"):
         assert np.array_equal(out[0][k], out[1][k]), (ns, k, np.argwhere(out[0][k] != out[1][k])[:5].tolist())
+
+
+@pytest.mark.parametrize("ns", [3, 4], ids=["tripole", "tripoleT"])
+def test_tenth_degree_width_tripole_grid_on_two_ranks(ctx, ns):
+    """The same grid as two wide-halo slabs on two ranks (two contexts of this process, in-process link): the lower rank
+    runs plain sweeps, the upper one sweeps + the band with the fold (3600 columns: the fold's four-kernel form), the
+    overlap rows are refreshed every 8 subcycles.  Against the one-block domain through one launch per subcycle."""
+    import threading
+    from cice4_amd import lib
+    nxg, nyg, ndte, R, H = 3600, 320, 24, 2, 8
+    dom1 = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.03, land_rows=0)
+    grid1 = synth.block_fields(gg, dom1, north_ocean=True)
+    s1 = synth.evp_state(grid1, dom1, cover="patchy")
+    ctx.evp_init(grid1, ndte=ndte, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident", 0); ctx.evp_set_option("skew", 0); ctx.evp_set_option("skew_fold", 0)
+    ctx.evp(DT, s1)
+    bar = threading.Barrier(R)
+    out, errs = [None] * R, []
+
+    def rank_fn(r):
+        try:
+            c = lib.Context(device=0); c.sync()
+            dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=ns, rank=r, nranks=R, overlap=H)
+            c.comm_init_local(7300 + ns, r, R)
+            grid = synth.block_fields(gg, dom, north_ocean=True)
+            s = synth.evp_state(grid, dom, cover="patchy")
+            c.evp_init(grid, ndte=ndte, krdg_partic=0, krdg_redist=0)
+            c.evp_set_option("resident", 0); c.evp_set_option("skew_min_cells", 0)
+            assert c.evp_get_info("skew_fold" if r == R - 1 else "skew") == 1, r
+            c.evp(DT, s)
+            out[r] = (dom, s)
+            bar.wait(timeout=300)
+        except BaseException as e:       # noqa: BLE001 -- reported by the main thread
+            errs.append((r, repr(e)))
+            bar.abort()
+
+    th = [threading.Thread(target=rank_fn, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(600)
+    assert not errs, errs
+    for k in ("uvel", "vvel", "stressp_1", "stressm_3", "stress12_4", "strintx", "divu", "shear", "prs_sig"):
+        for r in range(R):
+            dom, s = out[r]
+            j0, jlo, olo, ohi = int(dom["j0"][0]), int(dom["jlo"][0]), int(dom["own_jlo"][0]), int(dom["own_jhi"][0])
+            got = s[k][0, olo - 1:ohi, 1:-1]
+            g0 = j0 + (olo - jlo)
+            want = s1[k][0, 1 + g0:1 + g0 + (ohi - olo + 1), 1:-1]
+            assert np.array_equal(got, want), (ns, k, r, np.argwhere(got != want)[:5].tolist())
+
