@@ -82,6 +82,42 @@ def test_multi_rank_messages_reproduce_single_rank_halo(npx, npy):
             assert len(sends[r]) <= 2
 
 
+@pytest.mark.parametrize("ns", [3, 4])
+@pytest.mark.parametrize("nb,nr,ov", [(2, 2, 0), (2, 2, 4), (3, 3, 6), (4, 2, 2)])
+def test_slabs_under_a_tripole_fold(nb, nr, ov, ns):
+    """A folded grid cut into (wide-halo) slabs: only the rank with the top slab has fold lists, and applied to the slab's
+    array they leave its top row and the ghost row beyond exactly as the one-block domain's lists leave them -- for every
+    field location, scalars and vectors.  Slabs whose overlap would reach the fold rows are refused."""
+    nxg, nyg = 16, 48
+    rng = np.random.default_rng(5 + ns)
+    g = rng.standard_normal((nyg, nxg))
+    one = lib.Context()
+    d1 = one.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    for r in range(nr):
+        c = lib.Context()
+        d = c.domain_create_slabs(nxg, nyg, nb, ew=1, ns=ns, rank=r, nranks=nr, overlap=ov)
+        top = [b for b in range(d["nblocks"]) if d["j0"][b] + (d["jhi"][b] - d["jlo"][b]) == nyg - 1]
+        assert (len(c.domain_list("fold_lsrc")) > 0) == bool(top), r
+        if not top:
+            continue
+        b = top[0]
+        for loc in (1, 2, 3, 4):
+            for kind in (1, 2):
+                a1 = np.zeros((1, d1["ny"], d1["nx"])); a1[0, 1:-1, 1:-1] = g
+                one.apply_halo_lists(a1, loc=loc, kind=kind)
+                a = np.zeros((d["nblocks"], d["ny"], d["nx"]))
+                for bb in range(d["nblocks"]):
+                    rows = d["jhi"][bb] - d["jlo"][bb] + 1
+                    a[bb, d["jlo"][bb] - 1:d["jhi"][bb], 1:-1] = g[d["j0"][bb]:d["j0"][bb] + rows]
+                c.apply_halo_lists(a, loc=loc, kind=kind)
+                jt = d["jhi"][b]                      # 1-based top physical row; the ghost row is jt + 1
+                assert np.array_equal(a[b, jt - 3:jt + 1], a1[0, -4:]), (r, loc, kind)
+    with pytest.raises(lib.CiceError):
+        lib.Context().domain_create_slabs(nxg, nyg, 2, ew=1, ns=ns, rank=0, nranks=2, overlap=nyg // 2 - 3)
+    with pytest.raises(lib.CiceError):
+        lib.Context().domain_create_slabs(nxg, nyg, 2, ew=0, ns=ns, rank=0, nranks=2, overlap=2)
+
+
 @pytest.mark.parametrize("nb,nr,ov", [(4, 1, 0), (4, 1, 3), (4, 2, 3), (8, 4, 2), (2, 2, 10)])
 def test_slab_overlap_lists(nb, nr, ov):
     """Wide-halo slabs: after wrap + refresh every cell of every extended block (and its ghost
