@@ -688,6 +688,31 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
             assert np.array_equal(a, b), (k, np.argwhere(a != b)[:8].ravel().tolist())
 
 
+@pytest.mark.parametrize("ns", [3, 4])
+@pytest.mark.parametrize("nb,overlap", [(2, 0), (3, 4), (2, 6)])
+def test_tripole_grid_cut_into_slabs_on_one_rank(ctx, ns, nb, overlap):
+    """the same with all slabs on one rank (on-rank refresh lists instead of messages; the top slab is one of several
+    local blocks, so the fold addresses a block that is not the first)"""
+    nxg, nyg = 96, 72
+    dom1 = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=17 + ns, land_rows=0)
+    grid1 = synth.block_fields(gg, dom1, ew_cyclic=True, north_ocean=True)
+    s1 = synth.evp_state(grid1, dom1, seed=17, cover="patchy")
+    s1, _ = _evp_with(ctx, grid1, s1, NDTE, False, resident=0, skew=0, skew_fold=0)
+    c = lib.Context(); c.sync()
+    dom = c.domain_create_slabs(nxg, nyg, nb, ew=1, ns=ns, overlap=overlap)
+    assert dom["nblocks"] == nb
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True)
+    s = synth.evp_state(grid, dom, seed=17, cover="patchy")
+    c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    c.evp(DT, s)
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
+        got, want = _owned(dom, s[k]), _owned(one, s1[k])
+        assert np.array_equal(got, want), (ns, nb, overlap, k, np.argwhere(got != want)[:5].tolist())
+
+
 def _evp_with(ctx, grid, s, ndte, damping, **opts):
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
