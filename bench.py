@@ -76,6 +76,10 @@ def parse():
     p.add_argument("--waves", type=int, default=0, help="wavefronts per EVP workgroup (4/8/16); 0 = auto")
     p.add_argument("--rows", type=int, default=0, help="T-rows per wavefront (1/2/4/8); 0 = auto")
     p.add_argument("--no-graph", action="store_true")
+    p.add_argument("--north", choices=("open", "tripole", "tripoleT"), default="open",
+                   help="north boundary of the synthetic grid.  'tripole' / 'tripoleT': the fold COSIMA's production grids have "
+                        "(ice_blocks.F90:228-233), ocean and ice up to it -- not BASELINE.json's configuration (no CPU baseline, "
+                        "no drop-in timing, no cross-rank-loop attempt for it)")
     p.add_argument("--overlap", type=int, default=-1,
                    help="N > 1: overlap rows of the wide-halo slabs = subcycles between ghost exchanges "
                         "(-1 = auto: 8, or a quarter of a rank's rows if that is smaller; 0 = exchange every subcycle)")
@@ -409,13 +413,17 @@ def launches_per_step(ndte, fused, overlap, skew_k=0):
     return n, max(sizes, key=lambda z: sizes[z] * z)
 
 
-def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False):
+NORTH = {"open": 0, "tripole": 3, "tripoleT": 4}   # Boundary codes of include/cice4_amd.h
+
+
+def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False, north="open"):
     nxg, nyg, ndte, _ = workload(wl)
+    ns = NORTH[north]
     if nyg % world:
         raise SystemExit(f"ny_global={nyg} not divisible by {world} ranks")
     if world > 1 and peer_loop:
         # one classic slab per rank (ghost rows owned by the neighbours): the decomposition of the cross-rank one-launch loop
-        dom = ctx.domain_create(nxg, nyg, nxg, nyg // world, ew=1, ns=0, rank=rank, npx=1, npy=world)
+        dom = ctx.domain_create(nxg, nyg, nxg, nyg // world, ew=1, ns=ns, rank=rank, npx=1, npy=world)
         dom["overlap"] = 0
         gg = synth.global_grid(nxg, nyg)
         grid = synth.block_fields(gg, dom)
@@ -424,11 +432,11 @@ def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False):
         rows = nyg // slabs
         if overlap < 0:
             overlap = auto_overlap(nxg, rows)
-        dom = ctx.domain_create_slabs(nxg, nyg, slabs, ew=1, ns=0, rank=0, nranks=1, overlap=overlap)
+        dom = ctx.domain_create_slabs(nxg, nyg, slabs, ew=1, ns=ns, rank=0, nranks=1, overlap=overlap)
         if dom["nsend"]:        # CICE4_AMD_SELF_COMM: messages to the own rank through a 1-rank communicator
             ctx.comm_init(ctx.comm_unique_id(), 0, 1)
     elif world == 1:
-        dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+        dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
         dom["overlap"] = 0
     else:
         rows = nyg // world
@@ -436,9 +444,10 @@ def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False):
             overlap = auto_overlap(nxg, rows)
         # j-slabs, one per GPU, each extended by `overlap` rows that are recomputed and refreshed
         # only every `overlap` subcycles
-        dom = ctx.domain_create_slabs(nxg, nyg, world, ew=1, ns=0, rank=rank, nranks=world, overlap=overlap)
-    gg = synth.global_grid(nxg, nyg)          # uniform 30 km rectangular grid (ice_grid.F90:976)
-    grid = synth.block_fields(gg, dom)
+        dom = ctx.domain_create_slabs(nxg, nyg, world, ew=1, ns=ns, rank=rank, nranks=world, overlap=overlap)
+    # uniform 30 km rectangular grid (ice_grid.F90:976); under a fold no land rows close the domain: ocean and ice up to it
+    gg = synth.global_grid(nxg, nyg, land_rows=0) if ns else synth.global_grid(nxg, nyg)
+    grid = synth.block_fields(gg, dom, north_ocean=bool(ns))
     state = synth.evp_state(grid, dom, cover="full")
     return dom, grid, state, ndte
 
@@ -698,7 +707,7 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     Returns everything the JSON line needs (rank-local cell counts already reduced over the ranks)."""
     progress(f"{wl}: building the synthetic case")
     peer_loop = bool(getattr(args, "peer_loop", False)) and world > 1
-    dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs, peer_loop)
+    dom, grid, state, ndte = build_case(ctx, wl, rank, world, args.overlap, args.slabs, peer_loop, args.north)
     progress(f"{wl}: case built, device set-up")
     if world > 1:
         # the communicator is created once per context and handed to every decomposition built afterwards
@@ -745,7 +754,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         ctx.evp_set_option("skew_prio", args.skew_prio)
     if args.skew_stagger_ns >= 0:
         ctx.evp_set_option("skew_stagger_ns", args.skew_stagger_ns)
-    skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") else 0
+    # (on a folded grid the sweep runs with a band of top rows beside it: "skew_fold"; the sweep is still the launch that counts)
+    skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") or ctx.evp_get_info("skew_fold") else 0
     if skew_k:
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
                 f"lanes, owns {62 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
@@ -945,6 +955,14 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                   f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
               "tile": tile, "metrics_recomputed_from_HTN_HTE": derive,
               "active_T_cells": nt_all, "active_U_cells": nu_all, "cell_subcycles_per_s": value * nt_all}
+    if args.north != "open":
+        config["north_boundary"] = (f"{args.north} fold (not BASELINE.json's configuration), ocean and ice up to it; "
+                                    + ("the rank with the top slab carries the fold (sweeps with a band of top rows beside them "
+                                       "where its slab is large enough, else one launch per subcycle), the others run as on "
+                                       "any grid" if world > 1 else
+                                       "the fold is part of the one-launch loop" if resident else
+                                       "sweeps with a band of top rows that carries the fold" if ctx.evp_get_info("skew_fold") else
+                                       "halo update with the fold after every subcycle"))
     if peer_verified:
         config["peer_loop_verified"] = ("one evp(dt) through the per-subcycle message exchange and one through the cross-rank "
                                         "one-launch loop from the same state: u, v and the 12 stresses bit-identical on every "
@@ -1006,6 +1024,10 @@ def main():
         raise SystemExit(launch_ranks(args))
     if args.host_only:
         raise SystemExit(host_only(args))
+    if args.north != "open":
+        if args.peer_loop:
+            raise SystemExit("--peer-loop: the cross-rank one-launch loop does not carry a tripole fold (DESIGN.md section 8)")
+        args.no_cpu_baseline = args.no_dropin_timing = args.no_peer_try = True
     # NOTE on load order: torch is imported before the product library touches the device.  Both bring a
     # HIP runtime and a librccl.so.1; whichever is loaded first serves the whole process, and loading the
     # system ones first leaves torch's own runtime without a device ("no ROCm-capable device").  With

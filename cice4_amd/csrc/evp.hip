@@ -2788,8 +2788,9 @@ bool Evp::can_skew_fold() const {
   if (!skew_on || !skew_fold_on || env_off || !fuse_on || !halo.fwd_ok() || !(derive_ok && derive_on)) return false;
   if (!halo.has_fold() || dom.nblocks() != 1) return false;
   // one block of the whole grid, or the top slab of a wide-halo domain (its overlap rows are refreshed between sweeps)
+  // (launch_range never lets a launch straddle a refresh: where K subcycles do not fit before the next one, the rest
+  //  runs one by one)
   if (dom.overlap == 0 && (halo.multi_rank() || halo.has_refresh())) return false;
-  if (dom.overlap > 0 && dom.overlap % skew_levels()) return false;
   if (n * 8 * 14 >= (1ull << 32)) return false;
   const Block& bl = dom.all[dom.local[0]];
   if (bl.jhi - bl.jlo + 1 < 4 * skew_levels() + 4) return false;

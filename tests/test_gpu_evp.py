@@ -617,12 +617,13 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
 
 @pytest.mark.parametrize("ns", [3, 4])
 @pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
-                                       ("slabs6-sweep", 3, 144)])
+                                       ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96)])
 def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     """Wide-halo slabs under a tripole north boundary (ns 3: fold through U points, 4: through T points), R ranks = R
     contexts of this process: the rank with the top slab folds u, v after every subcycle (its overlap rows come with the
     refresh like everybody's); it runs one launch per subcycle or, "sweep", K subcycles per sweep with the band of top
-    rows beside it, while the ranks below keep their pairs / plain sweeps.  slabs0: no overlap, ghost rows and the fold
+    rows beside it (K = 3, or 4 which does not divide the refresh interval), while the ranks below keep their pairs /
+    plain sweeps.  slabs0: no overlap, ghost rows and the fold
     after every subcycle.  Against the one-block domain through one launch per subcycle (pinned to the compiled reference
     on such a grid), bit for bit on every owned cell; ocean and patchy ice up to the fold."""
     import threading
@@ -649,8 +650,8 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
             s = synth.evp_state(grid, dom, seed=31, cover="patchy")
             c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
             c.evp_set_option("resident", 0)
-            if mode.endswith("sweep"):
-                c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", 3)
+            if "sweep" in mode:      # "sweep4": K = 4 does not divide the 6 subcycles between refreshes (4 + 1 + 1 / 4 + 2)
+                c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", int(mode[-1]) if mode[-1].isdigit() else 3)
                 assert c.evp_get_info("skew_fold" if r == R - 1 else "skew") == 1, r
             else:
                 c.evp_set_option("skew", 0); c.evp_set_option("skew_fold", 0)
