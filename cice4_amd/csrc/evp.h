@@ -86,6 +86,10 @@ class Evp {
   int skew_prio = 1;             // rotate the issue priority among the workgroups sharing a CU
   bool skew_debug = false;
   DevBuf<long long> skew_dbg;
+  bool stamps_on = false;        // option "stamps": in-kernel clock stamps (diagnostic build -DCICE4_AMD_STAMPS only)
+  DevBuf<long long> stamp_buf;
+  size_t stamp_used = 0;
+  long long* stamp_buffer(size_t workgroups);
   int skew_stagger_ns = 0;   // start delay per workgroup sharing a CU (k_subcycle_skew), 0 = none
   int skew_k_opt = 0, skew_seg_opt = 0;   // forced K / rows per workgroup (tests, tuning), 0 = auto
   long long skew_min_cells = 600000;      // smaller grids keep k_subcycle2 (or the resident loop); measured: 1000 x 800

@@ -862,6 +862,22 @@ __global__ __launch_bounds__(64 * W, (W == 12 ? 3 : 4)) void k_subcycle2(const S
 // Infinity-Cache hits.
 // Same arithmetic, same order, same bits as k_subcycle; columns walk the block as a ring exactly as in k_subcycle2.
 // Used where k_subcycle2 can be used (can_fuse) and the metrics derive from HTN / HTE.
+// In-kernel clock (MI355X_MICROARCH.md, DVFS item 6): a DIAGNOSTIC build (-DCICE4_AMD_STAMPS, scripts/build_ab.sh) stamps
+// the shader-cycle counter (s_memtime) and the 100 MHz wall clock (s_memrealtime) once before and once after the loop
+// of k_evp_resident / k_subcycle_skew; clock = d(cycles) / d(ticks) x 100 MHz, median over the workgroups
+// (scripts/inkernel_clock.py).  The product build has no stamp: both helpers are empty there.  The stamps go to a
+// buffer of their own that nothing else reads.
+__device__ __forceinline__ void stamp_at(long long* stamps, int slot) {
+#ifdef CICE4_AMD_STAMPS
+  if (stamps && threadIdx.x == 0) {
+    stamps[4 * (size_t)blockIdx.x + slot] = (long long)__builtin_amdgcn_s_memtime();
+    stamps[4 * (size_t)blockIdx.x + slot + 2] = (long long)__builtin_amdgcn_s_memrealtime();
+  }
+#else
+  (void)stamps; (void)slot;
+#endif
+}
+
 struct SkewArgs {
   SubArgs a;               // only what the kernel names is fetched from the argument block
   const double* st_in;     // u, v, 12 stresses of the current state: 14 planes of a.n doubles
@@ -874,6 +890,7 @@ struct SkewArgs {
   int prio_rotate;         // rotate the issue priority among the workgroups sharing a CU (see the kernel)
   int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
   long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
+  long long* stamps;       // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups], see stamp_at
 };
 
 // WS: wavefronts per SIMD the kernel is built for (bounds the registers)
@@ -976,6 +993,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x] = wall_clock64();
   // generation of this workgroup: workgroups are dispatched in blockIdx order, one per CU first
   const int gen = (int)(blockIdx.x / (gridDim.x / (unsigned)sa.stagger_mod + 1u));
+  stamp_at(sa.stamps, 0);
 #pragma clang loop unroll(disable)
   for (int t = -1; t < nsteps; ++t) {
     // The SIMD issues from its OLDEST ready wavefront first: of the workgroups sharing a CU the first one dispatched
@@ -1205,6 +1223,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     }
     __syncthreads();
   }
+  stamp_at(sa.stamps, 1);
   if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -1262,6 +1281,7 @@ struct ResArgs {
   double* xraw[2];       // [parity] raw top-row velocities (u at 0, v at a.n)
   unsigned* prog2;       // [tiles * RES_STRIDE] raw top row of subcycle k published = epoch0 + k + 1
   const int32_t* deps2;  // [tiles][4] tiles that hold the partners of this tile's top-row cells, -1 padded
+  long long* stamps;     // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups] see stamp_begin / stamp_end
 };
 enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
 
@@ -1422,6 +1442,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
     if (threadIdx.x < 2 && s_pub[threadIdx.x])
       __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
+  stamp_at(r.stamps, 0);
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
@@ -1665,6 +1686,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
     }
   }
 
+  stamp_at(r.stamps, 1);
   // ---- results (owners only), into the other copy of the state ----
   if (sown) {
 #pragma unroll
@@ -2145,6 +2167,8 @@ void Evp::set_option(const char* key, int value) {
     skew_gen_pct = value;
   } else if (!std::strcmp(key, "skew_debug")) {  // record start / end ticks of every workgroup of the sweep kernel
     skew_debug = value != 0;
+  } else if (!std::strcmp(key, "stamps")) {      // diagnostic build (-DCICE4_AMD_STAMPS): cycle / wall-clock stamps per workgroup
+    stamps_on = value != 0;
   } else if (!std::strcmp(key, "skew_prio")) {   // rotate issue priorities among the workgroups of a CU
     skew_prio = value;
   } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
@@ -2397,11 +2421,23 @@ void Evp::prepare(double dt) {
 
 // test aid: start / end wall-clock ticks (10 ns) of the workgroups of the last k_subcycle_skew launch
 long long Evp::debug_read(const char* what, long long* out, long long cap) {
-  CICE_REQUIRE(!std::strcmp(what, "skew_times"), "unknown debug array");
+  const bool stamps = !std::strcmp(what, "stamps");
+  CICE_REQUIRE(stamps || !std::strcmp(what, "skew_times"), "unknown debug array");
   CICE_HIP(hipStreamSynchronize(stream));
-  const long long nn = (long long)skew_dbg.n;
-  if (out && nn) CICE_HIP(hipMemcpy(out, skew_dbg.p, (size_t)std::min(nn, cap) * 8, hipMemcpyDeviceToHost));
+  DevBuf<long long>& b = stamps ? stamp_buf : skew_dbg;
+  const long long nn = stamps ? (long long)stamp_used : (long long)b.n;
+  if (out && nn) CICE_HIP(hipMemcpy(out, b.p, (size_t)std::min(nn, cap) * 8, hipMemcpyDeviceToHost));
   return nn;
+}
+
+// [4 * workgroups] cycle / wall-clock stamps of the last launch of a stamped kernel, or NULL (option "stamps" off, or the
+// product build, whose kernels hold no stamp: cice_evp_debug("stamps") then returns zeros)
+long long* Evp::stamp_buffer(size_t workgroups) {
+  if (!stamps_on) return nullptr;
+  if (stamp_buf.n < 4 * workgroups) stamp_buf.alloc(4 * workgroups);
+  stamp_used = 4 * workgroups;
+  CICE_HIP(hipMemsetAsync(stamp_buf.p, 0, stamp_used * 8, stream));
+  return stamp_buf.p;
 }
 
 // aggregate (source/ice_itd.F90:279-): the category sums the dynamics read, formed in the reference's order
@@ -2743,6 +2779,7 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
     if (skew_dbg.n < want) skew_dbg.alloc(want);
     sa.dbg = skew_dbg.p;
   }
+  sa.stamps = stamp_buffer(8 * ((sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks + 7) / 8));
   sa.stagger_ticks = skew_stagger_ns / 10;
   sa.stagger_mod = std::max(1, skew_blocks(K));
   sa.st_in = st[cur].p;
@@ -3455,6 +3492,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
       return false;
     }
   }
+  r.stamps = stamp_buffer(g.x);
   switch (W) {
     case 4: launch_res<4>(r, damp, peer, g, stream); break;
     case 6: launch_res<6>(r, damp, peer, g, stream); break;

@@ -240,8 +240,11 @@ int cice_evp_peer_connect(cice_ctx *ctx, int side, void *xu0, void *xu1, void *r
 int cice_evp_peer_export_ipc(cice_ctx *ctx, char handles[3][64], long long *plane);
 int cice_evp_peer_connect_ipc(cice_ctx *ctx, int side, const char handles[3][64], long long plane);
 /* Test / tuning aid: `what` = "skew_times" (after cice_evp_set_option("skew_debug", 1)): start and end wall-clock ticks
- * (10 ns) of every workgroup of the last K-subcycle sweep launch.  *count: in = capacity of out (out may be NULL),
- * out = entries available. */
+ * (10 ns) of every workgroup of the last K-subcycle sweep launch; "stamps" (after cice_evp_set_option("stamps", 1), in a
+ * DIAGNOSTIC build of the library compiled -DCICE4_AMD_STAMPS only -- the product build's kernels hold no stamp and the
+ * array comes back zero): per workgroup of the last one-launch loop / sweep {cycles before, cycles after, 100 MHz ticks
+ * before, ticks after} its loop (s_memtime / s_memrealtime: the in-kernel clock, scripts/inkernel_clock.py).
+ * *count: in = capacity of out (out may be NULL), out = entries available. */
 int cice_evp_debug(cice_ctx *ctx, const char *what, long long *out, long long *count);
 
 /* Per-routine entries with the reference's own argument lists (host pointers, one
