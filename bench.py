@@ -377,17 +377,33 @@ def host_only(args):
     return 0 if res[0] else 1
 
 
-def auto_overlap(nxg, rows):
-    """Rows of overlap = subcycles between ghost exchanges.  Redundant work grows like
-    2H/rows x t_kernel, exchange cost falls like t_comm/H (t_comm ~ 12 us measured through
-    pack + RCCL p2p + unpack); small slabs are latency-bound, so extra rows cost them nothing.
-    Always even: the subcycle kernel then runs two subcycles per launch."""
-    t_kernel = nxg * rows * 50e-6            # us per subcycle, from 430 us per 8.63 M cells
+SKEW_MIN_CELLS = 600000   # the library's own threshold for K-subcycle sweeps (Evp::skew_min_cells)
+SKEW_K = 4                # ... and its K (Evp::skew_levels)
+
+
+def auto_overlap(nxg, rows, skew_k=SKEW_K):
+    """Rows of overlap H = subcycles between two ghost refreshes of a wide-halo slab of `rows` owned rows.
+
+    Slabs large enough for K-subcycle SWEEPS (k_subcycle_skew; the library uses them from SKEW_MIN_CELLS cells): H is a
+    MULTIPLE OF K, or part of every refresh interval would fall back to the pair kernel (round 3: H = 6 with K = 4 sent a
+    third of the subcycles through it).  Cost per subcycle of one rank, measured at HEAD on one MI355X with grids of the
+    slab's size (scripts/gpu_r4_slabs.sh, profiles/r04_slab_costs_*.txt; 3600 columns, K = 4):
+        kernel    9.5 + 0.1163 x (rows + 2 H) us      (300 rows: H = 4 / 8 / 12 -> 44.0 / 44.9 / 46.0 us)
+        exchange  (t_fix + (H + 1) x nxg x 14 x 8 B / link) / H:  one packed message per neighbour, u, v and 12 stresses of
+                  H + 1 rows; t_fix ~ 20 us (pack + RCCL p2p + unpack, measured through the one-GPU message path), link ~ 60 GB/s
+                  (one xGMI link, estimated -- nothing here has run between two devices)
+    The byte term hardly depends on H ((H + 1) / H), the fixed term falls like 1 / H, the redundant rows cost 0.23 us per
+    unit of H: H = 8 and 12 are within 0.5 % of each other at every slab height, H = 4 is 4 % worse.  -> H = 2 K.
+    Smaller slabs (pairs of subcycles per launch): H even; latency-bound slabs take many rows, they cost nothing there."""
+    if nxg * (rows + 4 * skew_k) >= SKEW_MIN_CELLS and rows >= 8 * skew_k:
+        return 2 * skew_k
     if nxg * rows <= 200 * 200:
         # latency-bound slabs (measured: 320x72 5.05 us, 320x120 5.28 us per subcycle): a row of overlap
         # costs ~0.005 us per subcycle, an exchange ~10 us -> the optimum is flat around 24-32 rows
         h = max(2, min(24, rows // 2))
     else:
+        # pair kernel (k_subcycle2), round-1 calibration: 50e-6 us per cell and subcycle, 12 us per exchange
+        t_kernel = nxg * rows * 50e-6
         h = max(2, min(rows // 4, int(round((12.0 * rows / (2.0 * t_kernel)) ** 0.5))))
     return h + (h & 1) if h + (h & 1) <= rows else max(2, h - (h & 1))
 
@@ -759,6 +775,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     if skew_k:
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
                 f"lanes, owns {62 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
+    if skew_k and dom.get("overlap") and dom["overlap"] % skew_k:
+        progress(f"{wl}: {dom['overlap']} overlap rows are no multiple of K = {skew_k}: part of every refresh interval "
+                 f"runs the pair kernel instead of sweeps (auto_overlap avoids this; --overlap was given)")
     ctx.evp_set_option("resident", 0 if args.no_resident else 1)
     if peer_loop:
         # every rank hands the IPC handles of its exchange copies / progress words to its neighbours (control plane: gloo)
@@ -953,7 +972,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                                 f"1x{world} j-slabs, one block per GPU") + (
                   f", {dom['overlap']} overlap rows (ghost exchange every {dom['overlap']} subcycles, "
                   f"u, v, 12 stresses in one RCCL message per neighbour)" if dom.get("overlap") else ""),
-              "tile": tile, "metrics_recomputed_from_HTN_HTE": derive,
+              "tile": tile, "launches_per_step": 1 if resident else n_step,
+              "subcycles_in_the_most_common_launch": ndte if resident else main_sub,
+              "metrics_recomputed_from_HTN_HTE": derive,
               "active_T_cells": nt_all, "active_U_cells": nu_all, "cell_subcycles_per_s": value * nt_all}
     if args.north != "open":
         config["north_boundary"] = (f"{args.north} fold (not BASELINE.json's configuration), ocean and ice up to it; "
@@ -1201,7 +1222,11 @@ def main():
             "ranks_seen": ctx.comm_count() if world > 1 else 1,     # ncclCommCount: what RCCL itself says
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * m["t_evp"] / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
-            "data": "synthetic", "timing": m["timing"], "config": m["config"], "roofline": m["roofline"],
+            "data": "synthetic",
+            # `steps` x `ms_per_step` describes ONE block of exactly K steps (the median block); the timed region as a whole
+            # is that block repeated `timing.blocks` times, each between barrier + synchronise: this many seconds
+            "timed_region_s": m["timing"]["timed_region_s"], "timed_blocks": m["timing"]["blocks"],
+            "timing": m["timing"], "config": m["config"], "roofline": m["roofline"],
         }
         if peer_try:
             # two decompositions were measured; `value` is the faster one, the other stays in the line

@@ -89,6 +89,20 @@ struct DevBuf {
     if (count == 0) return;
     CICE_HIP(hipMalloc((void**)&p, count * sizeof(T)));
     n = count;
+    fine = false;
+  }
+  // FINE-GRAINED device memory: what ANOTHER device writes or polls while a kernel of this one runs (exchange copies and
+  // progress words of the cross-rank one-launch loop).  Ordinary (coarse-grained) hipMalloc memory carries no cross-device
+  // coherence guarantee before the end of a kernel; fine-grained memory does, for system-scope accesses (RCCL allocates
+  // its own flags this way for the same reason).
+  bool fine = false;
+  void alloc_fine(size_t count) {
+    if (count == n && p && fine) return;
+    release();
+    if (count == 0) return;
+    CICE_HIP(hipExtMallocWithFlags((void**)&p, count * sizeof(T), hipDeviceMallocFinegrained));
+    n = count;
+    fine = true;
   }
   void zero(hipStream_t s) {
     if (p) CICE_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));

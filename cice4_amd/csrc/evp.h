@@ -44,6 +44,7 @@ class Evp {
   void peer_export(void* out[3]);  // this rank's exchange copies and remote-progress words (device pointers)
   void peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n);
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
+  bool peer_buffers_fine() const { return res_xu[0].fine && res_xu[1].fine && res_rprog.fine; }   // what other devices write / poll is fine-grained memory
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle

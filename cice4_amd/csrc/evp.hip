@@ -189,6 +189,37 @@ struct StepuOut {
   double u, v, strintx, strinty, taux, tauy;
 };
 
+// The same in two halves (same operations, same order, same bits): what does not depend on the stresses of the current
+// subcycle (:1390-1411) and what does (:1413-1425).  k_subcycle_skew can run the first half while the stresses load.
+struct StepuPre {
+  double taux, tauy, cca, ccb, ab2;
+};
+__device__ __forceinline__ void stepu_pre(double uold, double vold, double Aiu, double Uocn, double Vocn, double Waterx,
+                                          double Watery, double Umassdtei, double Fm, StepuPre& p) {
+  const double du = Uocn - uold, dv = Vocn - vold;
+  const double vrel = Aiu * dragw * sqrt(du * du + dv * dv);
+  p.taux = vrel * Waterx;
+  p.tauy = vrel * Watery;
+  p.cca = Umassdtei + vrel * cosw;
+#ifdef CICE4_AMD_AUSCOM
+  p.ccb = Fm < 0.0 ? Fm - vrel * sinw : Fm + vrel * sinw;
+#else
+  p.ccb = Fm + vrel * sinw;
+#endif
+  p.ab2 = p.cca * p.cca + p.ccb * p.ccb;
+}
+__device__ __forceinline__ void stepu_post(const StepuPre& p, double uold, double vold, double Umassdtei, double Forcex,
+                                           double Forcey, double Uarear, double sx, double sy, StepuOut& o) {
+  o.taux = p.taux;
+  o.tauy = p.tauy;
+  o.strintx = Uarear * sx;
+  o.strinty = Uarear * sy;
+  const double cc1 = o.strintx + Forcex + p.taux + Umassdtei * uold;
+  const double cc2 = o.strinty + Forcey + p.tauy + Umassdtei * vold;
+  o.u = (p.cca * cc1 + p.ccb * cc2) / p.ab2;
+  o.v = (p.cca * cc2 - p.ccb * cc1) / p.ab2;
+}
+
 // One U-cell of `stepu` (ice_dyn_evp.F90:1390-1435); sx/sy are the four-term sums of :1415-1418.
 __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu, double Uocn,
                                            double Vocn, double Waterx, double Watery, double Forcex,
@@ -282,6 +313,18 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #endif
 #ifndef SKEW_OPAQUE_STRIDE
 #define SKEW_OPAQUE_STRIDE 1
+#endif
+#ifndef SKEW_TRIM        // every level computes only the rows its successors need (see the kernel)
+#define SKEW_TRIM 1
+#endif
+#ifndef SKEW_LOADPRIO    // highest issue priority while a step's loads are being issued, the rotation afterwards
+#define SKEW_LOADPRIO 0
+#endif
+#ifndef SKEW_TPASS       // HTN, HTE, strength and the two masks of a row travel from level to level through LDS (K <= 4)
+#define SKEW_TPASS 0
+#endif
+#ifndef SKEW_HOIST       // the part of the momentum equation that does not need this step's stresses runs before them
+#define SKEW_HOIST 0
 #endif
 // The same shifts with bound_ctrl: the lane without a source (lane 0 / lane 63) reads zero instead of keeping its own
 // value, which frees the compiler from copying the operand first (one instruction per half instead of two).  For
@@ -904,6 +947,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   constexpr int OWN0 = K + 1, OWNL = 62 - 2 * K;   // lanes OWN0 .. OWN0+OWNL-1 own their column
   __shared__ double s_sig[K - 1][2][12][TX];
   __shared__ double s_uv[K - 1][2][2][TX];
+  // TP: the T-cell inputs of a row (HTN, HTE, strength, icetmask, iceumask) ride along with it: only level 0 fetches them
+  // from memory, the others find them in LDS a step after the level before them held them (10.5 KB more per workgroup:
+  // K = 4 stays at three workgroups per CU, 3 x 52.5 KB of 160)
+  constexpr bool TP = SKEW_TPASS && K <= 4;
+  __shared__ double s_tin[TP ? K - 1 : 1][2][3][TX];
+  __shared__ int s_msk[TP ? K - 1 : 1][2][TX];
   const int per_blk = a.tiles_x * a.tiles_y;
   const int nt = per_blk * a.nblocks;
   const int chunk = (nt + 7) >> 3;
@@ -957,8 +1006,18 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     jb = jlo + sa.rows[2 * rem + 1];
   }
   const int jt0 = max(jlo, ja - (K - 1)), jt1 = min(jhi + 1, jb + K);
-  const int nsteps = (jt1 - jt0 + 1) + 2 * (K - 1);
   const bool lastlev = k == K - 1;
+#if SKEW_TRIM
+  // What a level has to compute shrinks by one row per level at either end of the segment (level K-1: T-rows ja..jb+1,
+  // level k: ja-(K-1-k) .. jb+(K-k)): rows beyond that feed nothing.  A level whose first row lies above the block's
+  // first row takes one light step before it -- the velocities and HTN of the row below, nothing computed (`pick`).
+  // The last level ends 2(K-1) steps after level 0 would have walked ITS last row: K-1 steps fewer per sweep.
+  const int lo = max(jlo, ja - (K - 1 - k)), hi = min(jhi + 1, jb + (K - k));
+  const int nsteps = (min(jhi + 1, jb + 1) - jt0 + 1) + 2 * (K - 1);
+#else
+  const int lo = jt0, hi = jt1;
+  const int nsteps = (jt1 - jt0 + 1) + 2 * (K - 1);
+#endif
 
   // row below the first T-row: unchanged during the sweep where it matters (a ghost row), harmless elsewhere
   double us = c0, vs = c0, usw = c0, vsw = c0, hn_s = c0;
@@ -999,19 +1058,24 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     // The SIMD issues from its OLDEST ready wavefront first: of the workgroups sharing a CU the first one dispatched
     // runs at its own pace, the last one gets what is left and finishes long after -- alone on the CU, bound by
     // latency.  Rotating the priority from step to step lets them advance together.
+#if SKEW_LOADPRIO
+    __builtin_amdgcn_s_setprio(3);   // the loads of a step go out first, whoever's turn it is in the rotation
+#else
     if (sa.prio_rotate) {
       const int p = (t + 1 + gen) % sa.stagger_mod;
       if (p == 0) __builtin_amdgcn_s_setprio(3);
       else if (p == 1) __builtin_amdgcn_s_setprio(1);
       else __builtin_amdgcn_s_setprio(0);
     }
+#endif
     const int r = jt0 + t - 2 * k;                 // T-row of this step (uniform)
-    const bool act = r >= jt0 && r <= jt1;
+    const bool act = r >= lo && r <= hi;
+    const bool pick = SKEW_TRIM && k > 0 && lo > jlo && r == lo - 1;   // the row below this level's first row: taken over, not computed
     const unsigned q = (unsigned)(r - 1) * nx8 + co;   // T-cell (col, r); the U-cell of this step is (col, r-1) = q - nx8
-    const bool urow = act && r > jt0;                  // (jlo <= r-1 <= jhi holds then)
+    const bool urow = act && r > lo;                   // (jlo <= r-1 <= jhi holds then)
     // ---- the stresses of the previous row go to the next level now, not when they were formed: the slot they go
     // into was read by that level during the previous step (two slots, one barrier per step)
-    if (!lastlev && r - 1 >= jt0 && r - 1 <= jt1) {
+    if (!lastlev && r - 1 >= lo && r - 1 <= hi) {
 #pragma unroll
       for (int c = 0; c < 12; ++c) s_sig[k][(r - 1) & 1][c][lx] = s[c];
     }
@@ -1030,6 +1094,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     const double hn = nhn, he = nhe, St = nst;
     double hew = nhew;
     const int tm_cur = ntm, um_cur = num;
+    if (TP && !lastlev && r >= jt0 && r <= jt1) {   // read by the next level during the NEXT step, as its prefetch
+      s_tin[k][r & 1][0][lx] = hn;
+      s_tin[k][r & 1][1][lx] = he;
+      s_tin[k][r & 1][2][lx] = St;
+      s_msk[k][r & 1][lx] = (tm_cur == 1 ? 1 : 0) | (um_cur != 0 ? 2 : 0);
+    }
     // ---- loads, oldest first: the momentum inputs of the U-row below (read-only: L2 hits for the levels behind
     // level 0; fetched whatever the mask says so that they do not wait for it) ...
     double xa, xuo, xvo, xfx, xfy, xum, xfm, xur;
@@ -1054,12 +1124,22 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         nun = ld8(u_in, qn);
         nvn = ld8((const double*)((const char*)u_in + pstride), qn);
       }
-      nhn = ld8(htn, qn);
-      nhe = ld8(hte, qn);
-      nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));   // only the lane at ilo uses it
-      nst = ld8(stren, qn);
-      ntm = ld4(tmk, qn >> 1);
-      num = ld4(umk, qn >> 1);
+      if (TP && k > 0) {
+        nhn = s_tin[k - 1][rn & 1][0][lx];
+        nhe = s_tin[k - 1][rn & 1][1][lx];
+        nst = s_tin[k - 1][rn & 1][2][lx];
+        const int m = s_msk[k - 1][rn & 1][lx];
+        ntm = m & 1;
+        num = m & 2;
+        if (has_ilo) nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));
+      } else {
+        nhn = ld8(htn, qn);
+        nhe = ld8(hte, qn);
+        if (!TP || has_ilo) nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));   // only the lane at ilo uses it
+        nst = ld8(stren, qn);
+        ntm = ld4(tmk, qn >> 1);
+        num = ld4(umk, qn >> 1);
+      }
     }
     // ... and, youngest, the stresses of this row: whoever waits for them waits for everything, which has arrived by then
     if (act) {
@@ -1083,8 +1163,18 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (act) {
-      const bool tact = tcol && tm_cur == 1;
+#if SKEW_LOADPRIO
+    if (sa.prio_rotate) {
+      const int p = (t + 1 + gen) % sa.stagger_mod;
+      if (p == 0) __builtin_amdgcn_s_setprio(2);
+      else if (p == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    } else {
+      __builtin_amdgcn_s_setprio(0);
+    }
+#endif
+    if (act || pick) {
+      const bool tact = act && tcol && tm_cur == 1;
       // the rows of the level below (a ghost row never changes: it is read where it lives)
       if (k > 0) {
         if (r > jhi) {
@@ -1118,11 +1208,21 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
           }
         }
       }
-      {
+      if (act) {
         const double hs = up1z(he);
         if (!at_ilo) hew = hs;
       }
       const bool uact = urow && ucol && um_prev != 0;
+#if SKEW_HOIST
+      // the half of the momentum equation of U-row r-1 that needs no stress of this step: its inputs were the first
+      // loads of the step, so it runs while the stresses are still on their way
+      StepuPre pre{};
+      if (uact) {
+        double wx, wy;
+        water_of(xuo, xvo, xfm, wx, wy);
+        stepu_pre(us, vs, xa, xuo, xvo, wx, wy, xum, xfm, pre);
+      }
+#endif
       // ---- stress (ice_dyn_evp.F90:1065-1289)
       StressOut o;
 #pragma unroll
@@ -1176,8 +1276,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
               // mirrored by ihi+1, column ihi by ilo-1, same row (the table look-up costs the two strips at the ends
               // of the ring four dependent memory round trips per row)
               StepuOut ro;
+#if SKEW_HOIST
+              stepu_post(pre, us, vs, x.umassdtei, x.forcex, x.forcey, x.uarear, sx, sy, ro);
+#else
               stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                          x.uarear, sx, sy, ro);
+#endif
               const unsigned qu = q - nx8;
               st8(s_out, qu, ro.u);
               st8(s_out, qu + n8, ro.v);
@@ -1198,8 +1302,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
           }
         } else {
           StepuOut ro;
+#if SKEW_HOIST
+          stepu_post(pre, us, vs, x.umassdtei, x.forcex, x.forcey, x.uarear, sx, sy, ro);
+#else
           stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                      x.uarear, sx, sy, ro);
+#endif
           u1 = ro.u;
           v1 = ro.v;
         }
@@ -2683,7 +2791,7 @@ int Evp::skew_waves_per_simd(int K) const {
 }
 int Evp::skew_blocks(int K) const {
   const int by_regs = skew_waves_per_simd(K) * 4 / K;
-  const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * 14336) : 16;
+  const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * (SKEW_TPASS && K <= 4 ? 17920 : 14336)) : 16;
   return std::max(1, std::min(by_regs, by_lds));
 }
 
@@ -2994,11 +3102,23 @@ void Evp::peer_export(void* out[3]) {
   out[2] = res_rprog.p;
 }
 
+// What a NEIGHBOURING DEVICE writes or polls during a launch -- both exchange copies (its tiles store their edge velocities
+// into them with system-scope stores, ours read them with system-scope loads) and the progress words its tiles publish
+// here -- lives in fine-grained device memory (DevBuf::alloc_fine); everything else of the loop (own progress words, abort
+// word, dependency lists, the state) is only ever touched by this device and stays ordinary hipMalloc memory.
+// CICE4_AMD_PEER_COARSE=1 restores plain hipMalloc for an A/B (scripts/peer_two_slabs.py).
 void Evp::peer_alloc() {
-  for (int k = 0; k < 2; ++k)
-    if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
+  static const bool coarse = [] { const char* e = std::getenv("CICE4_AMD_PEER_COARSE"); return e && e[0] == '1'; }();
+  for (int k = 0; k < 2; ++k) {
+    if (coarse) {
+      if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
+    } else if (res_xu[k].n < 2 * n || !res_xu[k].fine) {
+      res_xu[k].alloc_fine(2 * n);
+    }
+  }
   if (res_rprog.n == 0) {
-    res_rprog.alloc((size_t)2 * RP_MAX * RES_STRIDE);
+    if (coarse) res_rprog.alloc((size_t)2 * RP_MAX * RES_STRIDE);
+    else res_rprog.alloc_fine((size_t)2 * RP_MAX * RES_STRIDE);
     res_rprog.zero(stream);
     CICE_HIP(hipStreamSynchronize(stream));
   }

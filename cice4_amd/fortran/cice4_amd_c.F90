@@ -456,6 +456,9 @@ contains
       rc = cice_host_register(cice_gpu_ctx, c_loc(a), int(n, c_size_t) * 8_c_size_t)
    end subroutine cice_gpu_pin_r8
 
+   ! A failed library call ends the run.  In an MPI job it has to end the JOB: the reference aborts through abort_ice ->
+   ! MPI_ABORT (mpi/ice_exit.F90:41-80); an `error stop` of one task alone would leave the others waiting in their next
+   ! exchange.  (The serial build has no MPI: error stop.)
    subroutine cice_gpu_check(rc, where)
       integer(c_int), intent(in) :: rc
       character(len=*), intent(in) :: where
@@ -469,8 +472,23 @@ contains
          n = n + 1
       enddo
       write(*,*) msg(1:n-1)
-      error stop 'cice4_amd'
+      call cice_gpu_abort('cice4_amd')
    end subroutine cice_gpu_check
+
+   subroutine cice_gpu_abort(what)
+      character(len=*), intent(in) :: what
+#ifdef CICE4_AMD_MPI
+      include 'mpif.h'
+      integer :: ierr
+      logical :: up
+      write(0,*) 'cice4_amd: aborting the MPI job: ', what
+      flush(6)
+      flush(0)
+      call MPI_INITIALIZED(up, ierr)
+      if (up) call MPI_ABORT(MPI_COMM_WORLD, 1, ierr)
+#endif
+      error stop 'cice4_amd'
+   end subroutine cice_gpu_abort
 
    subroutine cice_gpu_ensure(device)
       integer(c_int), intent(in), optional :: device

@@ -184,7 +184,7 @@
           nblocks > max_blocks) then
          write(nu_diag,*) 'init_evp: GPU block layout differs from the host layout', info(1:3), &
                           nx_block, ny_block, nblocks, max_blocks
-         error stop 'init_evp'
+         call cice_gpu_abort('init_evp: GPU block layout differs from the host layout')
       endif
       g%dxt = addr_r8(dxt); g%dyt = addr_r8(dyt); g%dxhy = addr_r8(dxhy); g%dyhx = addr_r8(dyhx)
       g%cxp = addr_r8(cxp); g%cyp = addr_r8(cyp); g%cxm = addr_r8(cxm); g%cym = addr_r8(cym)
@@ -214,7 +214,7 @@
       case ('tripoleT'); bnd_code = 4
       case default
          write(nu_diag,*) 'boundary type not supported on the GPU path: ', trim(name)
-         error stop 'bnd_code'
+         call cice_gpu_abort('bnd_code: boundary type not supported on the GPU path')
       end select
       end function bnd_code
 

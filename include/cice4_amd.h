@@ -234,7 +234,10 @@ int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucell
  * With every neighbour connected, cice_evp_get_info("resident_peer") is 1 and cice_evp / cice_evp_subcycles run the loop
  * as one launch per rank; a rank whose launch times out raises a flag that is all-reduced over the communicator
  * ("resident_peer_agree", default 1) so that all ranks fall back to the launch-per-pair loop together.
- * "resident_peer_share": contexts sharing one device (default 1; the one-GPU test uses 2). */
+ * "resident_peer_share": contexts sharing one device (default 1; the one-GPU test uses 2).
+ * Memory types: the three exported buffers -- what another device writes (edge velocities, progress words) while a launch
+ * of this one polls and reads them -- are FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained));
+ * every access to them that crosses devices is system-scope.  cice_evp_get_info("resident_peer_fine") says so. */
 int cice_evp_peer_export(cice_ctx *ctx, void *bufs[3], long long *plane);
 int cice_evp_peer_connect(cice_ctx *ctx, int side, void *xu0, void *xu1, void *rprog, long long plane);
 int cice_evp_peer_export_ipc(cice_ctx *ctx, char handles[3][64], long long *plane);

@@ -442,6 +442,14 @@ contains
 #endif
 
 #ifdef DROPIN
+   ! drop-in build only (tests/mpi_evp_case.py `badsize`): a library call that fails on THIS task -- a model built with
+   ! another ncat than the library -- must end the whole MPI job (cice_gpu_check -> MPI_ABORT), not just this task
+   subroutine ref_gpu_bad_size() bind(C, name='ref_gpu_bad_size')
+      use cice4_amd_c, only: cice_check_sizes, cice_gpu_check, cice_gpu_ctx
+      use ice_domain_size, only: ncat, nilyr, nslyr, max_ntrcr
+      call cice_gpu_check(cice_check_sizes(cice_gpu_ctx, ncat + 1, nilyr, nslyr, max_ntrcr), 'ref_gpu_bad_size (test)')
+   end subroutine ref_gpu_bad_size
+
    integer(c_int) function ref_evp_info(ckey) bind(C, name='ref_evp_info')
       use cice4_amd_c, only: cice_evp_get_info, cice_gpu_ctx
       character(kind=c_char), intent(in) :: ckey(*)

@@ -65,6 +65,11 @@ def main():
     ref.set("tmask", mine(grid1["tmask"].astype(float))); ref.set("umask", mine(grid1["umask"].astype(float)))
     ref.set_strength_parameters(1, 0, 0, 4.0)
     ref.evp_gpu_setup()
+    if len(sys.argv) > 4 and sys.argv[4] == "badsize" and int(os.environ.get("PMI_RANK", "0")) == nprocs - 1:
+        # ONE task is handed a size the library was not built for: its cice_gpu_check has to end the JOB (MPI_ABORT, as the
+        # reference's abort_ice does, mpi/ice_exit.F90:78); the other tasks are on their way into evp's first exchange
+        ref.lib.ref_gpu_bad_size()
+        raise SystemExit("cice_gpu_check returned after a failed library call")
     for k in ("aice", "vice", "vsno", "aice0", "strairxT", "strairyT", "uocn", "vocn", "ss_tltx", "ss_tlty", "uvel", "vvel", "fm",
               "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty") + synth.SIG_NAMES:
         ref.set(k, mine(s1[k]))

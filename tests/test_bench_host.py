@@ -42,6 +42,22 @@ def test_auto_overlap_is_even_and_fits(nxg, rows):
     assert h >= 2 and h % 2 == 0 and h <= rows
 
 
+def test_auto_overlap_keeps_sweeps_between_the_refreshes():
+    """slabs that the library sweeps (K = 4 subcycles per launch) get an overlap that is a multiple of
+    K -- every launch between two refreshes is then a sweep, none falls back to the pair kernel."""
+    for nxg, nyg, ndte in ((3600, 2400, 240), (1440, 1080, 240)):
+        for world in (2, 4, 8):
+            rows = nyg // world
+            h = bench.auto_overlap(nxg, rows)
+            if nxg * (rows + 2 * h) >= bench.SKEW_MIN_CELLS:
+                assert h % bench.SKEW_K == 0 and h >= bench.SKEW_K, (nxg, rows, h)
+                n, main = bench.launches_per_step(ndte, True, h, bench.SKEW_K)
+                assert main == bench.SKEW_K and n == ndte // bench.SKEW_K, (nxg, rows, h, n, main)
+    assert bench.auto_overlap(3600, 300) == 8      # the 8-rank slab of the 0.1-degree grid
+    # small slabs keep the pair rule
+    assert bench.auto_overlap(320, 48) % 2 == 0
+
+
 def test_workload_names():
     assert bench.workload("gx1")[:3] == (320, 384, 120)
     assert bench.workload("tenth")[:3] == (3600, 2400, 240)

@@ -4,6 +4,8 @@ without FMA contraction -> required BIT-EXACT.  Whole evp(dt) passes through exp
 ice_strength, which the device evaluates with glibc's own algorithm (cice4_amd/csrc/libm_exact.h):
 also BIT-EXACT on a host whose glibc runs its FMA build of exp (conftest.TOL_EXP = 0); on any
 other host the field-level bound 1e-10 of BASELINE.json applies."""
+import os
+
 import numpy as np
 import pytest
 
@@ -474,11 +476,15 @@ def _owned(dom, f):
     return g
 
 
-@pytest.mark.parametrize("overlap,selfcomm", [(0, False), (1, False), (2, False), (4, False), (7, False), (4, True), (6, True), (7, True)])
-def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm):
+@pytest.mark.parametrize("overlap,selfcomm,skew_k", [(0, False, 0), (1, False, 0), (2, False, 0), (4, False, 0), (7, False, 0),
+                                                     (4, True, 0), (6, True, 0), (7, True, 0),
+                                                     (8, False, 4), (8, True, 4), (12, True, 4), (6, True, 3)])
+def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm, skew_k):
     """Wide-halo j-slabs: the overlap rows are recomputed and refreshed (u, v, 12 sigma in one
     message) only every `overlap` subcycles.  Owned rows must equal the single-domain checker run
-    bit for bit; with CICE4_AMD_SELF_COMM the refresh goes through pack/RCCL/unpack."""
+    bit for bit; with CICE4_AMD_SELF_COMM the refresh goes through pack/RCCL/unpack.
+    skew_k: K-subcycle SWEEPS between the refreshes, the overlap a multiple of K -- H = 8 with K = 4 is what
+    bench.py --gpus N picks for slabs of the 0.1-degree grid (bench.auto_overlap)."""
     nxg, nyg, nb = 96, 72, 4
     c1 = lib.Context()
     dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
@@ -498,11 +504,14 @@ def test_wide_halo_slabs_equal_single_domain(orc, monkeypatch, overlap, selfcomm
     grid = synth.block_fields(gg, dom)
     s = synth.evp_state(grid, dom, seed=31, cover="patchy")
     c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    if skew_k:
+        c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", skew_k)
+        assert c.evp_get_info("skew") == 1 and overlap % skew_k == 0
     c.evp(DT, s)
     one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
                own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
     for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
-        assert np.array_equal(_owned(dom, s[k]), _owned(one, s1[k])), (overlap, selfcomm, k)
+        assert np.array_equal(_owned(dom, s[k]), _owned(one, s1[k])), (overlap, selfcomm, skew_k, k)
     nt, nu = c.evp_active_cells()
     c1.evp_init(grid1, ndte=NDTE, krdg_partic=0, krdg_redist=0)
     s1b = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
@@ -568,6 +577,8 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                 if r < R - 1 or ns == 1:
                     c.evp_peer_connect(1, exports[(r + 1) % R])
                 assert c.evp_get_info("resident_peer") == 1
+                # what the neighbour writes or polls is fine-grained device memory (coherent across devices during a launch)
+                assert c.evp_get_info("resident_peer_fine") == (0 if os.environ.get("CICE4_AMD_PEER_COARSE") == "1" else 1)
                 bar.wait(timeout=60)
             else:
                 c.evp_set_option("resident", 0)

@@ -49,6 +49,7 @@ if mode == "peer":
     if rank > 0: c.evp_peer_connect_ipc(0, every[rank - 1])
     if rank < world - 1: c.evp_peer_connect_ipc(1, every[rank + 1])
     assert c.evp_get_info("resident_peer") == 1
+    assert c.evp_get_info("resident_peer_fine") == 1     # IPC-mapped exchange copies / progress words: fine-grained memory
     dist.barrier()
 else:
     c.evp_set_option("resident", 0)
@@ -161,3 +162,27 @@ def test_mpi_job_of_the_fortran_dropin_on_one_gpu(cfg, nprocs, shape):
                        cwd="/tmp")
     # counted, not matched line by line: the tasks write to one pipe and two of their lines can run together
     assert p.returncode == 0 and p.stdout.count("MPI-EVP-OK") == nprocs, p.stdout[-2500:] + p.stderr[-2500:]
+
+
+@pytest.mark.timeout(300)
+def test_a_failed_library_call_on_one_task_ends_the_mpi_job():
+    """mpi/ice_exit.F90:41-80: the reference aborts through abort_ice -> MPI_ABORT.  One task of an `mpiexec -n 2` job of the
+    drop-in build is handed a bad size (ncat + 1): cice_gpu_check prints the library's message and calls MPI_ABORT, so the job
+    ends non-zero within seconds -- an `error stop` of that task alone would leave the other one waiting in evp's first
+    exchange until the link's time-out."""
+    import shutil
+    import time
+    from oracle import refapi
+    mpiexec = shutil.which("mpiexec") or "/opt/conda/bin/mpiexec"
+    if not os.path.exists(mpiexec):
+        pytest.skip("no mpiexec")
+    if not refapi.available("gx3b4", "dropinmpi"):
+        pytest.skip("oracle/_ref/libcice_dropinmpi_gx3b4.so not built")
+    t0 = time.time()
+    p = subprocess.run([mpiexec, "-n", "2", sys.executable, os.path.join(ROOT, "tests", "mpi_evp_case.py"), "gx3b4", "2",
+                        "slenderX2", "badsize"], capture_output=True, text=True, timeout=250, cwd="/tmp")
+    took = time.time() - t0
+    assert p.returncode != 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "MPI-EVP-OK" not in p.stdout
+    assert "aborting the MPI job" in p.stderr and "ncat" in (p.stdout + p.stderr), p.stdout[-2000:] + p.stderr[-2000:]
+    assert took < 90.0, f"the job took {took:.0f} s to end: a task was left waiting"
