@@ -38,6 +38,11 @@ struct cice_ctx {
   CopyFan fan;                 // side streams for the entries that move many separate host arrays: ONE set per context,
                                // shared by the dynamics, the thermodynamic half-step and the transport
   hipStream_t cs() { return fan.forked ? fan.next() : stream; }   // the stream for the next host <-> device copy
+  // evp -> transport chain (cice_transport_chain): the host arrays the transport calls will be given; chain_ready: a
+  // cice_evp call has prefetched them and no transport call has consumed that yet
+  cice_transport_fields chain{};
+  bool chain_on = false, chain_ready = false;
+  const double *chain_aicen = nullptr, *chain_vicen = nullptr, *chain_u = nullptr, *chain_v = nullptr;   // what cice_evp was given
   double chio = 0.006;         // coupled flavour: the namelist's chio (cice_thermo_set_chio)
   double nml[4] = {1.0, 0.0, 0.00536, 0.0};   // coupled flavour: cosw, sinw, dragio, use_ocnslope last sent to the device
   bool nml_set = false;
@@ -494,6 +499,7 @@ int cice_destroy(cice_ctx* ctx) {
   ctx->unpin_all();
   ctx->evp.reset();
   ctx->transport.reset();
+  ctx->chain_on = ctx->chain_ready = false;
   ctx->upwind.reset();
   ctx->frame_halo.reset();
   ctx->halo.reset();
@@ -568,6 +574,7 @@ int cice_domain_create(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, int ew
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->chain_on = c_->chain_ready = false;
   c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
@@ -585,6 +592,7 @@ int cice_domain_create_map(cice_ctx* ctx, int nxg, int nyg, int bsx, int bsy, in
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->chain_on = c_->chain_ready = false;
   c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
@@ -623,6 +631,7 @@ int cice_domain_create_slabs(cice_ctx* ctx, int nxg, int nyg, int nblocks_y, int
   c_->have_domain = true;
   c_->evp.reset();
   c_->transport.reset();
+  c_->chain_on = c_->chain_ready = false;
   c_->upwind.reset();
   c_->halo.reset();
   c_->frame_halo.reset();
@@ -793,6 +802,13 @@ int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
   c_->evp->upload(*f);
+  c_->chain_ready = false;
+  if (c_->chain_on && c_->transport) {
+    // the rest of the transport's state travels while the subcycle loop runs (the link idles then); see cice_transport_chain
+    c_->transport->prefetch(c_->chain);
+    c_->chain_aicen = f->aicen; c_->chain_vicen = f->vicen; c_->chain_u = f->uvel; c_->chain_v = f->vvel;
+    c_->chain_ready = true;
+  }
   c_->evp->step(dt);
   c_->evp->download(*f);
   CICE_CATCH
@@ -1745,7 +1761,26 @@ int cice_transport_remap(cice_ctx* ctx, double dt, const cice_transport_fields* 
   CICE_TRY(ctx)
   CICE_REQUIRE(c_->transport != nullptr, "cice_transport_init has not been called");
   CICE_REQUIRE(f, "NULL argument");
+  if (c_->chain_on && c_->chain_ready && c_->evp && f->aice0 == c_->chain.aice0 && f->trcrn == c_->chain.trcrn &&
+      f->vsnon == c_->chain.vsnon && f->eicen == c_->chain.eicen && f->esnon == c_->chain.esnon &&
+      f->aicen == c_->chain_aicen && f->vicen == c_->chain_vicen && f->uvel == c_->chain_u && f->vvel == c_->chain_v)
+    c_->transport->adopt(c_->evp->d_uv(), c_->evp->d_aicen(), c_->evp->d_vicen());
+  c_->chain_ready = false;
   c_->transport->remap(dt, *f, l_stop, istop, jstop);
+  CICE_CATCH
+}
+
+int cice_transport_chain(cice_ctx* ctx, const cice_transport_fields* f) {
+  CICE_TRY(ctx)
+  c_->chain_ready = false;
+  c_->chain_on = false;
+  if (f) {
+    CICE_REQUIRE(c_->transport != nullptr, "cice_transport_chain: cice_transport_init has not been called");
+    CICE_REQUIRE(f->aice0 && f->aicen && f->trcrn && f->vicen && f->vsnon && f->eicen && f->esnon && f->uvel && f->vvel,
+                 "cice_transport_chain: NULL field");
+    c_->chain = *f;
+    c_->chain_on = true;
+  }
   CICE_CATCH
 }
 

@@ -161,6 +161,9 @@ struct CopyFan {
     for (int i = 0; i < n; ++i) CICE_HIP(hipStreamWaitEvent(side[i], ev[n], 0));
   }
   hipStream_t next() { return forked ? side[k++ % n] : main; }
+  // leave the copies enqueued since fork() in flight: `main` does NOT wait for them (a later fork() / join() pair does --
+  // the side streams run in order)
+  void detach() { forked = false; }
   void join() {
     if (!forked) return;
     for (int i = 0; i < n; ++i) {

@@ -44,6 +44,11 @@ class Evp {
   void peer_export(void* out[3]);  // this rank's exchange copies and remote-progress words (device pointers)
   void peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n);
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
+  // device copies the transport may take over right after evp(dt) (cice_transport_chain): u | v of the current state,
+  // aicen, vicen as uploaded (host layout)
+  const double* d_uv() const { return uv[cur].p; }
+  const double* d_aicen() const { return aicen.p; }
+  const double* d_vicen() const { return vicen.p; }
   bool peer_buffers_fine() const { return res_xu[0].fine && res_xu[1].fine && res_rprog.fine; }   // what other devices write / poll is fine-grained memory
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
@@ -120,6 +125,7 @@ class Evp {
   DevBuf<double> band[2];        // the band's two copies of u, v, 12 sigma (full planes; only the top rows are used)
   DevBuf<int32_t> blk_band;
   int band_k = 0;
+  bool res_blocks_on = true;     // one-rank domains of several blocks run the one-launch loop as well
   bool res_fold_on = true;       // one-block tripole domains run the one-launch loop with the fold inside
   void build_resident(int W);
   void build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W);   // tripole north boundary inside the loop

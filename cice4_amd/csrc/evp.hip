@@ -323,6 +323,9 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #ifndef SKEW_TPASS       // HTN, HTE, strength and the two masks of a row travel from level to level through LDS (K <= 4)
 #define SKEW_TPASS 0
 #endif
+#ifndef SKEW_EARLY       // a third slot for the hand-off of level 0: its stresses of the NEXT row are fetched before the barrier
+#define SKEW_EARLY 0
+#endif
 #ifndef SKEW_HOIST       // the part of the momentum equation that does not need this step's stresses runs before them
 #define SKEW_HOIST 0
 #endif
@@ -945,7 +948,13 @@ template <int K, bool LAST, bool DAMP, int WS>
 __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa) {
   const SubArgs& a = sa.a;
   constexpr int OWN0 = K + 1, OWNL = 62 - 2 * K;   // lanes OWN0 .. OWN0+OWNL-1 own their column
-  __shared__ double s_sig[K - 1][2][12][TX];
+  // EARLY: the hand-off of level 0 has THREE slots (row mod 3), s_sig0; the others two, s_sig[k - 1] for level k >= 1.
+  // Level 0 can then put the stresses it has just formed into LDS at the END of its step (the slot was read two steps
+  // ago) and fetch those of the next row into the same registers BEFORE the barrier: they are in flight during the
+  // barrier and the first third of the next step instead of being waited for in the middle of it.
+  constexpr bool EARLY = SKEW_EARLY && !(SKEW_TPASS && K <= 4);
+  __shared__ double s_sig[EARLY ? (K > 2 ? K - 2 : 1) : K - 1][2][12][TX];
+  __shared__ double s_sig0[EARLY ? 3 : 1][EARLY ? 12 : 1][TX];
   __shared__ double s_uv[K - 1][2][2][TX];
   // TP: the T-cell inputs of a row (HTN, HTE, strength, icetmask, iceumask) ride along with it: only level 0 fetches them
   // from memory, the others find them in LDS a step after the level before them held them (10.5 KB more per workgroup:
@@ -1075,14 +1084,16 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     const bool urow = act && r > lo;                   // (jlo <= r-1 <= jhi holds then)
     // ---- the stresses of the previous row go to the next level now, not when they were formed: the slot they go
     // into was read by that level during the previous step (two slots, one barrier per step)
-    if (!lastlev && r - 1 >= lo && r - 1 <= hi) {
+    if (!lastlev && r - 1 >= lo && r - 1 <= hi && !(EARLY && k == 0)) {
 #pragma unroll
-      for (int c = 0; c < 12; ++c) s_sig[k][(r - 1) & 1][c][lx] = s[c];
+      for (int c = 0; c < 12; ++c) s_sig[EARLY ? k - 1 : k][(r - 1) & 1][c][lx] = s[c];
     }
     // ---- take over what was fetched for this row.  The empty asm is a use of those registers placed BEFORE this
     // step's loads are issued: the wait for them that the compiler needs (it cannot count loads across the back edge
-    // and waits for everything) then falls here, where only loads of the previous step are in flight
-    asm volatile("" : "+v"(nun), "+v"(nvn), "+v"(nhn), "+v"(nhe), "+v"(nhew), "+v"(nst), "+v"(ntm), "+v"(num));
+    // and waits for everything) then falls here, where only loads of the previous step are in flight.  (EARLY: that use
+    // sits at the end of the previous step, in front of level 0's early loads.)
+    if (!EARLY) asm volatile("" : "+v"(nun), "+v"(nvn), "+v"(nhn), "+v"(nhe), "+v"(nhew), "+v"(nst), "+v"(ntm), "+v"(num));
+    const int r3 = (int)((unsigned)(r + 3 * 4096) % 3u);   // slot of row r in the three-slot hand-off of level 0
     // the planes of an array are walked with a scalar pointer (base += plane stride: scalar adds, no vector
     // arithmetic per access); the stride is made opaque once per step, or the compiler would form all the plane bases
     // before the loop and keep them in (spilled) scalar registers
@@ -1150,16 +1161,21 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       } else {
 #else
       if (k == 0) {
-        const char* ps = (const char*)u_in + 2 * pstride;
+        if (!EARLY) {
+          const char* ps = (const char*)u_in + 2 * pstride;
 #pragma unroll
-        for (int c = 0; c < 12; ++c) {
-          s[c] = SKEW_NT ? ld8nt((const double*)ps, q) : ld8((const double*)ps, q);
-          ps += pstride;
-        }
+          for (int c = 0; c < 12; ++c) {
+            s[c] = SKEW_NT ? ld8nt((const double*)ps, q) : ld8((const double*)ps, q);
+            ps += pstride;
+          }
+        }   // (EARLY: fetched at the end of the previous step)
+      } else if (EARLY && k == 1) {
+#pragma unroll
+        for (int c = 0; c < 12; ++c) s[c] = s_sig0[r3][c][lx];
       } else {
 #endif
 #pragma unroll
-        for (int c = 0; c < 12; ++c) s[c] = s_sig[k - 1][r & 1][c][lx];
+        for (int c = 0; c < 12; ++c) s[c] = s_sig[EARLY ? k - 2 : k - 1][r & 1][c][lx];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1329,6 +1345,25 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       hn_s = hn;
       um_prev = um_cur;
     }
+    if (EARLY) {
+      // what the next step starts with has arrived by now (fetched at the top of this step): the use that makes the
+      // compiler wait for it stands HERE, in front of level 0's early loads
+      asm volatile("" : "+v"(nun), "+v"(nvn), "+v"(nhn), "+v"(nhe), "+v"(nhew), "+v"(nst), "+v"(ntm), "+v"(num));
+      if (k == 0) {
+        if (act) {
+#pragma unroll
+          for (int c = 0; c < 12; ++c) s_sig0[r3][c][lx] = s[c];
+        }
+        if (r + 1 >= lo && r + 1 <= hi) {
+          const char* ps = (const char*)u_in + 2 * pstride;
+#pragma unroll
+          for (int c = 0; c < 12; ++c) {
+            s[c] = ld8((const double*)ps, q + nx8);
+            ps += pstride;
+          }
+        }
+      }
+    }
     __syncthreads();
   }
   stamp_at(sa.stamps, 1);
@@ -1430,19 +1465,26 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
   __shared__ int s_rfd[PEER || FOLD ? W : 1][4][TX];   // PEER: ghost cells on other ranks mirroring this lane's cell; FOLD: ghost cells the fold fills
   __shared__ int s_pub[2];                      // PEER: this tile publishes to the south / north rank
   __shared__ int s_abort;
-  const int nt = a.tiles_x * a.tiles_y;
+  // tiles are numbered block by block (a one-rank domain of several blocks: every block is cut into tiles_x x tiles_y
+  // tiles of the largest block's extent; the cells of a block are addressed from its own plane, which is what the
+  // forwarding lists and the dependency lists use as well -- the PEER and FOLD forms have one block)
+  const int per_blk = a.tiles_x * a.tiles_y;
+  const int nt = per_blk * ((PEER || FOLD) ? 1 : a.nblocks);
   const int chunk = (nt + 7) >> 3;
   const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (tile >= nt) return;  // whole workgroup
-  const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
-  const int ilo = a.blk[0], ihi = a.blk[1], jlo = a.blk[2], jhi = a.blk[3];
+  const int b = (PEER || FOLD) ? 0 : tile / per_blk;
+  const int rem = tile - b * per_blk;
+  const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
+  const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+  if (i0 > ihi || j0 > jhi) return;   // a block smaller than the largest one (padded decomposition): no cell to own here, nobody waits for this tile
   const int lx = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int nx = a.nx;
   const int i = i0 + lx, j = j0 + w;
   const bool in_i = i <= ihi + 1;
   const bool ok = in_i && j <= jhi + 1;
-  const size_t q = ok ? (size_t)(j - 1) * nx + (i - 1) : 0;
+  const size_t q = ok ? (size_t)b * nx * a.ny + (size_t)(j - 1) * nx + (i - 1) : 0;
   const unsigned qb = (unsigned)q * 8u, nxb = (unsigned)nx * 8u;   // byte offsets into an exchange copy
   const bool own_i = (min(i, ihi) - i0) < (TX - 1);
   const bool uown = lx < TX - 1 && i <= ihi && w < W - 1 && j <= jhi;
@@ -2242,6 +2284,8 @@ void Evp::set_option(const char* key, int value) {
     }
   } else if (!std::strcmp(key, "skew_fold")) {              // sweeps on a tripole grid (a band of top rows beside them)
     skew_fold_on = value != 0;
+  } else if (!std::strcmp(key, "resident_blocks")) {        // the one-launch loop on a one-rank domain of several blocks
+    res_blocks_on = value != 0;
   } else if (!std::strcmp(key, "resident_fold")) {          // a tripole north boundary inside the one-launch loop
     res_fold_on = value != 0;
   } else if (!std::strcmp(key, "resident_retry_steps")) {   // evp(dt) calls until a time-out is forgiven, 0 = never
@@ -2791,7 +2835,8 @@ int Evp::skew_waves_per_simd(int K) const {
 }
 int Evp::skew_blocks(int K) const {
   const int by_regs = skew_waves_per_simd(K) * 4 / K;
-  const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * (SKEW_TPASS && K <= 4 ? 17920 : 14336)) : 16;
+  const bool tp = SKEW_TPASS && K <= 4, early = SKEW_EARLY && !tp;
+  const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * (tp ? 17920 : 14336) + (early ? 6144 : 0)) : 16;
   return std::max(1, std::min(by_regs, by_lds));
 }
 
@@ -3023,8 +3068,16 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
 bool Evp::can_reside() const {
   static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT"); return e && e[0] == '0'; }();
   if (!resident_on || resident_failed || env_off) return false;
-  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0) return false;
-  if (halo.has_refresh() || halo.multi_rank()) return false;
+  if (!halo.fwd_ok() || dom.nblocks() < 1 || dom.overlap > 0 || halo.multi_rank()) return false;
+  if (dom.nblocks() == 1) {
+    if (halo.has_refresh()) return false;
+  } else {
+    // several blocks of one rank: every ghost cell is an on-rank copy (forwarded by its producer), lies beyond an open /
+    // closed edge, or faces an eliminated land block (constant: the fill value of the halo update in prepare()); the
+    // fold inside the loop is built for one block
+    static const bool env_one = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_BLOCKS"); return e && e[0] == '0'; }();
+    if (!res_blocks_on || env_one || halo.has_fold()) return false;
+  }
   if (halo.has_fold() && !res_fold_on) return false;   // the fold inside the loop: option "resident_fold"
   return resident_waves() > 0;
 }
@@ -3043,7 +3096,7 @@ bool Evp::resident_dense() const {   // more tiles than CUs: several workgroups 
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
-  return tx * (((dom.ny_block - 2) + (W - 1) - 1) / (W - 1)) > ncu;
+  return dom.nblocks() * tx * (((dom.ny_block - 2) + (W - 1) - 1) / (W - 1)) > ncu;
 }
 
 int Evp::resident_waves() const {
@@ -3056,7 +3109,7 @@ int Evp::resident_waves() const {
   const int share = halo.multi_rank() ? std::max(1, res_peer_share) : 1;   // contexts sharing this device (tests)
   ncu = std::max(1, ncu / share);
   const long long tx = ((dom.nx_block - 2) + (TX - 1) - 1) / (TX - 1);
-  auto tiles_raw = [&](int w) { return tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
+  auto tiles_raw = [&](int w) { return dom.nblocks() * tx * (((dom.ny_block - 2) + (w - 1) - 1) / (w - 1)); };
   // Several ranks' loops on ONE device (tests only): every workgroup needs a CU of its own and the dispatcher deals the
   // workgroups of a launch round-robin over 8 XCDs x 4 shader engines without moving them between engines afterwards --
   // the `share` launches together must fit every engine (3 launches of 80 workgroups = 3 + 3 + 3 on an engine of 8 CUs
@@ -3421,29 +3474,42 @@ void Evp::build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W) 
 }
 
 void Evp::build_resident(int W) {
-  const int nx = dom.nx_block, ny = dom.ny_block;
-  const Block& bl = dom.all[dom.local[0]];
-  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
+  // One rank, one or SEVERAL blocks (source/ice_blocks.F90:133-330: any block size; comp_ice:34-46 gives the serial
+  // build many small ones): tiles are numbered block by block, a cell's address is its address in the rank's arrays
+  // (block plane + position), which is what the on-rank ghost copies dom.hsrc / hdst and the forwarding lists of
+  // Halo use.  A ghost cell is produced by the tile that owns its SOURCE cell -- in whichever block that lies.
+  const int nx = dom.nx_block, ny = dom.ny_block, nb = dom.nblocks();
+  const size_t np = (size_t)nx * ny;
   const int tiles_x = ((nx - 2) + (TX - 1) - 1) / (TX - 1), tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1);
-  const int nt = tiles_x * tiles_y;
-  std::vector<int32_t> src_of((size_t)nx * ny, -1);
+  const int per_blk = tiles_x * tiles_y, nt = per_blk * nb;
+  std::vector<int32_t> src_of(np * nb, -1);
   for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
-  auto owner = [&](int i, int j) -> int {   // 1-based cell -> tile that produces its velocity, -1: nobody (constant)
+  auto owner = [&](int b, int i, int j) -> int {   // block, 1-based cell -> tile that produces its velocity, -1: nobody (constant)
     if (i < 1 || i > nx || j < 1 || j > ny) return -1;
-    int q = (j - 1) * nx + (i - 1);
-    if (src_of[q] >= 0) q = src_of[q];
-    const int si = q % nx + 1, sj = q / nx + 1;
-    if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
-    return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
+    size_t q = (size_t)b * np + (size_t)(j - 1) * nx + (i - 1);
+    if (src_of[q] >= 0) q = (size_t)src_of[q];
+    const int sb = (int)(q / np);
+    const size_t qq = q - (size_t)sb * np;
+    const int si = (int)(qq % nx) + 1, sj = (int)(qq / nx) + 1;
+    const Block& s = dom.all[dom.local[sb]];
+    if (si < s.ilo || si > s.ihi || sj < s.jlo || sj > s.jhi) return -1;
+    return sb * per_blk + ((sj - s.jlo) / (W - 1)) * tiles_x + (si - s.ilo) / (TX - 1);
   };
-  if (halo.has_fold()) build_resident_fold(src_of, tiles_x, W);   // ghost cells the fold fills now have a source as well
+  if (halo.has_fold()) {
+    CICE_REQUIRE(nb == 1, "resident EVP loop: the tripole fold inside the loop is built for one block");
+    build_resident_fold(src_of, tiles_x, W);   // ghost cells the fold fills now have a source as well
+  }
   std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
   for (int t = 0; t < nt; ++t) {
-    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int b = t / per_blk, rem = t - b * per_blk;
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const Block& bl = dom.all[dom.local[b]];
+    const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
     const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    if (i0 > ihi || j0 > jhi) continue;   // (a block smaller than the largest: the kernel's workgroup leaves at once)
     int nd = 0;
     auto add = [&](int i, int j) {
-      const int o = owner(i, j);
+      const int o = owner(b, i, j);
       if (o < 0 || o == t) return;
       for (int k = 0; k < nd; ++k)
         if (deps[(size_t)t * RES_MAXDEP + k] == o) return;

@@ -33,6 +33,12 @@ class Transport {
   void init(const cice_transport_config& c, const cice_transport_grid& g);
   // one transport_remap(dt) on host arrays (upload, remap, bound_state on the device, download)
   void remap(double dt, const cice_transport_fields& f, int32_t* l_stop, int32_t* istop, int32_t* jstop);
+  // evp -> transport chain (cice_transport_chain): prefetch() starts the upload of aice0, trcrn, vsnon, eicen, esnon on the
+  // copy streams and returns at once; adopt() copies uvel | vvel (one buffer) and aicen, vicen (host layout) from the
+  // dynamics' device buffers; the next remap() then uploads nothing
+  void prefetch(const cice_transport_fields& f);
+  void adopt(const double* d_uv, const double* d_aicen, const double* d_vicen);
+  bool chained = false;   // the state of the next remap() is on the device already
   // test aid: stop the next remap() after kernel stage `s` (1 tracers, 2 fields + departure points + their halos,
   // 3 fluxes, 4 update; 0 = run through) and copy a work array to the host (0 mm, 1 tm, 2 mc|tc, 3 mx|tx|my|ty,
   // 4 dpx|dpy, 5 mflx, 6 mtflx, 7 mmask, 8 tmask); returns the number of doubles
@@ -47,6 +53,7 @@ class Transport {
   CopyFan& fan;  // the context's side streams for the state upload / download
   size_t n = 0;  // nblocks * nx_block * ny_block
   int ntrace = 0, ntrcr = 0;
+  void up(double* d, const double* h, int levels);   // host (nx,ny,levels,nblocks) -> device (nx,ny,nblocks) per level
   TransportKernelArgs a{};
   DevBuf<int32_t> blk;
   DevBuf<double> HTN, HTE, dxt, dyt, dxu, dyu, tarear, hm;

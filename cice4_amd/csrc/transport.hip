@@ -631,22 +631,54 @@ void Transport::init(const cice_transport_config& c, const cice_transport_grid& 
   a.errkey = key.p;
 }
 
+// host arrays are (nx,ny,levels,nblocks); the device keeps (nx,ny,nblocks) per level
+void Transport::up(double* d, const double* h, int levels) {
+  const size_t np = (size_t)dom.nx_block * dom.ny_block;
+  const int nb = dom.nblocks();
+  if (levels == 1 || nb == 1) {
+    CICE_HIP(hipMemcpyAsync(d, h, (size_t)levels * n * 8, hipMemcpyHostToDevice, fan.next()));
+    return;
+  }
+  for (int b = 0; b < nb; ++b)
+    CICE_HIP(hipMemcpy2DAsync(d + (size_t)b * np, n * 8, h + (size_t)b * levels * np, np * 8, np * 8, levels,
+                              hipMemcpyHostToDevice, fan.next()));
+}
+
+// evp -> transport chain: the part of the state the dynamics do not hold starts its way to the device now, on the copy
+// streams, and nobody waits for it here -- the next fork() / join() pair on the context's CopyFan (the download of evp,
+// at the latest the one in remap()) orders the main stream behind these copies.
+void Transport::prefetch(const cice_transport_fields& f) {
+  CICE_REQUIRE(n > 0, "cice_transport_init has not been called");
+  fan.fork(stream);
+  up(aice0.p, f.aice0, 1); up(trcrn.p, f.trcrn, NCAT * NTRCR); up(vsnon.p, f.vsnon, NCAT);
+  up(eicen.p, f.eicen, NCAT * NILYR); up(esnon.p, f.esnon, NCAT * NSLYR);
+  fan.detach();
+}
+
+void Transport::adopt(const double* d_uv, const double* d_aicen, const double* d_vicen) {
+  const size_t np = (size_t)dom.nx_block * dom.ny_block;
+  const int nb = dom.nblocks();
+  CICE_HIP(hipMemcpyAsync(uv.p, d_uv, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
+  const double* src[2] = {d_aicen, d_vicen};
+  double* dst[2] = {aicen.p, vicen.p};
+  for (int k = 0; k < 2; ++k) {
+    if (nb == 1) {
+      CICE_HIP(hipMemcpyAsync(dst[k], src[k], (size_t)NCAT * n * 8, hipMemcpyDeviceToDevice, stream));
+    } else {   // the dynamics keep the host layout (nx,ny,ncat,nblocks)
+      for (int b = 0; b < nb; ++b)
+        CICE_HIP(hipMemcpy2DAsync(dst[k] + (size_t)b * np, n * 8, src[k] + (size_t)b * NCAT * np, np * 8, np * 8, NCAT,
+                                  hipMemcpyDeviceToDevice, stream));
+    }
+  }
+  chained = true;
+}
+
 void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop, int32_t* istop, int32_t* jstop) {
   CICE_REQUIRE(n > 0, "cice_transport_init has not been called");
   CICE_REQUIRE(f.aice0 && f.aicen && f.trcrn && f.vicen && f.vsnon && f.eicen && f.esnon && f.uvel && f.vvel,
                "cice_transport_remap: NULL field");
   const size_t np = (size_t)dom.nx_block * dom.ny_block;
   const int nb = dom.nblocks();
-  // host arrays are (nx,ny,levels,nblocks); the device keeps (nx,ny,nblocks) per level
-  auto up = [&](double* d, const double* h, int levels) {
-    if (levels == 1 || nb == 1) {
-      CICE_HIP(hipMemcpyAsync(d, h, (size_t)levels * n * 8, hipMemcpyHostToDevice, fan.next()));
-      return;
-    }
-    for (int b = 0; b < nb; ++b)
-      CICE_HIP(hipMemcpy2DAsync(d + (size_t)b * np, n * 8, h + (size_t)b * levels * np, np * 8, np * 8, levels,
-                                hipMemcpyHostToDevice, fan.next()));
-  };
   auto down = [&](double* h, const double* d, int levels) {
     if (levels == 1 || nb == 1) {
       CICE_HIP(hipMemcpyAsync(h, d, (size_t)levels * n * 8, hipMemcpyDeviceToHost, fan.next()));
@@ -657,10 +689,13 @@ void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop
                                 hipMemcpyDeviceToHost, fan.next()));
   };
   fan.fork(stream);
-  up(aice0.p, f.aice0, 1); up(aicen.p, f.aicen, NCAT); up(trcrn.p, f.trcrn, NCAT * NTRCR); up(vicen.p, f.vicen, NCAT);
-  up(vsnon.p, f.vsnon, NCAT); up(eicen.p, f.eicen, NCAT * NILYR); up(esnon.p, f.esnon, NCAT * NSLYR);
-  up(uv.p, f.uvel, 1); up(uv.p + n, f.vvel, 1);
-  fan.join();
+  if (!chained) {   // (chained: five arrays were prefetched during evp, four came from the dynamics' device buffers)
+    up(aice0.p, f.aice0, 1); up(aicen.p, f.aicen, NCAT); up(trcrn.p, f.trcrn, NCAT * NTRCR); up(vicen.p, f.vicen, NCAT);
+    up(vsnon.p, f.vsnon, NCAT); up(eicen.p, f.eicen, NCAT * NILYR); up(esnon.p, f.esnon, NCAT * NSLYR);
+    up(uv.p, f.uvel, 1); up(uv.p + n, f.vvel, 1);
+  }
+  chained = false;
+  fan.join();   // (also behind prefetched copies still in flight on the side streams)
   CICE_HIP(hipMemsetAsync(key.p, 0xff, 8, stream));
   a.dt = dt;
   const unsigned gx = (unsigned)((np + 255) / 256);

@@ -141,6 +141,11 @@ module cice4_amd_c
          real(c_double), value :: dt
          type(cice_transport_fields), intent(in) :: f
       end function
+      integer(c_int) function cice_transport_chain(ctx, f) bind(C, name='cice_transport_chain')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_transport_fields), intent(in) :: f
+      end function
       integer(c_int) function cice_transport_remap(ctx, dt, f, l_stop, istop, jstop) &
             bind(C, name='cice_transport_remap')
          import

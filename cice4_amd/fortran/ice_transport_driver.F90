@@ -23,7 +23,7 @@
       save
 
       character (len=char_len) :: advection   ! 'remap' or 'upwind' (ice_init.F90 reads it by this name)
-      logical, private :: fields_pinned = .false., upwind_ready = .false.
+      logical, private :: fields_pinned = .false., upwind_ready = .false., chain_asked = .false.
 
       contains
 
@@ -66,6 +66,7 @@
       type (cice_transport_fields) :: f
       integer (c_int) :: l_stop, istop, jstop
       integer :: np
+      character (len=8) :: chain_env
 
       call ice_timer_start(timer_advect)
       f%aice0 = addr_r8(aice0); f%aicen = addr_r8(aicen); f%trcrn = addr_r8(trcrn)
@@ -78,6 +79,18 @@
          call cice_gpu_pin_r8(vsnon, np*ncat); call cice_gpu_pin_r8(eicen, np*ntilyr)
          call cice_gpu_pin_r8(esnon, np*ntslyr)
          fields_pinned = .true.
+      endif
+      if (.not. chain_asked) then
+         ! evp -> transport without a PCIe round trip (include/cice4_amd.h: cice_transport_chain): step_dynamics calls
+         ! evp(dt) and transport_remap(dt) back to back (ice_step_mod.F90:575-584), nothing writes the state in between.
+         ! A statement about the DRIVER, hence opt-in: CICE4_AMD_CHAIN=1 in the environment.
+         chain_asked = .true.
+         call get_environment_variable('CICE4_AMD_CHAIN', chain_env)
+         if (trim(chain_env) == '1') then
+            call cice_gpu_check(cice_transport_chain(cice_gpu_ctx, f), 'cice_transport_chain')
+            if (my_task == master_task) write(nu_diag,*) &
+               'transport_remap takes its state from the device after evp (CICE4_AMD_CHAIN=1)'
+         endif
       endif
       call cice_gpu_check(cice_transport_remap(cice_gpu_ctx, dt, f, l_stop, istop, jstop), 'transport_remap')
       if (l_stop /= 0) then

@@ -602,6 +602,20 @@ class Context:
         self._ck(self.lib.cice_transport_remap(self.h, C.c_double(dt), C.byref(f), *[C.byref(x) for x in st]))
         return tuple(x.value for x in st)
 
+    def transport_chain(self, s):
+        """cice_transport_chain: s = the arrays the following transport_remap calls will be given (None ends the chain).
+        Every evp(dt, ...) then prefetches the transport's state while it subcycles; a transport_remap that follows it with
+        these arrays (and the uvel, vvel, aicen, vicen ARRAYS evp was given) uploads nothing."""
+        if s is None:
+            self._ck(self.lib.cice_transport_chain(self.h, None))
+            self._chain = None
+            return
+        f = TransportFields()
+        for n, _t in TransportFields._fields_:
+            setattr(f, n, _f8(s[n]))
+        self._chain = s          # keep the arrays alive: the library remembers their addresses
+        self._ck(self.lib.cice_transport_chain(self.h, C.byref(f)))
+
     def transport_debug(self, stop_stage=0, which=-1):
         cnt = C.c_longlong(0)
         self._ck(self.lib.cice_transport_debug(self.h, stop_stage, which, None, C.byref(cnt)))

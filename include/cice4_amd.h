@@ -459,6 +459,20 @@ typedef struct {
 int cice_transport_init(cice_ctx *ctx, const cice_transport_config *cfg, const cice_transport_grid *grid);
 int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *f, int32_t *l_stop,
                          int32_t *istop, int32_t *jstop);
+/* evp -> transport WITHOUT a PCIe round trip.  In step_dynamics `call evp(dt)` is followed at once by `call
+ * transport_remap(dt)` (source/ice_step_mod.F90:575-584): uvel, vvel come up from the device and go straight down again,
+ * aicen, vicen are uploaded twice, and the rest of the state waits for the link while it idles during the subcycle loop.
+ * cice_transport_chain(ctx, fields) names the host arrays the transport calls of this context will be given; from then on
+ *   - every cice_evp call also STARTS the upload of aice0, trcrn, vsnon, eicen, esnon into the transport's buffers (on the
+ *     copy streams, behind its own inputs: they travel while the subcycle loop runs), and
+ *   - the next cice_transport_remap that is given the chained arrays uploads nothing: those five are there, uvel, vvel,
+ *     aicen, vicen are taken from the dynamics on the device.
+ * CONTRACT (the caller's statement, as for cice_evp_adopt_thermo_state): between the START of a cice_evp call and the
+ * transport call that follows it, nothing writes to the seven state arrays, and uvel, vvel, aicen, vicen are the arrays
+ * cice_evp was given -- true for step_dynamics of every driver under drivers/.  A transport call that does not follow a
+ * cice_evp call (or is given other arrays) uploads as usual.  fields = NULL ends the chain.  The Fortran drop-in sets it up
+ * in init_transport when CICE4_AMD_CHAIN=1 is in the environment. */
+int cice_transport_chain(cice_ctx *ctx, const cice_transport_fields *fields);
 /* advection = 'upwind' (source/ice_transport_driver.F90:672-834 transport_upwind with state_to_work :1570, upwind_field
  * :1796, work_to_state :1686 and compute_tracers, source/ice_itd.F90:1482): first-order donor-cell transport of aice0, of
  * every category's area, volumes and tracers and of the layer enthalpies, then bound_state, on the device.  HTE, HTN,

@@ -866,6 +866,55 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
         assert np.array_equal(b[k], ref[k]), ("ranges", k)
 
 
+@pytest.mark.parametrize("nxg,nyg,bsx,bsy,ew,ns", [(96, 70, 48, 35, 1, 0), (100, 116, 50, 58, 1, 0), (26, 22, 12, 10, 1, 0),
+                                                    (100, 116, 10, 10, 1, 0), (130, 54, 65, 18, 1, 1), (96, 70, 32, 70, 0, 0),
+                                                    (96, 72, 96, 18, 1, 2), (320, 384, 160, 192, 1, 0), (200, 120, 67, 41, 2, 0)])
+def test_whole_loop_in_one_launch_on_several_blocks(ctx, orc, nxg, nyg, bsx, bsy, ew, ns):
+    """The one-launch loop on a ONE-RANK DOMAIN OF SEVERAL BLOCKS (source/ice_blocks.F90:133-330; comp_ice:34-46 gives the
+    serial build 5 x 5-cell blocks, COSIMA's configurations full-height slabs): tiles are numbered block by block, a ghost
+    cell is produced by the tile that owns its source cell in the NEIGHBOURING block, forwarded like the east-west
+    images.  Against one launch per subcycle + the on-rank halo copies (the path such domains ran before), and that
+    against the checker: bit for bit, ghost cells included.  2 x 2 blocks, the gx3 2 x 2 decomposition, padded 3 x 3
+    blocks (the last block row / column smaller: workgroups without a cell leave at once), 10 x 12 tiny blocks,
+    cyclic north-south, full-height and full-width slabs, gx1 size in 2 x 2 blocks, blocks wider than a tile."""
+    dom = ctx.domain_create(nxg, nyg, bsx, bsy, ew=ew, ns=ns)
+    assert dom["nblocks"] > 1
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=nxg + nyg, land_rows=0 if ns == 1 else 2)
+    grid = synth.block_fields(gg, dom, ew_cyclic=(ew == 1), ns_cyclic=(ns == 1))
+    s = synth.evp_state(grid, dom, seed=nxg, cover="patchy")
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    big = nxg * nyg >= 50000
+    for ndte, damping in (((NDTE, False),) if big else ((NDTE, False), (7, True), (2, False))):
+        ref, _ = _evp_with(ctx, grid, s, ndte, damping, fuse=0, resident=0)
+        assert np.abs(ref["uvel"]).max() > 0.01
+        if (ndte, damping) == (NDTE, False):
+            orc.set_evp_parameters(DT, ndte, damping); orc.set_strength_parameters(1, 0, 0, 4.0)
+            so = {k: v.copy() for k, v in s.items()}
+            orc.evp(orc.make_domain(dom, grid), so)
+            orc.set_strength_parameters()
+            for k in keys:
+                assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
+        tried = 0
+        for W, dense in ((0, 1), (4, 1), (6, 0), (8, 0), (11, 0)):
+            sg = {k: v.copy() for k, v in s.items()}
+            ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+            ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
+            ctx.evp_set_option("resident_dense", dense)
+            if not ctx.evp_get_info("resident"):
+                assert W != 0, "some shape has to fit this domain"
+                continue                      # this height does not give every tile a CU
+            ctx.evp(DT, sg)
+            assert ctx.evp_get_info("resident") == 1, ("the resident loop timed out and fell back", W, dense)
+            for k in keys:
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, dense, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+            tried += 1
+        assert tried >= 2
+    # switched off, such a domain runs one launch per subcycle as before
+    ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
+    ctx.evp_set_option("resident_blocks", 0)
+    assert ctx.evp_get_info("resident") == 0
+
+
 @pytest.mark.parametrize("nxg,nyg", [(96, 70), (320, 384), (130, 27), (64, 40), (20, 33)])
 @pytest.mark.parametrize("ns", [3, 4], ids=["tripole", "tripoleT"])
 def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
