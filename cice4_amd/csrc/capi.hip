@@ -866,6 +866,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "skew_seg_rows")) *value = c_->evp->skew_seg_rows(c_->evp->skew_levels());
   else if (!std::strcmp(key, "resident")) *value = (c_->evp->can_reside() || c_->evp->can_reside_peer()) ? 1 : 0;
   else if (!std::strcmp(key, "resident_peer")) *value = c_->evp->can_reside_peer() ? 1 : 0;
+  else if (!std::strcmp(key, "last_launches")) *value = c_->evp->last_launches;
   else if (!std::strcmp(key, "resident_peer_fine")) *value = c_->evp->peer_buffers_fine() ? 1 : 0;
   else if (!std::strcmp(key, "resident_waves")) *value = c_->evp->resident_waves();
   else if (!std::strcmp(key, "resident_dense")) *value = c_->evp->can_reside() && c_->evp->resident_dense() ? 1 : 0;

@@ -49,6 +49,7 @@ class Evp {
   const double* d_uv() const { return uv[cur].p; }
   const double* d_aicen() const { return aicen.p; }
   const double* d_vicen() const { return vicen.p; }
+  int last_launches = 0;     // subcycle-loop kernel launches of the last subcycles() call (1: the one-launch loop)
   bool peer_buffers_fine() const { return res_xu[0].fine && res_xu[1].fine && res_rprog.fine; }   // what other devices write / poll is fine-grained memory
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
@@ -140,6 +141,7 @@ class Evp {
   bool res_peer_built = false, res_peer_agree = true;
   int res_peer_share = 1;
   bool run_resident(int ksub0, int nsub);
+  int loop_launches = 0, graph_launches = 0, stats_left = 3;   // subcycle-loop kernels launched by the current / the captured range
   int flips = 0, graph_flips = 0;  // buffer swaps since the counter was reset / in the captured loop
   bool derive_ok = false, derive_on = true;  // metrics recomputed from HTN/HTE (verified at init)
   size_t n = 0;  // nblocks*ny*nx

@@ -2689,6 +2689,7 @@ SubArgs Evp::make_args() const {
 }
 
 void Evp::launch_subcycle(int ksub) {
+  ++loop_launches;
   SubArgs a = make_args();
   const int trows = waves * rows_per_wave;
   // physical extent of a block (a wide-halo slab is bsy + 2*overlap rows tall)
@@ -2795,6 +2796,7 @@ int Evp::fused_waves() const {
 
 // subcycles ksub and ksub+1
 void Evp::launch_subcycle_pair(int ksub) {
+  ++loop_launches;
   SubArgs a = make_args();
   const int W = fused_waves();
   a.tiles_x = ((dom.nx_block - 2) + 1 + OWN_LANES - 1) / OWN_LANES;
@@ -2913,6 +2915,7 @@ static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hip
 
 // subcycles ksub .. ksub+K-1
 void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
+  ++loop_launches;
   SkewArgs sa{};
   sa.a = make_args();
   const int ownl = 62 - 2 * K;
@@ -3803,7 +3806,11 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     build_skew_rows(K, ((dom.nx_block - 2) + 1 + ownl - 1) / ownl, ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
   bool replayed = false;
-  if (nsub >= 2 && (can_reside() || can_reside_peer())) replayed = run_resident(ksub0, nsub);
+  loop_launches = 0;
+  if (nsub >= 2 && (can_reside() || can_reside_peer())) {
+    replayed = run_resident(ksub0, nsub);
+    if (replayed) loop_launches = 1;
+  }
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +
@@ -3817,8 +3824,10 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
         CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         capturing = true;
         flips = 0;
+        loop_launches = 0;
         launch_range(ksub0, nsub);
         graph_flips = flips;
+        graph_launches = loop_launches;
         capturing = false;
         CICE_HIP(hipStreamEndCapture(stream, &gph));
         CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
@@ -3838,10 +3847,20 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
       CICE_HIP(hipGraphLaunch(graph_exec, stream));
       if (graph_flips & 1) cur = 1 - cur;
       replayed = true;
+      loop_launches = graph_launches;
     }
   }
   if (!replayed) launch_range(ksub0, nsub);
   CICE_HIP(hipGetLastError());
+  last_launches = loop_launches;
+  {   // CICE4_AMD_STATS=1: how the first ranges of subcycles ran (the whole-model tests read it from the model's log)
+    static const bool stats = [] { const char* e = std::getenv("CICE4_AMD_STATS"); return e && e[0] == '1'; }();
+    if (stats && stats_left > 0) {
+      --stats_left;
+      std::fprintf(stderr, "cice4_amd: subcycles %d..%d of evp(dt) on %d block(s): %d kernel launch(es)%s\n", ksub0, ksub0 + nsub - 1,
+                   dom.nblocks(), last_launches, last_launches == 1 && nsub > 1 ? " (the whole loop in one launch, state in registers)" : "");
+    }
+  }
   if (elapsed_ms) {
     CICE_HIP(hipEventRecord(e1, stream));
     CICE_HIP(hipEventSynchronize(e1));

@@ -81,8 +81,11 @@ def test_pure_reference_reproduces_its_golden_dump(name):
 @pytest.mark.parametrize("name,tol", [("gx3_exact3", 0.0), ("gx3_default3", TOL_EXP), ("gx3_default25", TOL_EXP),
                                       ("gx1_default3", TOL_EXP)])
 def test_reference_step_loop_with_dropin_modules(name, tol):
-    rec, gold, stride, log = _run_case("dropin", name)
+    # (gx3_default25 also runs with the evp -> transport chain: same dump)
+    rec, gold, stride, log = _run_case("dropin", name, {"CICE4_AMD_STATS": "1", **({"CICE4_AMD_CHAIN": "1"} if name == "gx3_default25" else {})})
     assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+    assert "on 1 block(s): 1 kernel launch(es)" in log
+    assert ("transport_remap takes its state from the device after evp" in log) == (name == "gx3_default25")
     worst = _compare(rec, gold, stride, tol)
     print("whole-driver drop-in", name, "worst field-relative difference", worst)
 
@@ -201,7 +204,7 @@ def test_whole_model_with_a_tripole_north_boundary(ns, ocean_at_fold):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,nprocs", [("gx3b4", 2), ("gx3b4", 4), ("gx3s2", 2)])
+@pytest.mark.parametrize("cfg,nprocs", [("gx3b4", 2), ("gx3b4", 4), ("gx3s2", 2), ("gx3b4", 1)])
 def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     """The reference's whole model in its MPI build (mpi/ modules, MPICH) with the four drop-in modules, `mpiexec -n P` on
     the real gx3 grid in 2 x 2 blocks: the P tasks share the one GPU and exchange through the shared-memory link
@@ -217,12 +220,15 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     rd = tempfile.mkdtemp(prefix="cice_mpi_")
     try:
         driver.write_rundir(rd, npt=25, nprocs=nprocs)
-        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(nprocs)}, nprocs=nprocs)
+        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(nprocs), "CICE4_AMD_STATS": "1"},
+                         nprocs=nprocs)
         hdr, rec = driver.read_restart(driver.restart_path(rd), 100, 116)
     finally:
         shutil.rmtree(rd, ignore_errors=True)
     assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
     assert ("EVP subcycling as one launch per task" in log) == (cfg == "gx3s2")
+    if nprocs == 1:     # all 2 x 2 blocks on one task: the one-launch loop on several blocks (round 4)
+        assert "on 4 block(s): 1 kernel launch(es)" in log, log[-3000:]
     assert "resident EVP loop timed out" not in log
     gold = np.load(os.path.join(GOLD, "step_gx3_default25.npz"))
     assert hdr["istep1"] == int(gold["istep1"]) and hdr["time"] == float(gold["time"])
@@ -280,9 +286,13 @@ def test_whole_model_on_120_blocks_with_eliminated_land_blocks():
         rec = {}
         for kind in exe:
             driver.write_rundir(dirs[kind], npt=6, istep0=19)
-            log = driver.run(exe[kind], dirs[kind])
+            log = driver.run(exe[kind], dirs[kind], env={"CICE4_AMD_STATS": "1", "CICE4_AMD_CHAIN": "1"})
             if kind == "dropin":
                 assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+                # round 4: 116 blocks on one rank subcycle in ONE launch (was: ndte launches + halo kernels), and the
+                # transport takes its state from the device after evp (cice_transport_chain)
+                assert "on 116 block(s): 1 kernel launch(es)" in log, log[-3000:]
+                assert "transport_remap takes its state from the device after evp" in log
             rec[kind] = driver.read_restart(driver.restart_path(dirs[kind]), 100, 116)
         assert rec["ref"][0] == rec["dropin"][0]
         for k in rec["ref"][1]:
