@@ -189,37 +189,6 @@ struct StepuOut {
   double u, v, strintx, strinty, taux, tauy;
 };
 
-// The same in two halves (same operations, same order, same bits): what does not depend on the stresses of the current
-// subcycle (:1390-1411) and what does (:1413-1425).  k_subcycle_skew can run the first half while the stresses load.
-struct StepuPre {
-  double taux, tauy, cca, ccb, ab2;
-};
-__device__ __forceinline__ void stepu_pre(double uold, double vold, double Aiu, double Uocn, double Vocn, double Waterx,
-                                          double Watery, double Umassdtei, double Fm, StepuPre& p) {
-  const double du = Uocn - uold, dv = Vocn - vold;
-  const double vrel = Aiu * dragw * sqrt(du * du + dv * dv);
-  p.taux = vrel * Waterx;
-  p.tauy = vrel * Watery;
-  p.cca = Umassdtei + vrel * cosw;
-#ifdef CICE4_AMD_AUSCOM
-  p.ccb = Fm < 0.0 ? Fm - vrel * sinw : Fm + vrel * sinw;
-#else
-  p.ccb = Fm + vrel * sinw;
-#endif
-  p.ab2 = p.cca * p.cca + p.ccb * p.ccb;
-}
-__device__ __forceinline__ void stepu_post(const StepuPre& p, double uold, double vold, double Umassdtei, double Forcex,
-                                           double Forcey, double Uarear, double sx, double sy, StepuOut& o) {
-  o.taux = p.taux;
-  o.tauy = p.tauy;
-  o.strintx = Uarear * sx;
-  o.strinty = Uarear * sy;
-  const double cc1 = o.strintx + Forcex + p.taux + Umassdtei * uold;
-  const double cc2 = o.strinty + Forcey + p.tauy + Umassdtei * vold;
-  o.u = (p.cca * cc1 + p.ccb * cc2) / p.ab2;
-  o.v = (p.cca * cc2 - p.ccb * cc1) / p.ab2;
-}
-
 // One U-cell of `stepu` (ice_dyn_evp.F90:1390-1435); sx/sy are the four-term sums of :1415-1418.
 __device__ __forceinline__ void stepu_cell(double uold, double vold, double Aiu, double Uocn,
                                            double Vocn, double Waterx, double Watery, double Forcex,
@@ -318,16 +287,13 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #define SKEW_TRIM 1
 #endif
 #ifndef SKEW_LOADPRIO    // highest issue priority while a step's loads are being issued, the rotation afterwards
-#define SKEW_LOADPRIO 0
+#define SKEW_LOADPRIO 1  // (0.1 degree: 278-283 us per subcycle against 281-285, A/B of round 4)
 #endif
 #ifndef SKEW_TPASS       // HTN, HTE, strength and the two masks of a row travel from level to level through LDS (K <= 4)
 #define SKEW_TPASS 0
 #endif
 #ifndef SKEW_EARLY       // a third slot for the hand-off of level 0: its stresses of the NEXT row are fetched before the barrier
 #define SKEW_EARLY 0
-#endif
-#ifndef SKEW_HOIST       // the part of the momentum equation that does not need this step's stresses runs before them
-#define SKEW_HOIST 0
 #endif
 // The same shifts with bound_ctrl: the lane without a source (lane 0 / lane 63) reads zero instead of keeping its own
 // value, which frees the compiler from copying the operand first (one instruction per half instead of two).  For
@@ -1229,16 +1195,6 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         if (!at_ilo) hew = hs;
       }
       const bool uact = urow && ucol && um_prev != 0;
-#if SKEW_HOIST
-      // the half of the momentum equation of U-row r-1 that needs no stress of this step: its inputs were the first
-      // loads of the step, so it runs while the stresses are still on their way
-      StepuPre pre{};
-      if (uact) {
-        double wx, wy;
-        water_of(xuo, xvo, xfm, wx, wy);
-        stepu_pre(us, vs, xa, xuo, xvo, wx, wy, xum, xfm, pre);
-      }
-#endif
       // ---- stress (ice_dyn_evp.F90:1065-1289)
       StressOut o;
 #pragma unroll
@@ -1292,12 +1248,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
               // mirrored by ihi+1, column ihi by ilo-1, same row (the table look-up costs the two strips at the ends
               // of the ring four dependent memory round trips per row)
               StepuOut ro;
-#if SKEW_HOIST
-              stepu_post(pre, us, vs, x.umassdtei, x.forcex, x.forcey, x.uarear, sx, sy, ro);
-#else
               stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                          x.uarear, sx, sy, ro);
-#endif
               const unsigned qu = q - nx8;
               st8(s_out, qu, ro.u);
               st8(s_out, qu + n8, ro.v);
@@ -1318,12 +1270,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
           }
         } else {
           StepuOut ro;
-#if SKEW_HOIST
-          stepu_post(pre, us, vs, x.umassdtei, x.forcex, x.forcey, x.uarear, sx, sy, ro);
-#else
           stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                      x.uarear, sx, sy, ro);
-#endif
           u1 = ro.u;
           v1 = ro.v;
         }
@@ -3080,6 +3028,9 @@ bool Evp::can_reside() const {
     // fold inside the loop is built for one block
     static const bool env_one = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_BLOCKS"); return e && e[0] == '0'; }();
     if (!res_blocks_on || env_one || halo.has_fold()) return false;
+    // (slab domains keep the copies between their blocks in the REFRESH list, even without overlap rows: those ghost rows
+    //  have no forwarding producer -- such a domain keeps its launch per subcycle)
+    if (halo.has_onrank_refresh()) return false;
   }
   if (halo.has_fold() && !res_fold_on) return false;   // the fold inside the loop: option "resident_fold"
   return resident_waves() > 0;

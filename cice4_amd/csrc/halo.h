@@ -37,6 +37,7 @@ class Halo {
   void set_link(LocalLink* l, int rank, int nranks);
   bool multi_rank() const { return remote_; }  // any message to exchange (normally: nranks > 1)
   bool has_refresh() const { return remote_ || nrefresh_ > 0 || nfill_ > 0; }
+  bool has_onrank_refresh() const { return nrefresh_ > 0; }   // block-to-block copies that are NOT in the every-subcycle list (create_slabs)
   // nfields fields of element type T, field k starting at base + k*stride (elements).
   // Always performs the refresh part (on-rank block-to-block rows of a wide-halo domain and all
   // off-rank messages); wrap = false skips the every-subcycle on-rank list (hsrc/hdst) because
