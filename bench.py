@@ -658,6 +658,24 @@ def pmc_traffic(workload, kernel_substr):
     return None, None
 
 
+def inkernel_clock(workload):
+    """Shader clock the dominant EVP kernel of `workload` holds under sustained load, from the archived in-kernel stamp run
+    (profiles/r*_inkernel_clock.csv: scripts/inkernel_clock.py with the diagnostic build -DCICE4_AMD_STAMPS -- s_memtime /
+    s_memrealtime around the loop after 2.5 s of back-to-back launches; the product build holds no stamp).  (GHz, source) or
+    (None, None)."""
+    import csv
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_inkernel_clock*.csv")), reverse=True):
+        try:
+            for row in csv.DictReader(open(path)):
+                if row["workload"] == workload:
+                    return float(row["clock_ghz_median"]), ("archived in-kernel stamps " + os.path.relpath(path, ROOT) +
+                                                             " (commit " + row.get("commit", "?") + ")")
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def pmc_counters(workload, kernel_substr):
     """VALU instructions per wavefront (and per subcycle) and per launch from an archived SQ counter pass
     (profiles/r*_sq_counters*.csv), newest round first; None if there is none for this kernel."""
@@ -774,7 +792,7 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") or ctx.evp_get_info("skew_fold") else 0
     if skew_k:
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
-                f"lanes, owns {62 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
+                f"lanes, owns {64 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
     if skew_k and dom.get("overlap") and dom["overlap"] % skew_k:
         progress(f"{wl}: {dom['overlap']} overlap rows are no multiple of K = {skew_k}: part of every refresh interval "
                  f"runs the pair kernel instead of sweeps (auto_overlap avoids this; --overlap was given)")
@@ -953,6 +971,11 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         if sq:   # the fraction that means something for this kernel: fp64 issue slots of the busiest SIMD that are used
             roofline["bound_effective"] = "valu_f64_issue"
             roofline["frac_valu_issue"] = roofline["not_hbm_bound"]["issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] / us_sub
+            ghz, src = inkernel_clock(wl)
+            if ghz:   # the same fraction at the clock the kernel really holds (2.4 GHz is the nominal figure)
+                roofline["clock_ghz"] = ghz
+                roofline["clock_source"] = src
+                roofline["frac_valu_issue_at_measured_clock"] = roofline["frac_valu_issue"] * 2.4 / ghz
     if skew_k and not resident:
         # The sweep moves the state once per K subcycles and is bound by fp64 issue, not by HBM: both fractions side by side.
         # VALU instructions per launch from the archived SQ pass (every one takes 4 cycles on a 16-lane SIMD; 1,024 SIMDs
@@ -965,6 +988,11 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                                 "counters_source": sq["source"], "counters_commit": sq.get("commit")}
             if roofline["frac_valu_issue"] > roofline["frac"]:
                 roofline["bound_effective"] = "valu_f64_issue"
+            ghz, src = inkernel_clock(wl)
+            if ghz:   # the sweep holds about 2.1 GHz, not the nominal 2.4: its issue fraction at the clock it runs at
+                roofline["clock_ghz"] = ghz
+                roofline["clock_source"] = src
+                roofline["frac_valu_issue_at_measured_clock"] = roofline["frac_valu_issue"] * 2.4 / ghz
     config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
               "subcycles_per_step": ndte,
               "decomposition": (f"1x{world} classic j-slabs, cross-rank one-launch loop (device-initiated exchange through the "

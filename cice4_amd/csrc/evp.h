@@ -56,6 +56,7 @@ class Evp {
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
+  int skew_strips(int K, int* shift) const;   // column strips of a block
   int skew_blocks(int K) const;    // workgroups per CU it is built for
   int skew_waves_per_simd(int K) const;
   bool can_fuse() const;     // two subcycles per launch on this domain

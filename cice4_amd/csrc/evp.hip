@@ -903,6 +903,7 @@ struct SkewArgs {
   int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
   long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
   long long* stamps;       // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups], see stamp_at
+  int own_shift;           // strip 0 owns one lane less (see the kernel's column geometry)
 };
 
 // WS: wavefronts per SIMD the kernel is built for (bounds the registers)
@@ -913,7 +914,13 @@ struct SkewArgs {
 template <int K, bool LAST, bool DAMP, int WS>
 __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa) {
   const SubArgs& a = sa.a;
-  constexpr int OWN0 = K + 1, OWNL = 62 - 2 * K;   // lanes OWN0 .. OWN0+OWNL-1 own their column
+  // Columns: a level loses one lane per side (the stress needs the western neighbour's velocity, the momentum equation
+  // the eastern neighbour's stress), so after K levels lanes K .. 63-K are right: a strip owns OWNW = 64 - 2K columns.
+  // Strip 0 starts at the ring's seam: its first owned lane is ilo, whose western neighbour ihi sits TWO lanes away (G in
+  // between) -- one lane more of rim, it owns lanes K+1 .. 63-K.  If that layout puts ihi on the last owned lane of a
+  // strip (G, with ilo behind it, would then be rim and need a lane more on that side), strip 0 gives up another lane
+  // (sa.own_shift = 1, Evp::skew_strips) and everything moves by one.
+  constexpr int OWNW = 64 - 2 * K;
   // EARLY: the hand-off of level 0 has THREE slots (row mod 3), s_sig0; the others two, s_sig[k - 1] for level k >= 1.
   // Level 0 can then put the stresses it has just formed into LDS at the END of its step (the slot was read two steps
   // ago) and fetch those of the next row into the same registers BEFORE the barrier: they are in flight during the
@@ -955,7 +962,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const bool cyc = a.ew_cyclic != 0;
   // column: ring position (0 = ilo, ncol = G) -> memory column, as in k_subcycle2
   const int ncol = ihi - ilo + 1;
-  const int kraw = txi * OWNL + lx - OWN0;
+  const int own0 = txi == 0 ? K + 1 + sa.own_shift : K;
+  const int kraw = (txi == 0 ? 0 : (OWNW - 1 - sa.own_shift) + (txi - 1) * OWNW) + lx - own0;
   int col = -1;
   if (cyc) {
     int kk = kraw % (ncol + 1);
@@ -967,7 +975,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const bool col_ok = col >= 1;
   const bool isG = cyc && col == ihi + 1;
   const bool at_ilo = cyc && col == ilo;
-  const bool own_col = lx >= OWN0 && lx < OWN0 + OWNL && kraw >= 0 && kraw <= ncol;
+  const bool own_col = lx >= own0 && lx <= 63 - K && kraw >= 0 && kraw <= ncol;
   const bool tcol = col_ok && col >= ilo;                 // (col <= ihi + 1 holds)
   const bool ucol = col_ok && col >= ilo && col <= ihi;
   const unsigned co = (unsigned)(col_ok ? col - 1 : 0) * 8u;
@@ -2777,6 +2785,19 @@ bool Evp::can_skew() const {
 
 int Evp::skew_levels() const { return skew_k_opt ? skew_k_opt : 4; }
 
+// Column strips of the sweep kernel (its geometry comment): strip 0 owns 63 - 2K - shift ring positions, every other
+// strip 64 - 2K; positions 0 .. ncol (ncol = the ghost column G, whose T-cell has stresses of its own).  shift = 1
+// where the plain layout would leave ihi (position ncol - 1) on the LAST owned lane of a strip.
+int Evp::skew_strips(int K, int* shift_out) const {
+  const int ncol = dom.nx_block - 2, ownw = 64 - 2 * K;
+  int shift = 0;
+  const int first = ownw - 1;                      // positions of strip 0 without the shift
+  if (ncol - 1 >= first - 1 && (ncol - 1 - (first - 1)) % ownw == 0) shift = 1;   // ihi = last position of strip t: 54 + 56 t (K = 4)
+  if (shift_out) *shift_out = shift;
+  const int f = first - shift, npos = ncol + 1;
+  return npos <= f ? 1 : 1 + (npos - f + ownw - 1) / ownw;
+}
+
 // wavefronts per SIMD the kernel is built for (registers), and the workgroups per CU that follow from it and from
 // the LDS a workgroup takes ((K-1) x 14 KB of 160 KB)
 int Evp::skew_waves_per_simd(int K) const {
@@ -2799,8 +2820,7 @@ int Evp::skew_seg_rows(int K) const {
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
-  const int ownl = 62 - 2 * K;
-  const long long strips = (long long)(((dom.nx_block - 2) + 1 + ownl - 1) / ownl) * dom.nblocks();
+  const long long strips = (long long)skew_strips(K, nullptr) * dom.nblocks();
   long long nseg = (long long)ncu * skew_blocks(K) / std::max(1LL, strips);
   nseg = std::max(1LL, std::min(nseg, (long long)std::max(1, rows / (4 * K))));
   return (int)((rows + nseg - 1) / nseg);
@@ -2866,9 +2886,8 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
   ++loop_launches;
   SkewArgs sa{};
   sa.a = make_args();
-  const int ownl = 62 - 2 * K;
   sa.seg_rows = skew_seg_rows(K);
-  sa.a.tiles_x = ((dom.nx_block - 2) + 1 + ownl - 1) / ownl;
+  sa.a.tiles_x = skew_strips(K, &sa.own_shift);
   sa.a.tiles_y = ((dom.ny_block - 2) + sa.seg_rows - 1) / sa.seg_rows;
   sa.prio_rotate = skew_prio;
   sa.rows = nullptr;
@@ -3753,8 +3772,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
   if (!can_skew() && can_skew_fold()) ensure_band(skew_levels());
   if ((can_skew() || can_skew_fold()) && skew_gen_pct > 0 && skew_seg_opt == 0) {   // the segment table of the sweep kernel, outside any capture
-    const int K = skew_levels(), ownl = 62 - 2 * K, seg = skew_seg_rows(K);
-    build_skew_rows(K, ((dom.nx_block - 2) + 1 + ownl - 1) / ownl, ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
+    const int K = skew_levels(), seg = skew_seg_rows(K);
+    build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
   bool replayed = false;
   loop_launches = 0;

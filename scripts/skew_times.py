@@ -35,7 +35,7 @@ for lo in range(0, n, max(1, n // 12)):
     if m.any():
         print(f"  blockIdx {lo:5d}..: start {st[sl][m].mean():8.1f}  end {en[sl][m].mean():8.1f}  (min {en[sl][m].min():8.1f} max {en[sl][m].max():8.1f})  dur {(en[sl][m]-st[sl][m]).mean():8.1f}")
 print("  end-time percentiles (us):", np.percentile(en[ok], [0, 10, 25, 50, 75, 90, 100]).round(1))
-tiles_x = -(-3601 // (62 - 2 * K))
+tiles_x = ctx.evp_get_info("skew_strips")
 segr = ctx.evp_get_info("skew_seg_rows")
 tiles_y = -(-2400 // segr)
 nt = tiles_x * tiles_y

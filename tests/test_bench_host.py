@@ -82,3 +82,10 @@ def test_archived_counter_passes_are_found_for_the_kernels_the_bench_reports():
         assert sq and 500 < sq["valu_per_wave_subcycle"] < 700, k
     sq = bench.pmc_counters("tenth", "k_subcycle_skew<4, false, false")
     assert sq and 500 < sq["valu_per_wave_subcycle"] and sq["valu_insts_per_launch"] > 1e8 and sq.get("commit")
+
+
+def test_archived_inkernel_clock_is_found():
+    """the issue fractions are also reported at the clock the kernels really hold (in-kernel stamps)."""
+    for wl in ("gx1", "tenth"):
+        ghz, src = bench.inkernel_clock(wl)
+        assert ghz and 1.2 < ghz < 2.6 and "inkernel_clock" in src, wl

@@ -770,11 +770,14 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
 
 @pytest.mark.parametrize("nxg,nyg,ew", [(96, 70, 1), (20, 33, 1), (53, 18, 1), (54, 18, 1), (55, 18, 1), (107, 9, 1),
                                          (109, 41, 1), (119, 5, 1), (200, 50, 1), (96, 70, 0), (130, 27, 2), (7, 6, 1),
-                                         (300, 120, 1)])
+                                         (300, 120, 1), (56, 12, 1), (57, 15, 1), (110, 12, 1), (111, 14, 1), (112, 11, 1),
+                                         (167, 13, 1), (111, 14, 2), (115, 12, 1), (103, 12, 1), (95, 14, 1)])
 def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
     """k_subcycle_skew (K subcycles in one sweep: a pipeline of K time levels, one wavefront each, two rows apart,
     rows handed from level to level through LDS) against one launch per subcycle and the checker: bit for bit.
-    Every K; widths around the strip strides (62 - 2K columns), blocks narrower than a strip (the ring wraps inside
+    Every K; widths around the strip strides (64 - 2K columns, the strip at the ring's seam one less; widths 55, 111, 167
+    (K = 4), 119 (K = 2), 115 (K = 3), 53, 107 (K = 5), 103 (K = 6), 95 (K = 8) are the ones where ihi would fall on a strip's
+    last owned lane and the layout shifts by one), blocks narrower than a strip (the ring wraps inside
     one wavefront), open / closed E-W edges; row segments of 1 .. many rows (interior segment ends: K rim rows) and
     the automatic choice, segments of unequal length (longer ones for the workgroups dispatched first) and the rotation
     of issue priorities; subcycle counts that are no multiple of K (the rest runs as pairs / single launches);
