@@ -10,6 +10,7 @@
 namespace cice {
 
 struct SubArgs;  // kernel argument block (evp.hip)
+struct SkewArgs; // ... of the sweep kernel
 
 struct EvpScalars {  // set_evp_parameters, ice_dyn_evp.F90:535-577
   double dtei, dte2T, denom1, denom2, rcon, ecci;
@@ -53,6 +54,7 @@ class Evp {
   bool peer_buffers_fine() const { return res_xu[0].fine && res_xu[1].fine && res_rprog.fine; }   // what other devices write / poll is fine-grained memory
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
+  bool can_split() const;    // ... and the sweep in front of a wide-halo refresh as edge + interior launches
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
@@ -177,6 +179,16 @@ class Evp {
   void launch_subcycle(int ksub);
   void launch_subcycle_pair(int ksub);
   void launch_subcycle_skew(int ksub, int K, bool flip_and_halo = true);
+  void skew_args(SkewArgs& sa, int K);
+  void skew_launch(const SkewArgs& sa, int K, bool last, int nt, hipStream_t s);
+  // the sweep in front of a wide-halo refresh as two launches: edge segments + refresh on the main stream, interior beside them
+  bool split_on = true, in_capture = false;
+  void build_split(int K);
+  void launch_subcycle_skew_split(int ksub, int K);
+  DevBuf<int32_t> split_tab;
+  int split_key[4] = {0, 0, 0, 0}, split_edge = 0, split_total = 0;
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void launch_range(int ksub0, int nsub);
   void after_subcycle(int ksub);
   SubArgs make_args() const;

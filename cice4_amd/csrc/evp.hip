@@ -890,6 +890,8 @@ __device__ __forceinline__ void stamp_at(long long* stamps, int slot) {
 #endif
 }
 
+}  // namespace
+
 struct SkewArgs {
   SubArgs a;               // only what the kernel names is fetched from the argument block
   const double* st_in;     // u, v, 12 stresses of the current state: 14 planes of a.n doubles
@@ -903,8 +905,15 @@ struct SkewArgs {
   int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
   long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
   long long* stamps;       // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups], see stamp_at
-  int own_shift;           // strip 0 owns one lane less (see the kernel's column geometry)
+  int own_shift;           // strip 0 owns this many lanes less (see the kernel's column geometry)
+  // a launch over an explicit LIST of tiles (Evp::build_split: the sweep in front of a wide-halo refresh runs as two
+  // launches, the segments the neighbours wait for first): [4 per tile] block, strip, first and last owned row relative
+  // to jlo; this launch covers tile_count entries from tile_first on.  NULL: every tile of the (strip x segment) grid.
+  const int32_t* tiles;
+  int tile_first, tile_count;
 };
+
+namespace {
 
 // WS: wavefronts per SIMD the kernel is built for (bounds the registers)
 //
@@ -917,9 +926,9 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   // Columns: a level loses one lane per side (the stress needs the western neighbour's velocity, the momentum equation
   // the eastern neighbour's stress), so after K levels lanes K .. 63-K are right: a strip owns OWNW = 64 - 2K columns.
   // Strip 0 starts at the ring's seam: its first owned lane is ilo, whose western neighbour ihi sits TWO lanes away (G in
-  // between) -- one lane more of rim, it owns lanes K+1 .. 63-K.  If that layout puts ihi on the last owned lane of a
-  // strip (G, with ilo behind it, would then be rim and need a lane more on that side), strip 0 gives up another lane
-  // (sa.own_shift = 1, Evp::skew_strips) and everything moves by one.
+  // between) -- one lane more of rim, it owns lanes K+1 .. 63-K.  If that layout puts G into the east rim of a strip within
+  // K-1 lanes of its last owned lane (the dependency path crosses G without gaining a level and would need a lane more),
+  // strip 0 gives up sa.own_shift lanes and everything moves west until G sits on that strip's lane 63 (Evp::skew_strips).
   constexpr int OWNW = 64 - 2 * K;
   // EARLY: the hand-off of level 0 has THREE slots (row mod 3), s_sig0; the others two, s_sig[k - 1] for level k >= 1.
   // Level 0 can then put the stresses it has just formed into LDS at the END of its step (the slot was read two steps
@@ -936,13 +945,25 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   __shared__ double s_tin[TP ? K - 1 : 1][2][3][TX];
   __shared__ int s_msk[TP ? K - 1 : 1][2][TX];
   const int per_blk = a.tiles_x * a.tiles_y;
-  const int nt = per_blk * a.nblocks;
+  const int nt = sa.tiles ? sa.tile_count : per_blk * a.nblocks;
   const int chunk = (nt + 7) >> 3;
-  const int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  int tile_lin = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (tile_lin >= nt) return;  // whole workgroup
-  const int b = tile_lin / per_blk;
-  const int rem = tile_lin - b * per_blk;
-  const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
+  int b, rem, tyi, txi, ja_rel = 0, jb_rel = -1;
+  if (sa.tiles) {
+    tile_lin += sa.tile_first;
+    b = sa.tiles[4 * tile_lin];
+    txi = sa.tiles[4 * tile_lin + 1];
+    ja_rel = sa.tiles[4 * tile_lin + 2];
+    jb_rel = sa.tiles[4 * tile_lin + 3];
+    rem = 0;
+    tyi = 0;
+  } else {
+    b = tile_lin / per_blk;
+    rem = tile_lin - b * per_blk;
+    tyi = rem / a.tiles_x;
+    txi = rem - tyi * a.tiles_x;
+  }
   const int ilo = a.blk[6 * b + 0], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   const int lx = threadIdx.x & 63;
   // time level of this wavefront (uniform); dealt differently from workgroup to workgroup, so that the wavefronts
@@ -984,7 +1005,10 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   // rows: this workgroup owns U-rows ja..jb (and T-rows ja..jb, the last segment T-row jhi+1 as well); every level
   // walks T-rows jt0..jt1, level k two rows behind level k-1
   int ja = jlo + tyi * sa.seg_rows, jb = min(ja + sa.seg_rows - 1, jhi);
-  if (sa.rows) {   // segments of unequal length (Evp::build_skew_rows): per tile of a block
+  if (sa.tiles) {
+    ja = jlo + ja_rel;
+    jb = jlo + jb_rel;
+  } else if (sa.rows) {   // segments of unequal length (Evp::build_skew_rows): per tile of a block
     ja = jlo + sa.rows[2 * rem];
     jb = jlo + sa.rows[2 * rem + 1];
   }
@@ -2208,6 +2232,9 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 Evp::~Evp() {
   drop_graph();
   if (res_done_ev) (void)hipEventDestroy(res_done_ev);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
+  if (ev_join) (void)hipEventDestroy(ev_join);
+  if (stream2) (void)hipStreamDestroy(stream2);
 }
 
 void Evp::drop_graph() {
@@ -2277,6 +2304,8 @@ void Evp::set_option(const char* key, int value) {
     skew_debug = value != 0;
   } else if (!std::strcmp(key, "stamps")) {      // diagnostic build (-DCICE4_AMD_STAMPS): cycle / wall-clock stamps per workgroup
     stamps_on = value != 0;
+  } else if (!std::strcmp(key, "skew_split")) {  // the sweep in front of a wide-halo refresh as edge + interior launches
+    split_on = value != 0;
   } else if (!std::strcmp(key, "skew_prio")) {   // rotate issue priorities among the workgroups of a CU
     skew_prio = value;
   } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
@@ -2792,7 +2821,13 @@ int Evp::skew_strips(int K, int* shift_out) const {
   const int ncol = dom.nx_block - 2, ownw = 64 - 2 * K;
   int shift = 0;
   const int first = ownw - 1;                      // positions of strip 0 without the shift
-  if (ncol - 1 >= first - 1 && (ncol - 1 - (first - 1)) % ownw == 0) shift = 1;   // ihi = last position of strip t: 54 + 56 t (K = 4)
+  // G (position ncol) d = 1 .. K-1 positions beyond the last owned position of a strip lies in that strip's east rim ON
+  // the dependency path of its last column: the path does not gain a level there (G's velocity is the next lane's), so
+  // it ends one lane beyond lane 63.  Strip 0 gives up K - d lanes: G then sits on lane 63, where only level 0 reads it.
+  if (ncol > first - 1) {
+    const int d = (ncol - (first - 1) - 1) % ownw + 1;   // distance of G from the last owned position at or below it
+    if (d <= K - 1) shift = K - d;
+  }
   if (shift_out) *shift_out = shift;
   const int f = first - shift, npos = ncol + 1;
   return npos <= f ? 1 : 1 + (npos - f + ownw - 1) / ownw;
@@ -2881,49 +2916,154 @@ static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hip
   }
 }
 
-// subcycles ksub .. ksub+K-1
-void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
-  ++loop_launches;
-  SkewArgs sa{};
+// the arguments every launch of the sweep kernel shares
+void Evp::skew_args(SkewArgs& sa, int K) {
   sa.a = make_args();
   sa.seg_rows = skew_seg_rows(K);
   sa.a.tiles_x = skew_strips(K, &sa.own_shift);
   sa.a.tiles_y = ((dom.ny_block - 2) + sa.seg_rows - 1) / sa.seg_rows;
   sa.prio_rotate = skew_prio;
   sa.rows = nullptr;
-  if (skew_gen_pct > 0 && skew_seg_opt == 0) {   // (built by subcycles() before any capture: it uploads a table)
-    build_skew_rows(K, sa.a.tiles_x, sa.a.tiles_y, sa.a.nblocks, sa.seg_rows);
-    sa.rows = skew_rows.p;
-  }
   sa.fwd_rule = fwd_is_ew_wrap ? 1 : 0;
   sa.dbg = nullptr;
-  if (skew_debug) {
-    const size_t want = 2 * (size_t)(8 * ((sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks + 7) / 8));
-    if (skew_dbg.n < want) skew_dbg.alloc(want);
-    sa.dbg = skew_dbg.p;
-  }
-  sa.stamps = stamp_buffer(8 * ((sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks + 7) / 8));
+  sa.stamps = nullptr;
   sa.stagger_ticks = skew_stagger_ns / 10;
   sa.stagger_mod = std::max(1, skew_blocks(K));
   sa.st_in = st[cur].p;
   sa.st_out = st[1 - cur].p;
   sa.uar = uarena.p;
-  const bool last = ksub + K - 1 == sc.ndte;
-  const int nt = sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks;
+  sa.tiles = nullptr;
+  sa.tile_first = sa.tile_count = 0;
+}
+
+void Evp::skew_launch(const SkewArgs& sa, int K, bool last, int nt, hipStream_t s) {
   const dim3 g(8 * ((nt + 7) / 8));
   const bool damp = sc.evp_damping != 0;
   const int WS = skew_waves_per_simd(K);
   switch (K * 10 + WS) {
-    case 23: launch_skew_kb<2, 3>(sa, last, damp, g, stream); break;
-    case 33: launch_skew_kb<3, 3>(sa, last, damp, g, stream); break;
-    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, stream); break;
-    case 42: launch_skew_kb<4, 2>(sa, last, damp, g, stream); break;
-    case 53: launch_skew_kb<5, 3>(sa, last, damp, g, stream); break;
-    case 63: launch_skew_kb<6, 3>(sa, last, damp, g, stream); break;
-    case 82: launch_skew_kb<8, 2>(sa, last, damp, g, stream); break;
+    case 23: launch_skew_kb<2, 3>(sa, last, damp, g, s); break;
+    case 33: launch_skew_kb<3, 3>(sa, last, damp, g, s); break;
+    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s); break;
+    case 42: launch_skew_kb<4, 2>(sa, last, damp, g, s); break;
+    case 53: launch_skew_kb<5, 3>(sa, last, damp, g, s); break;
+    case 63: launch_skew_kb<6, 3>(sa, last, damp, g, s); break;
+    case 82: launch_skew_kb<8, 2>(sa, last, damp, g, s); break;
     default: throw Error{CICE_EINVAL, "unsupported (skew_levels, skew_blocks) combination"};
   }
+}
+
+// subcycles ksub .. ksub+K-1
+void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
+  ++loop_launches;
+  SkewArgs sa{};
+  skew_args(sa, K);
+  if (skew_gen_pct > 0 && skew_seg_opt == 0) {   // (built by subcycles() before any capture: it uploads a table)
+    build_skew_rows(K, sa.a.tiles_x, sa.a.tiles_y, sa.a.nblocks, sa.seg_rows);
+    sa.rows = skew_rows.p;
+  }
+  const int nt = sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks;
+  if (skew_debug) {
+    const size_t want = 2 * (size_t)(8 * ((nt + 7) / 8));
+    if (skew_dbg.n < want) skew_dbg.alloc(want);
+    sa.dbg = skew_dbg.p;
+  }
+  sa.stamps = stamp_buffer(8 * ((nt + 7) / 8));
+  skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, stream);
   if (flip_and_halo) after_subcycle(ksub + K - 1);
+}
+
+// ---- the sweep in front of a wide-halo refresh: the rows the neighbours wait for FIRST ------------------------------
+// A slab of a domain cut across ranks (cice_domain_create_slabs, overlap H) refreshes its H + 1 outer rows from their
+// owners every H subcycles: pack -> one message per neighbour -> unpack, ~3.6 MB per neighbour at 0.1 degree / 8 ranks
+// (DESIGN.md section 7).  Run after the sweep it costs its full time; but only the H + 1 owned rows at either end of
+// the slab are sent, and the rows that are received are not read before the NEXT sweep.  So the last sweep before a
+// refresh runs as TWO launches over an explicit tile list (SkewArgs::tiles): the edge segments -- owned rows
+// own_jlo .. own_jlo + H and own_jhi - H .. own_jhi, where there is a neighbour -- on the main stream, followed there by
+// the refresh; the interior segments on a second stream, beside both.  The extension rows themselves are not computed
+// in this sweep at all: the refresh overwrites them (all 14 planes, whole rows).  Edge segments are short (H + 1 rows
+// against ~30), so the edge launch ends at about half the interior's time and the exchange has the other half.
+// Same arithmetic on every owned row as the one-launch sweep: a segment's rows depend on the rows of the state the sweep
+// starts from, not on which launch computes its neighbours.
+bool Evp::can_split() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SPLIT"); return e && e[0] == '0'; }();
+  if (!split_on || env_off || in_capture) return false;
+  if (dom.overlap <= 0 || !halo.multi_rank() || halo.has_fold() || dom.nblocks() < 1) return false;
+  const int K = skew_levels(), H = dom.overlap;
+  for (int gid : dom.local) {
+    const Block& b = dom.all[gid];
+    if (b.own_jhi - b.own_jlo + 1 < 2 * (H + 1) + 4 * K) return false;   // edges and at least one interior segment of 4K rows
+  }
+  return true;
+}
+
+void Evp::build_split(int K) {
+  const int H = dom.overlap, S = skew_strips(K, nullptr), nb = dom.nblocks();
+  const int key[4] = {K, H, S, nb};
+  if (split_tab.n && !std::memcmp(key, split_key, sizeof(key))) return;
+  int ncu = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+  }
+  std::vector<int32_t> edge, inner;
+  int nedge_seg = 0;
+  for (int l = 0; l < nb; ++l) {
+    const Block& b = dom.all[dom.local[l]];
+    int lo = b.own_jlo, hi = b.own_jhi;      // rows left for the interior
+    if (b.own_jlo > b.jlo) {                 // a neighbour to the south: its refresh reads our first H + 1 owned rows
+      for (int t = 0; t < S; ++t) edge.insert(edge.end(), {l, t, b.own_jlo - b.jlo, b.own_jlo + H - b.jlo});
+      lo = b.own_jlo + H + 1;
+      ++nedge_seg;
+    }
+    if (b.own_jhi < b.jhi) {
+      for (int t = 0; t < S; ++t) edge.insert(edge.end(), {l, t, b.own_jhi - H - b.jlo, b.own_jhi - b.jlo});
+      hi = b.own_jhi - H - 1;
+      ++nedge_seg;
+    }
+    inner.insert(inner.end(), {l, lo, hi, 0});   // (filled below, once the number of interior segments is known)
+  }
+  // as many workgroups as the chip holds at once, like the one-launch sweep (skew_seg_rows)
+  const long long slots = (long long)ncu * skew_blocks(K);
+  std::vector<int32_t> tab = edge;
+  for (size_t e = 0; e + 3 < inner.size(); e += 4) {
+    const int l = inner[e], lo = inner[e + 1], hi = inner[e + 2], rows = hi - lo + 1;
+    long long nseg = (slots - (long long)nedge_seg * S) / std::max(1LL, (long long)S * nb);
+    nseg = std::max(1LL, std::min(nseg, (long long)std::max(1, rows / (4 * K))));
+    const Block& b = dom.all[dom.local[l]];
+    for (int g = 0; g < (int)nseg; ++g) {
+      const int a0 = lo + (int)((long long)rows * g / nseg), a1 = lo + (int)((long long)rows * (g + 1) / nseg) - 1;
+      for (int t = 0; t < S; ++t) tab.insert(tab.end(), {l, t, a0 - b.jlo, a1 - b.jlo});
+    }
+  }
+  split_edge = (int)(edge.size() / 4);
+  split_total = (int)(tab.size() / 4);
+  split_tab.alloc(tab.size());
+  split_tab.upload(tab.data(), stream);
+  CICE_HIP(hipStreamSynchronize(stream));
+  if (!stream2) CICE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  if (!ev_fork) CICE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  if (!ev_join) CICE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  std::memcpy(split_key, key, sizeof(key));
+}
+
+void Evp::launch_subcycle_skew_split(int ksub, int K) {
+  loop_launches += 2;
+  SkewArgs sa{};
+  skew_args(sa, K);
+  sa.tiles = split_tab.p;
+  const bool last = ksub + K - 1 == sc.ndte;
+  // the interior beside everything that follows on the main stream
+  CICE_HIP(hipEventRecord(ev_fork, stream));
+  CICE_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
+  sa.tile_first = 0;
+  sa.tile_count = split_edge;
+  if (split_edge) skew_launch(sa, K, last, split_edge, stream);
+  sa.tile_first = split_edge;
+  sa.tile_count = split_total - split_edge;
+  skew_launch(sa, K, last, sa.tile_count, stream2);
+  CICE_HIP(hipEventRecord(ev_join, stream2));
+  after_subcycle(ksub + K - 1);          // flips the copies; the refresh follows the edge launch on the main stream
+  CICE_HIP(hipStreamWaitEvent(stream, ev_join, 0));
 }
 
 // ---- K subcycles per sweep on a grid with a tripole fold ----------------------------------------------------------
@@ -3727,6 +3867,7 @@ void Evp::launch_range(int ksub0, int nsub) {
   const bool fuse = can_fuse();
   const bool skew = can_skew(), skew_fold = !skew && can_skew_fold();
   const int K = skew_levels();
+  const bool split = skew && can_split();
   const int end = ksub0 + nsub - 1;
   for (int k = ksub0; k <= end;) {
     // a wide-halo refresh falls after subcycles that are multiples of `overlap`: a launch must not straddle one,
@@ -3739,7 +3880,9 @@ void Evp::launch_range(int ksub0, int nsub) {
       return true;
     };
     if (skew && clear(K)) {
-      launch_subcycle_skew(k, K);
+      const int kend = k + K - 1;
+      if (split && (kend % dom.overlap == 0 || kend == sc.ndte)) launch_subcycle_skew_split(k, K);   // a refresh follows
+      else launch_subcycle_skew(k, K);
       k += K;
     } else if (skew_fold && clear(K)) {
       launch_subcycle_skew_fold(k, K);
@@ -3775,6 +3918,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     const int K = skew_levels(), seg = skew_seg_rows(K);
     build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
+  if (can_skew() && can_split()) build_split(skew_levels());   // (uploads a table: outside any capture)
   bool replayed = false;
   loop_launches = 0;
   if (nsub >= 2 && (can_reside() || can_reside_peer())) {
@@ -3793,18 +3937,21 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
       try {
         CICE_HIP(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         capturing = true;
+        in_capture = true;
         flips = 0;
         loop_launches = 0;
         launch_range(ksub0, nsub);
         graph_flips = flips;
         graph_launches = loop_launches;
         capturing = false;
+        in_capture = false;
         CICE_HIP(hipStreamEndCapture(stream, &gph));
         CICE_HIP(hipGraphInstantiate(&graph_exec, gph, nullptr, nullptr, 0));
         CICE_HIP(hipGraphDestroy(gph));
         std::memcpy(graph_key, key, sizeof(key));
       } catch (const Error&) {
         // capture not possible here: close it, forget graphs for this context, run eagerly
+        in_capture = false;
         if (capturing) (void)hipStreamEndCapture(stream, &gph);
         if (gph) (void)hipGraphDestroy(gph);
         (void)hipGetLastError();

@@ -3,8 +3,9 @@
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_evp.py tests/test_gpu_fullsize.py tests/test_gpu_auscom.py -x -q -k "k_subcycles_per_sweep or wide_halo or sweeps_on_a_tripole or tenth or ranks_in_one_process or sweep or auscom" 2>&1 | tail -4 | cut -c1-300 | tee gpurun_out/r4_tests6.txt
-grep -q "passed" gpurun_out/r4_tests6.txt && ! grep -q "failed" gpurun_out/r4_tests6.txt || exit 1
+timeout -k 10 1100 python -m pytest tests/test_gpu_evp.py tests/test_gpu_fullsize.py tests/test_gpu_auscom.py tests/test_gpu_multiproc.py -x -q -k "k_subcycles_per_sweep or wide_halo or sweeps_on_a_tripole or tenth or ranks_in_one_process or sweep or auscom or slabs or rank_processes or bench" > gpurun_out/r4_tests6.log 2>&1
+grep -E "passed|failed|error" gpurun_out/r4_tests6.log | tail -3 | cut -c1-300 | tee gpurun_out/r4_tests6.txt
+grep -q "passed" gpurun_out/r4_tests6.txt && ! grep -q "failed" gpurun_out/r4_tests6.txt || { grep -B30 "short test summary" gpurun_out/r4_tests6.log | tail -45 | cut -c1-250; exit 1; }
 B="--steps 4 --warmup 1 --no-thermo --no-cpu-baseline --no-dropin-timing --no-tenth"
 : > gpurun_out/r4_ab6.txt
 for rep in 1 2 3; do

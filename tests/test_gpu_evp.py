@@ -525,7 +525,9 @@ _LINK = [1000]
 
 
 @pytest.mark.parametrize("mode,R,nyg", [("classic", 2, 72), ("peer", 2, 72), ("peer", 3, 72), ("peer", 2, 16), ("slabs4", 2, 72),
-                                       ("slabs4", 3, 72), ("slabs6-sweep", 2, 96), ("peer-cyclic", 2, 40)])
+                                       ("slabs4", 3, 72), ("slabs6-sweep", 2, 96), ("peer-cyclic", 2, 40),
+                                       ("slabs8-sweep4", 2, 128), ("slabs8-sweep4", 3, 192), ("slabs4-sweep4", 2, 96),
+                                       ("slabs8-sweep4-nosplit", 2, 128)])
 def test_ranks_in_one_process(orc, mode, R, nyg):
     """The multi-rank path with R ranks = R contexts of this process on the one GPU, one host thread each, messages through
     the in-process link (cice_comm_init_local: pack kernel -> host mailbox -> unpack kernel), against the single-domain
@@ -537,7 +539,9 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                2 and 3 ranks (a middle rank has two neighbours), slabs one tile tall, cyclic north-south (both
                neighbours are the same rank);
       slabs    wide-halo slabs as bench.py --gpus N cuts them (refresh of u, v, 12 sigma every H subcycles), pairs of
-               subcycles per launch and, "sweep", K subcycles per sweep between the refreshes."""
+               subcycles per launch and, "sweep", K subcycles per sweep between the refreshes (K = 3, "sweep4": K = 4 with
+               H = 8 -- what bench.auto_overlap picks -- and H = 4); the sweep in front of a refresh is split into edge
+               and interior launches, the refresh overlapping the interior ("nosplit": the one-launch form)."""
     import threading
     nxg = 96
     ns = 1 if mode == "peer-cyclic" else 0
@@ -582,9 +586,14 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                 bar.wait(timeout=60)
             else:
                 c.evp_set_option("resident", 0)
-                if mode.endswith("sweep"):
-                    c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", 3)
+                if "sweep" in mode:
+                    c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", 4 if "sweep4" in mode else 3)
                     assert c.evp_get_info("skew") == 1
+                    # the sweep in front of every refresh runs as two launches: the edge segments, followed by the
+                    # refresh, on the main stream; the interior beside them on a second one (round 4)
+                    if mode.endswith("nosplit"):
+                        c.evp_set_option("skew_split", 0)
+                    assert c.evp_get_info("skew_split") == (0 if mode.endswith("nosplit") else 1)
                 else:
                     c.evp_set_option("skew", 0)
             c.evp(DT, s)
