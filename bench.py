@@ -96,6 +96,9 @@ def parse():
     p.add_argument("--skew-gen-pct", type=int, default=-1, help="longer row segments for the workgroups dispatched first; -1 = library's choice")
     p.add_argument("--skew-prio", type=int, default=-1, help="rotate issue priorities among workgroups of a CU; -1 = library's choice")
     p.add_argument("--skew-stagger-ns", type=int, default=-1, help="start delay between workgroups sharing a CU; -1 = library's choice")
+    p.add_argument("--skew-split-probe", type=int, default=0,
+                   help="measurement aid: cut a one-block grid as an interior slab with this many overlap rows and run every "
+                        "sweep as edge + interior launches (results are not meaningful)")
     p.add_argument("--no-derive", action="store_true", help="load the 9 T-cell metrics instead of recomputing them")
     p.add_argument("--calibrate", action="store_true",
                    help="also run the 8-B-per-lane calibration copy (k_diag_copy8, 2 x 256 MiB) for PMC runs")
@@ -788,6 +791,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         ctx.evp_set_option("skew_prio", args.skew_prio)
     if args.skew_stagger_ns >= 0:
         ctx.evp_set_option("skew_stagger_ns", args.skew_stagger_ns)
+    if getattr(args, "skew_split_probe", 0):
+        ctx.evp_set_option("skew_split_probe", args.skew_split_probe)
+        ctx.evp_set_option("use_graph", 0)
     # (on a folded grid the sweep runs with a band of top rows beside it: "skew_fold"; the sweep is still the launch that counts)
     skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") or ctx.evp_get_info("skew_fold") else 0
     if skew_k:

@@ -1,6 +1,7 @@
 // Device-resident EVP dynamics: state, kernels' launch wrappers.
 #pragma once
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "common.h"
@@ -55,6 +56,7 @@ class Evp {
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
   bool can_split() const;    // ... and the sweep in front of a wide-halo refresh as edge + interior launches
+  bool can_trim() const;     // sweeps on wide-halo slabs over tile lists (extension rows trimmed)
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
@@ -185,8 +187,12 @@ class Evp {
   bool split_on = true, in_capture = false;
   void build_split(int K);
   void launch_subcycle_skew_split(int ksub, int K);
-  DevBuf<int32_t> split_tab;
-  int split_key[4] = {0, 0, 0, 0}, split_edge = 0, split_total = 0;
+  void launch_subcycle_skew_ext(int ksub, int K, int ext);
+  bool trim_ext_on = true;
+  int split_probe = 0;
+  struct TileTab { int K, ext, S, nb, edge, total; bool split; DevBuf<int32_t> tab; };
+  std::vector<std::unique_ptr<TileTab>> tile_tabs;
+  const TileTab& tiles_for(int K, int ext, bool split);
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   void launch_range(int ksub0, int nsub);

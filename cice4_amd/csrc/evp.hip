@@ -2306,6 +2306,12 @@ void Evp::set_option(const char* key, int value) {
     stamps_on = value != 0;
   } else if (!std::strcmp(key, "skew_split")) {  // the sweep in front of a wide-halo refresh as edge + interior launches
     split_on = value != 0;
+  } else if (!std::strcmp(key, "skew_split_probe")) {   // measurement aid, see Evp::tiles_for (wrong results by design)
+    CICE_REQUIRE(value >= 0 && value <= 64, "skew_split_probe must be 0 .. 64");
+    split_probe = value;
+    tile_tabs.clear();
+  } else if (!std::strcmp(key, "skew_trim_ext")) {  // sweeps on wide-halo slabs compute only the extension rows still needed
+    trim_ext_on = value != 0;
   } else if (!std::strcmp(key, "skew_prio")) {   // rotate issue priorities among the workgroups of a CU
     skew_prio = value;
   } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
@@ -2987,6 +2993,13 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
 bool Evp::can_split() const {
   static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SPLIT"); return e && e[0] == '0'; }();
   if (!split_on || env_off || in_capture) return false;
+  return can_trim();
+}
+
+// sweeps over tile lists (extension rows trimmed to what the next sweeps need): wide-halo slabs with neighbours
+bool Evp::can_trim() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW_TRIM_EXT"); return e && e[0] == '0'; }();
+  if (!trim_ext_on || env_off) return false;
   if (dom.overlap <= 0 || !halo.multi_rank() || halo.has_fold() || dom.nblocks() < 1) return false;
   const int K = skew_levels(), H = dom.overlap;
   for (int gid : dom.local) {
@@ -2996,10 +3009,16 @@ bool Evp::can_split() const {
   return true;
 }
 
-void Evp::build_split(int K) {
-  const int H = dom.overlap, S = skew_strips(K, nullptr), nb = dom.nblocks();
-  const int key[4] = {K, H, S, nb};
-  if (split_tab.n && !std::memcmp(key, split_key, sizeof(key))) return;
+// Tile list of a sweep on a wide-halo slab domain that computes the owned rows and `ext` extension rows beyond them at
+// either end (where there is a neighbour): after a sweep only as many extension rows have to be right as there are
+// subcycles left until the next refresh -- none in front of the refresh itself.  split: the segments the neighbours wait
+// for (the first / last H + 1 owned rows) come first in the list (edge tiles), the rest behind them (ext = 0 only).
+const Evp::TileTab& Evp::tiles_for(int K, int ext, bool split) {
+  // (split_probe: a measurement aid -- a one-block domain WITHOUT neighbours is cut as if it were an interior slab with
+  //  split_probe overlap rows at either end: the kernel cost of the edge + interior form at the deployment's geometry)
+  const int H = split_probe > 0 ? split_probe : dom.overlap, S = skew_strips(K, nullptr), nb = dom.nblocks();
+  for (const auto& t : tile_tabs)
+    if (t->K == K && t->ext == ext && t->split == split && t->S == S && t->nb == nb) return *t;
   int ncu = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
     int v = 0;
@@ -3008,19 +3027,23 @@ void Evp::build_split(int K) {
   std::vector<int32_t> edge, inner;
   int nedge_seg = 0;
   for (int l = 0; l < nb; ++l) {
-    const Block& b = dom.all[dom.local[l]];
-    int lo = b.own_jlo, hi = b.own_jhi;      // rows left for the interior
-    if (b.own_jlo > b.jlo) {                 // a neighbour to the south: its refresh reads our first H + 1 owned rows
+    Block b = dom.all[dom.local[l]];
+    if (split_probe > 0) {
+      b.own_jlo = b.jlo + split_probe;
+      b.own_jhi = b.jhi - split_probe;
+    }
+    int lo = std::max(b.jlo, b.own_jlo - ext), hi = std::min(b.jhi, b.own_jhi + ext);   // rows this sweep computes
+    if (split && b.own_jlo > b.jlo) {        // a neighbour to the south: its refresh reads our first H + 1 owned rows
       for (int t = 0; t < S; ++t) edge.insert(edge.end(), {l, t, b.own_jlo - b.jlo, b.own_jlo + H - b.jlo});
       lo = b.own_jlo + H + 1;
       ++nedge_seg;
     }
-    if (b.own_jhi < b.jhi) {
+    if (split && b.own_jhi < b.jhi) {
       for (int t = 0; t < S; ++t) edge.insert(edge.end(), {l, t, b.own_jhi - H - b.jlo, b.own_jhi - b.jlo});
       hi = b.own_jhi - H - 1;
       ++nedge_seg;
     }
-    inner.insert(inner.end(), {l, lo, hi, 0});   // (filled below, once the number of interior segments is known)
+    inner.insert(inner.end(), {l, lo, hi, 0});
   }
   // as many workgroups as the chip holds at once, like the one-launch sweep (skew_seg_rows)
   const long long slots = (long long)ncu * skew_blocks(K);
@@ -3029,28 +3052,55 @@ void Evp::build_split(int K) {
     const int l = inner[e], lo = inner[e + 1], hi = inner[e + 2], rows = hi - lo + 1;
     long long nseg = (slots - (long long)nedge_seg * S) / std::max(1LL, (long long)S * nb);
     nseg = std::max(1LL, std::min(nseg, (long long)std::max(1, rows / (4 * K))));
-    const Block& b = dom.all[dom.local[l]];
+    const Block& b = dom.all[dom.local[l]];   // (jlo is what the table is relative to: the same with or without the probe)
     for (int g = 0; g < (int)nseg; ++g) {
       const int a0 = lo + (int)((long long)rows * g / nseg), a1 = lo + (int)((long long)rows * (g + 1) / nseg) - 1;
       for (int t = 0; t < S; ++t) tab.insert(tab.end(), {l, t, a0 - b.jlo, a1 - b.jlo});
     }
   }
-  split_edge = (int)(edge.size() / 4);
-  split_total = (int)(tab.size() / 4);
-  split_tab.alloc(tab.size());
-  split_tab.upload(tab.data(), stream);
+  std::unique_ptr<TileTab> t(new TileTab);
+  t->K = K; t->ext = ext; t->split = split; t->S = S; t->nb = nb;
+  t->edge = (int)(edge.size() / 4);
+  t->total = (int)(tab.size() / 4);
+  t->tab.alloc(tab.size());
+  t->tab.upload(tab.data(), stream);
   CICE_HIP(hipStreamSynchronize(stream));
-  if (!stream2) CICE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-  if (!ev_fork) CICE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-  if (!ev_join) CICE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-  std::memcpy(split_key, key, sizeof(key));
+  tile_tabs.push_back(std::move(t));
+  return *tile_tabs.back();
+}
+
+// every table a range of subcycles will use, and the second stream: allocations and uploads stay outside captures
+void Evp::build_split(int K) {
+  const int H = dom.overlap;
+  for (int ext = 0; ext <= H; ++ext) (void)tiles_for(K, ext, false);   // (a few KB each; any value can occur at the end of a step)
+  if (can_split()) {
+    (void)tiles_for(K, 0, true);
+    if (!stream2) CICE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    if (!ev_fork) CICE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    if (!ev_join) CICE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+  }
+}
+
+// a sweep that leaves `ext` extension rows right (one launch over a tile list)
+void Evp::launch_subcycle_skew_ext(int ksub, int K, int ext) {
+  ++loop_launches;
+  const TileTab& t = tiles_for(K, ext, false);
+  SkewArgs sa{};
+  skew_args(sa, K);
+  sa.tiles = t.tab.p;
+  sa.tile_first = 0;
+  sa.tile_count = t.total;
+  skew_launch(sa, K, ksub + K - 1 == sc.ndte, t.total, stream);
+  after_subcycle(ksub + K - 1);
 }
 
 void Evp::launch_subcycle_skew_split(int ksub, int K) {
   loop_launches += 2;
+  const TileTab& t = tiles_for(K, 0, true);
+  const int split_edge = t.edge, split_total = t.total;
   SkewArgs sa{};
   skew_args(sa, K);
-  sa.tiles = split_tab.p;
+  sa.tiles = t.tab.p;
   const bool last = ksub + K - 1 == sc.ndte;
   // the interior beside everything that follows on the main stream
   CICE_HIP(hipEventRecord(ev_fork, stream));
@@ -3867,7 +3917,7 @@ void Evp::launch_range(int ksub0, int nsub) {
   const bool fuse = can_fuse();
   const bool skew = can_skew(), skew_fold = !skew && can_skew_fold();
   const int K = skew_levels();
-  const bool split = skew && can_split();
+  const bool trim = skew && can_trim(), split = trim && can_split();
   const int end = ksub0 + nsub - 1;
   for (int k = ksub0; k <= end;) {
     // a wide-halo refresh falls after subcycles that are multiples of `overlap`: a launch must not straddle one,
@@ -3881,8 +3931,23 @@ void Evp::launch_range(int ksub0, int nsub) {
     };
     if (skew && clear(K)) {
       const int kend = k + K - 1;
-      if (split && (kend % dom.overlap == 0 || kend == sc.ndte)) launch_subcycle_skew_split(k, K);   // a refresh follows
-      else launch_subcycle_skew(k, K);
+      if (split_probe > 0 && !in_capture && dom.overlap == 0 && dom.nblocks() == 1 && !halo.multi_rank()) {
+        if (!stream2) {
+          (void)tiles_for(K, 0, true);
+          CICE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+          CICE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+          CICE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        }
+        launch_subcycle_skew_split(k, K);    // timing only: the extension rows are not computed and nobody refreshes them
+      } else if (trim) {
+        // subcycles left until the next refresh = extension rows that still have to be right after this sweep
+        const int next = std::min(((kend + dom.overlap - 1) / dom.overlap) * dom.overlap, sc.ndte);
+        const int ext = std::min(dom.overlap, next - kend);
+        if (ext == 0 && split) launch_subcycle_skew_split(k, K);   // a refresh follows: edge segments first
+        else launch_subcycle_skew_ext(k, K, ext);
+      } else {
+        launch_subcycle_skew(k, K);
+      }
       k += K;
     } else if (skew_fold && clear(K)) {
       launch_subcycle_skew_fold(k, K);
@@ -3918,7 +3983,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     const int K = skew_levels(), seg = skew_seg_rows(K);
     build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
-  if (can_skew() && can_split()) build_split(skew_levels());   // (uploads a table: outside any capture)
+  if (can_skew() && can_trim()) build_split(skew_levels());   // (uploads tables: outside any capture)
   bool replayed = false;
   loop_launches = 0;
   if (nsub >= 2 && (can_reside() || can_reside_peer())) {
