@@ -87,6 +87,7 @@ def parse():
                    help="N = 1 only (diagnostic): cut the grid into this many wide-halo slabs on the one GPU; with "
                         "CICE4_AMD_SELF_COMM=1 their ghost refresh goes through pack/RCCL/unpack")
     p.add_argument("--resident-waves", type=int, default=0, help="wavefronts per workgroup of k_evp_resident (0 = library's choice)")
+    p.add_argument("--resident-prio", type=int, default=-1, help="issue priority among the workgroups of a CU in k_evp_resident (0, 1, 2); -1 = library's choice")
     p.add_argument("--no-resident", action="store_true", help="do not run the whole subcycle loop in one launch (k_evp_resident)")
     p.add_argument("--no-fuse", action="store_true", help="one subcycle per launch (k_subcycle) even where two are possible")
     p.add_argument("--fused-waves", type=int, default=0, help="wavefronts per workgroup of k_subcycle2 (8/12/13/14/16); 0 = auto")
@@ -818,6 +819,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         dist.barrier()
     if tune and args.resident_waves:
         ctx.evp_set_option("resident_waves", args.resident_waves)
+    if tune and getattr(args, "resident_prio", -1) >= 0:
+        ctx.evp_set_option("resident_prio", args.resident_prio)
     resident = bool(ctx.evp_get_info("resident"))
     rw = ctx.evp_get_info("resident_waves") if resident else 0
     if resident:
@@ -878,6 +881,31 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     for _ in range(warmup):
         ctx.evp_subcycles(1, ndte)
     sync_all()
+    # N > 1, sweeps between refreshes: the sweep in front of a refresh can run as edge + interior launches with the refresh
+    # beside the interior (Evp::launch_subcycle_skew_split).  Whether that pays depends on what the exchange costs on THIS
+    # machine -- timed here, both forms, a few steps each, the maximum over the ranks decides for all of them.
+    refresh_overlap = None
+    if world > 1 and skew_k and dom.get("overlap") and ctx.evp_get_info("skew_trim_ext"):
+        tms = {}
+        for split in (0, 1):
+            ctx.evp_set_option("skew_split", split)
+            if split and not ctx.evp_get_info("skew_split"):
+                continue
+            ctx.evp_subcycles(1, ndte)
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                ctx.evp_subcycles(1, ndte)
+            sync_all()
+            tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tms[split] = float(tt[0]) / 3
+        use = 1 if 1 in tms and tms[1] < tms[0] else 0
+        ctx.evp_set_option("skew_split", use)
+        refresh_overlap = {"what": "the sweep in front of a refresh as edge + interior launches, the refresh beside the interior",
+                           "ms_per_step_one_launch": 1e3 * tms[0], "ms_per_step_split": 1e3 * tms[1] if 1 in tms else None,
+                           "used": bool(use)}
+        progress(f"{wl}: refresh overlap {'ON' if use else 'off'} ({refresh_overlap})")
     progress(f"{wl}: ramp ({n_ramp[0]} steps) and warm-up done, timing {steps} steps")
     # EXACTLY `steps` steps between barrier + synchronise on both sides, maximum over the ranks -- and that block
     # repeated until about `min_timed_s` of device time have been timed (a 13 ms block alone is not a measurement):
@@ -1018,6 +1046,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                                        "the fold is part of the one-launch loop" if resident else
                                        "sweeps with a band of top rows that carries the fold" if ctx.evp_get_info("skew_fold") else
                                        "halo update with the fold after every subcycle"))
+    if refresh_overlap:
+        config["refresh_overlap"] = refresh_overlap
     if peer_verified:
         config["peer_loop_verified"] = ("one evp(dt) through the per-subcycle message exchange and one through the cross-rank "
                                         "one-launch loop from the same state: u, v and the 12 stresses bit-identical on every "

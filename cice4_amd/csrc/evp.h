@@ -113,6 +113,8 @@ class Evp {
   bool resident_on = true, resident_failed = false;
   int res_w_opt = 0;             // forced wavefronts per workgroup (tests), 0 = auto
   bool res_dense = true;         // allow three 4-wavefront workgroups per CU
+  int res_prio = 2;              // issue priority among them: 0 none, 1 by dispatch generation, 2 rotating per subcycle
+                                 // (gx1: 183.8 k subcycles/s against 177.4 k with 0 or 1, profiles/r04_resident_prio.txt)
   int res_spin_us = 200000;      // bound of every wait inside the resident kernel
   int res_level = 0;             // 0: dense allowed, 1: one workgroup per CU only (after a dense time-out)
   hipEvent_t res_done_ev = nullptr;   // end of the cross-rank loop, polled (run_resident)
@@ -184,7 +186,7 @@ class Evp {
   void skew_args(SkewArgs& sa, int K);
   void skew_launch(const SkewArgs& sa, int K, bool last, int nt, hipStream_t s);
   // the sweep in front of a wide-halo refresh as two launches: edge segments + refresh on the main stream, interior beside them
-  bool split_on = true, in_capture = false;
+  bool split_on = false, in_capture = false;   // (off by default: on one GPU the two-launch form costs more than it hides)
   void build_split(int K);
   void launch_subcycle_skew_split(int ksub, int K);
   void launch_subcycle_skew_ext(int ksub, int K, int ext);

@@ -892,6 +892,20 @@ __device__ __forceinline__ void stamp_at(long long* stamps, int slot) {
 
 }  // namespace
 
+// Phase clock of the one-launch loop (diagnostic build only): cycles a workgroup's wavefront 0 spends between marked points
+// of a subcycle, summed over the subcycles of a launch (scripts/resident_phases.py).  Nothing in the product build.
+#ifdef CICE4_AMD_STAMPS
+#define PHASE_DECL long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long ph_t_ = (long long)__builtin_amdgcn_s_memtime();
+#define PHASE(i) { const long long tn_ = (long long)__builtin_amdgcn_s_memtime(); ph_[i] += tn_ - ph_t_; ph_t_ = tn_; }
+#define PHASE_DRAIN asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#define PHASE_STORE(buf) if ((buf) && threadIdx.x == 0) { for (int i_ = 0; i_ < 8; ++i_) (buf)[8 * (size_t)blockIdx.x + i_] = ph_[i_]; }
+#else
+#define PHASE_DECL
+#define PHASE(i)
+#define PHASE_DRAIN
+#define PHASE_STORE(buf)
+#endif
+
 struct SkewArgs {
   SubArgs a;               // only what the kernel names is fetched from the argument block
   const double* st_in;     // u, v, 12 stresses of the current state: 14 planes of a.n doubles
@@ -1405,6 +1419,9 @@ struct ResArgs {
   unsigned* prog2;       // [tiles * RES_STRIDE] raw top row of subcycle k published = epoch0 + k + 1
   const int32_t* deps2;  // [tiles][4] tiles that hold the partners of this tile's top-row cells, -1 padded
   long long* stamps;     // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups] see stamp_begin / stamp_end
+  long long* phases;     // ... [8 * workgroups] cycles per phase of the subcycle, summed over the launch (PHASE)
+  int prio_mode;         // issue priority of the workgroups that share a CU (dense shape): 0 none, 1 by generation, 2 rotating
+  int prio_div;          // workgroups of one generation per XCD (= CUs per XCD)
 };
 enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
 
@@ -1573,9 +1590,30 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
       __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   stamp_at(r.stamps, 0);
+  PHASE_DECL
+  // The workgroups a CU holds (dense shape: three) are copies of one program that depend on their neighbours once per
+  // subcycle: left alone they end up IN PHASE -- all three compute together, each at a third of the SIMD, then all
+  // three wait for their hand-off together (profiles/r04_resident_phases.txt: 1.4 us of stress for 0.5 us of issue, then
+  // 2.4 us in the poll).  Workgroups are dispatched in blockIdx order, one per CU of an XCD before any CU gets its second:
+  // the "generation" of a workgroup (0: first on its CU) is also a band of neighbouring tile rows.  Priority by
+  // generation lets one band compute at full speed while the other two are in their hand-off.
+  const int gen = r.prio_div > 0 ? min(2, (int)(blockIdx.x >> 3) / r.prio_div) : 0;
+  if (r.prio_mode == 1) {
+    if (gen == 0) __builtin_amdgcn_s_setprio(3);
+    else if (gen == 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
+  }
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
+    if (r.prio_mode == 2) {
+      const int p = (k + gen) % 3;
+      if (p == 0) __builtin_amdgcn_s_setprio(3);
+      else if (p == 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
+    PHASE_DRAIN      // (diagnostic build: the exchanged velocities have arrived before the clock of the stress starts)
+    PHASE(7)         // 7: load of the exchanged velocities
     // (A) velocities of the row below and of the western neighbour
     if (!south_h && w > 0) {
       us = s_uv[w - 1][0][lx];
@@ -1606,7 +1644,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
       s_edge[w][2][lx] = o.str[5];
       s_edge[w][3][lx] = e7;
     }
+    PHASE(0)         // 0: stress
     __syncthreads();
+    PHASE(1)         // 1: barrier (C)
     if (uact) {
       const double sx = o.str[0] + e1 + s_edge[w + 1][0][lx] + s_edge[w + 1][1][lx];   // :1415-1416 order
       const double sy = o.str[4] + s_edge[w + 1][2][lx] + e6 + s_edge[w + 1][3][lx];   // :1417-1418 order
@@ -1682,6 +1722,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
     if (!PEER && k + 1 == r.nsub) break;
     s_uv[w][0][lx] = un;     // read after (E); the reads of the previous values lie before (C)
     s_uv[w][1][lx] = vn;
+    PHASE(2)         // 2: momentum
     // (D) publish the edge velocities of subcycle k, then the progress word
     double* xu = r.xu[k & 1];
     double* xv = xu + a.n;
@@ -1757,8 +1798,11 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
         }
       }
     }
+    PHASE(3)         // 3: edge stores issued
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    PHASE(4)         // 4: stores drained
     __syncthreads();
+    PHASE(5)         // 5: barrier (D)
     const unsigned target = r.epoch0 + (unsigned)k + (PEER ? 2u : 1u);
     if (threadIdx.x == 0)
       __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1798,6 +1842,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
       if (lx == 0) s_abort = bad;
     }
     __syncthreads();
+    PHASE(6)         // 6: progress word, poll of the producers' words, barrier (E)
     if (s_abort) return;
     // every exchanged velocity is an agent-scope load (system scope where another rank may have written it)
     if (foreign) {
@@ -1817,6 +1862,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
   }
 
   stamp_at(r.stamps, 1);
+  PHASE_STORE(r.phases)
   // ---- results (owners only), into the other copy of the state ----
   if (sown) {
 #pragma unroll
@@ -2282,6 +2328,9 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "resident_spin_us")) {   // how long a tile waits for its neighbours before giving up
     CICE_REQUIRE(value >= 0, "resident_spin_us must be >= 0");
     res_spin_us = value;
+  } else if (!std::strcmp(key, "resident_prio")) {    // issue priority among the workgroups of a CU (dense shape): 0, 1, 2
+    CICE_REQUIRE(value >= 0 && value <= 2, "resident_prio must be 0, 1 or 2");
+    res_prio = value;
   } else if (!std::strcmp(key, "resident_dense")) {   // three 4-wavefront workgroups per CU where that fills the chip
     res_dense = value != 0;
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
@@ -2990,9 +3039,14 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
 // against ~30), so the edge launch ends at about half the interior's time and the exchange has the other half.
 // Same arithmetic on every owned row as the one-launch sweep: a segment's rows depend on the rows of the state the sweep
 // starts from, not on which launch computes its neighbours.
+// Cost, measured on one GPU at the 8-rank geometry of the 0.1-degree grid (profiles/r04_split_probe.txt): the sweep in
+// front of the refresh takes 48.4 us per subcycle in this form against 39.7 as one launch over the same 300 rows (short
+// edge segments, a fork and a join between two streams) = +35 us per refresh; it pays where the exchange it hides costs
+// more than that.  Nothing has run between two devices, so it is OFF by default and bench.py --gpus N decides by timing.
 bool Evp::can_split() const {
-  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SPLIT"); return e && e[0] == '0'; }();
-  if (!split_on || env_off || in_capture) return false;
+  // off unless asked for: option "skew_split" or CICE4_AMD_SKEW_SPLIT=1 (bench.py --gpus N times both forms and keeps the faster)
+  static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SPLIT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  if (env == 0 || (!split_on && env != 1) || in_capture) return false;
   return can_trim();
 }
 
@@ -3841,7 +3895,17 @@ bool Evp::run_resident(int ksub0, int nsub) {
       return false;
     }
   }
-  r.stamps = stamp_buffer(g.x);
+  r.prio_mode = dense ? res_prio : 0;
+  {
+    int ncu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) {
+      int v = 0;
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+    }
+    r.prio_div = std::max(1, ncu / 8);
+  }
+  r.stamps = stamp_buffer(3 * (size_t)g.x);             // [4 g] stamps, then [8 g] phase sums
+  r.phases = r.stamps ? r.stamps + 4 * (size_t)g.x : nullptr;
   switch (W) {
     case 4: launch_res<4>(r, damp, peer, g, stream); break;
     case 6: launch_res<6>(r, damp, peer, g, stream); break;

@@ -16,3 +16,4 @@ for rep in 1 2 3; do
   done
 done
 bash scripts/gpu_r4_split.sh
+timeout -k 10 300 python scripts/resident_phases.py build/ab/lib_stamps.so gpurun_out/r04_resident_phases.csv 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r4_phases.txt

@@ -591,9 +591,10 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                     assert c.evp_get_info("skew") == 1
                     # the sweep in front of every refresh runs as two launches: the edge segments, followed by the
                     # refresh, on the main stream; the interior beside them on a second one (round 4)
-                    if mode.endswith("nosplit"):
-                        c.evp_set_option("skew_split", 0)
+                    # (off by default -- on one GPU it costs more than it hides; bench.py --gpus N decides by timing)
+                    c.evp_set_option("skew_split", 0 if mode.endswith("nosplit") else 1)
                     assert c.evp_get_info("skew_split") == (0 if mode.endswith("nosplit") else 1)
+                    assert c.evp_get_info("skew_trim_ext") == 1    # extension rows trimmed to what the next sweeps need
                 else:
                     c.evp_set_option("skew", 0)
             c.evp(DT, s)
