@@ -888,10 +888,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     if world > 1 and skew_k and dom.get("overlap") and ctx.evp_get_info("skew_trim_ext"):
         tms = {}
         for split in (0, 1):
-            ctx.evp_set_option("skew_split", split)
-            if split and not ctx.evp_get_info("skew_split"):
-                continue
-            ctx.evp_subcycles(1, ndte)
+            ctx.evp_set_option("skew_split", split)     # (a rank that cannot split -- the fold's rank, a short slab -- runs the
+            ctx.evp_subcycles(1, ndte)                  #  one-launch form both times: every rank takes part in both timings)
             sync_all()
             t1 = time.perf_counter()
             for _ in range(3):
@@ -900,11 +898,10 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
             tt = torch.tensor([time.perf_counter() - t1], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tms[split] = float(tt[0]) / 3
-        use = 1 if 1 in tms and tms[1] < tms[0] else 0
+        use = 1 if tms[1] < tms[0] else 0
         ctx.evp_set_option("skew_split", use)
         refresh_overlap = {"what": "the sweep in front of a refresh as edge + interior launches, the refresh beside the interior",
-                           "ms_per_step_one_launch": 1e3 * tms[0], "ms_per_step_split": 1e3 * tms[1] if 1 in tms else None,
-                           "used": bool(use)}
+                           "ms_per_step_one_launch": 1e3 * tms[0], "ms_per_step_split": 1e3 * tms[1], "used": bool(use)}
         progress(f"{wl}: refresh overlap {'ON' if use else 'off'} ({refresh_overlap})")
     progress(f"{wl}: ramp ({n_ramp[0]} steps) and warm-up done, timing {steps} steps")
     # EXACTLY `steps` steps between barrier + synchronise on both sides, maximum over the ranks -- and that block
