@@ -159,6 +159,10 @@ class Evp {
       fcor, HTN, HTE;
   DevBuf<int32_t> tmask, umask, blk;  // blk: ilo,ihi,jlo,jhi per block
   DevBuf<double> uarena;   // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear live here (views below)
+  DevBuf<double> uar4, hnhe;   // the sweep kernel's interleaved copies: 4 planes of pairs of the above; {HTN, HTE} pairs
+  DevBuf<int32_t> skew_msk;    // bit 0: icetmask == 1, bit 1: iceumask != 0
+  bool skew_packed = false;    // ... built for the current prepare()
+  void skew_pack();
   // in
   DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,
       ss_tlty;

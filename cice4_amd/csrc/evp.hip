@@ -292,6 +292,9 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #ifndef SKEW_TPASS       // HTN, HTE, strength and the two masks of a row travel from level to level through LDS (K <= 4)
 #define SKEW_TPASS 0
 #endif
+#ifndef SKEW_WIDE        // the read-only inputs of a step come interleaved: 16-byte loads, 7 instead of 14 per level and step
+#define SKEW_WIDE 1
+#endif
 #ifndef SKEW_EARLY       // a third slot for the hand-off of level 0: its stresses of the NEXT row are fetched before the barrier
 #define SKEW_EARLY 0
 #endif
@@ -584,6 +587,10 @@ __device__ __forceinline__ double ld8(const double* p, unsigned off) {
 __device__ __forceinline__ void st8(double* p, unsigned off, double v) { *(double*)((char*)p + off) = v; }
 __device__ __forceinline__ int ld4(const int32_t* p, unsigned off) {
   return *(const int32_t*)((const char*)p + off);
+}
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dbl2 ld16(const double* p, unsigned off) {   // p + off is 16-byte aligned
+  return *(const dbl2*)((const char*)p + off);
 }
 
 template <bool DERIVE>
@@ -919,6 +926,13 @@ struct SkewArgs {
   int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
   long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
   long long* stamps;       // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups], see stamp_at
+  // SKEW_WIDE: the read-only inputs interleaved cell by cell (Evp::prepare / init build them): uar4 = 4 planes of pairs
+  // {aiu, uocn} {vocn, forcex} {forcey, umassdtei} {fm, uarear}; hnhe = one plane of pairs {HTN, HTE}; msk = one int per cell:
+  // bit 0 icetmask == 1, bit 1 iceumask != 0.  A level's 14 loads per step become 4 + 1 of 16 bytes, strength, and one int.
+  const double* uar4;
+  const double* hnhe;
+  const int32_t* msk;
+  long long* phases;       // diagnostic build: [8 * K * workgroups] cycles per phase of a step, per level, summed over the sweep
   int own_shift;           // strip 0 owns this many lanes less (see the kernel's column geometry)
   // a launch over an explicit LIST of tiles (Evp::build_split: the sweep in front of a wide-halo refresh runs as two
   // launches, the segments the neighbours wait for first): [4 per tile] block, strip, first and last owned row relative
@@ -994,6 +1008,11 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const double* const stren = a.strength + base;
   const int32_t* const tmk = a.icetmask + base;
   const int32_t* const umk = a.iceumask + base;
+  constexpr bool WIDE = SKEW_WIDE != 0;
+  const double* const uar4 = sa.uar4 + 2 * base;           // pairs: 16 bytes per cell and plane
+  const double* const hnhe = sa.hnhe + 2 * base;
+  const int32_t* const msk = sa.msk + base;
+  const unsigned n16 = (unsigned)(a.n * 16);               // bytes between two planes of pairs
   const bool cyc = a.ew_cyclic != 0;
   // column: ring position (0 = ilo, ncol = G) -> memory column, as in k_subcycle2
   const int ncol = ihi - ilo + 1;
@@ -1074,6 +1093,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   // generation of this workgroup: workgroups are dispatched in blockIdx order, one per CU first
   const int gen = (int)(blockIdx.x / (gridDim.x / (unsigned)sa.stagger_mod + 1u));
   stamp_at(sa.stamps, 0);
+  PHASE_DECL
 #pragma clang loop unroll(disable)
   for (int t = -1; t < nsteps; ++t) {
     // The SIMD issues from its OLDEST ready wavefront first: of the workgroups sharing a CU the first one dispatched
@@ -1128,15 +1148,28 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     double xa, xuo, xvo, xfx, xfy, xum, xfm, xur;
     if (urow && ucol) {
       const unsigned qu = q - nx8;
-      const char* pu = (const char*)uar;
-      xa = ld8((const double*)pu, qu); pu += pstride;
-      xuo = ld8((const double*)pu, qu); pu += pstride;
-      xvo = ld8((const double*)pu, qu); pu += pstride;
-      xfx = ld8((const double*)pu, qu); pu += pstride;
-      xfy = ld8((const double*)pu, qu); pu += pstride;
-      xum = ld8((const double*)pu, qu); pu += pstride;
-      xfm = ld8((const double*)pu, qu); pu += pstride;
-      xur = ld8((const double*)pu, qu);
+      if (WIDE) {
+        size_t pstride2 = n16;
+#if SKEW_OPAQUE_STRIDE
+        asm volatile("" : "+s"(pstride2));
+#endif
+        const char* pu = (const char*)uar4;
+        const dbl2 w0 = ld16((const double*)pu, 2u * qu); pu += pstride2;
+        const dbl2 w1 = ld16((const double*)pu, 2u * qu); pu += pstride2;
+        const dbl2 w2 = ld16((const double*)pu, 2u * qu); pu += pstride2;
+        const dbl2 w3 = ld16((const double*)pu, 2u * qu);
+        xa = w0.x; xuo = w0.y; xvo = w1.x; xfx = w1.y; xfy = w2.x; xum = w2.y; xfm = w3.x; xur = w3.y;
+      } else {
+        const char* pu = (const char*)uar;
+        xa = ld8((const double*)pu, qu); pu += pstride;
+        xuo = ld8((const double*)pu, qu); pu += pstride;
+        xvo = ld8((const double*)pu, qu); pu += pstride;
+        xfx = ld8((const double*)pu, qu); pu += pstride;
+        xfy = ld8((const double*)pu, qu); pu += pstride;
+        xum = ld8((const double*)pu, qu); pu += pstride;
+        xfm = ld8((const double*)pu, qu); pu += pstride;
+        xur = ld8((const double*)pu, qu);
+      }
     }
     // ... what the next step starts with (straight-line code: a row index clamped into the sweep instead of a branch,
     // so that the number of loads in flight is the same on every path) ...
@@ -1155,6 +1188,15 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         ntm = m & 1;
         num = m & 2;
         if (has_ilo) nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));
+      } else if (WIDE) {
+        const dbl2 hh = ld16(hnhe, 2u * qn);
+        nhn = hh.x;
+        nhe = hh.y;
+        if (has_ilo) nhew = ld8(hte, qn - (col >= 2 ? 8u : 0u));   // only the lane at ilo uses it
+        nst = ld8(stren, qn);
+        const int m = ld4(msk, qn >> 1);
+        ntm = m & 1;
+        num = m & 2;
       } else {
         nhn = ld8(htn, qn);
         nhe = ld8(hte, qn);
@@ -1191,6 +1233,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    PHASE(0)         // 0: hand-off written, this step's loads issued
 #if SKEW_LOADPRIO
     if (sa.prio_rotate) {
       const int p = (t + 1 + gen) % sa.stagger_mod;
@@ -1276,6 +1319,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
           }
         }
       }
+      PHASE(1)       // 1: stress (with the wait for its stresses and inputs)
       // ---- momentum of U-row r-1 (:1390-1435): str of (i,j) carried, of (i+1, .) by wave shift
       const double e1 = down1z(o.str[1]), e3 = down1z(o.str[3]), e6 = down1z(o.str[6]), e7 = down1z(o.str[7]);
       double u1 = us, v1 = vs;   // velocity of row r-1 after this level
@@ -1358,9 +1402,15 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         }
       }
     }
+    PHASE(2)         // 2: momentum, stores, hand-off of u, v
     __syncthreads();
+    PHASE(3)         // 3: barrier
   }
   stamp_at(sa.stamps, 1);
+#ifdef CICE4_AMD_STAMPS
+  if (sa.phases && lx == 0)
+    for (int i_ = 0; i_ < 8; ++i_) sa.phases[8 * ((size_t)blockIdx.x * K + k) + i_] = ph_[i_];
+#endif
   if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x + 1] = wall_clock64();
 }
 
@@ -2241,6 +2291,28 @@ __global__ __launch_bounds__(256) void k_finish(const PrepArgs a) {
   a.strocnyT[t] = yT;
 }
 
+// The read-only inputs of the sweep kernel, interleaved cell by cell (SkewArgs::uar4 / hnhe / msk): once per evp(dt)
+// (the momentum inputs and the masks) and once per grid (HTN | HTE).  16 bytes per lane and load instead of 8.
+__global__ __launch_bounds__(256) void k_skew_pack(size_t n, const double* __restrict__ uar, const int32_t* __restrict__ tmk,
+                                                   const int32_t* __restrict__ umk, double* __restrict__ uar4,
+                                                   int32_t* __restrict__ msk) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    uar4[2 * ((size_t)p * n + q)] = uar[(size_t)(2 * p) * n + q];
+    uar4[2 * ((size_t)p * n + q) + 1] = uar[(size_t)(2 * p + 1) * n + q];
+  }
+  msk[q] = (tmk[q] == 1 ? 1 : 0) | (umk[q] != 0 ? 2 : 0);
+}
+__global__ __launch_bounds__(256) void k_skew_pack_grid(size_t n, const double* __restrict__ HTN, const double* __restrict__ HTE,
+                                                        double* __restrict__ hnhe) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  hnhe[2 * q] = HTN[q];
+  hnhe[2 * q + 1] = HTE[q];
+}
+
 __global__ __launch_bounds__(1024) void k_count_active(const PrepArgs a) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   int b, i, j;
@@ -2606,9 +2678,24 @@ void Evp::prepare(double dt) {
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
   CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
+  skew_packed = false;
+  if (can_skew() || can_skew_fold()) skew_pack();   // the sweep kernel's interleaved inputs of this step
   CICE_HIP(hipGetLastError());
   prepared = true;
   counted = false;   // the diagnostic counts are formed when somebody asks (active_cells)
+}
+
+// the sweep kernel's interleaved read-only inputs (SkewArgs::uar4 / hnhe / msk) from this step's work arrays
+void Evp::skew_pack() {
+  if (uar4.n < 8 * n) {
+    uar4.alloc(8 * n);
+    skew_msk.alloc(n);
+    hnhe.alloc(2 * n);
+    hipLaunchKernelGGL(k_skew_pack_grid, grid1(n), dim3(256), 0, stream, n, (const double*)HTN.p, (const double*)HTE.p, hnhe.p);
+  }
+  hipLaunchKernelGGL(k_skew_pack, grid1(n), dim3(256), 0, stream, n, (const double*)uarena.p, (const int32_t*)icetmask.p,
+                     (const int32_t*)iceumask.p, uar4.p, skew_msk.p);
+  skew_packed = true;
 }
 
 // test aid: start / end wall-clock ticks (10 ns) of the workgroups of the last k_subcycle_skew launch
@@ -2982,11 +3069,15 @@ void Evp::skew_args(SkewArgs& sa, int K) {
   sa.fwd_rule = fwd_is_ew_wrap ? 1 : 0;
   sa.dbg = nullptr;
   sa.stamps = nullptr;
+  sa.phases = nullptr;
   sa.stagger_ticks = skew_stagger_ns / 10;
   sa.stagger_mod = std::max(1, skew_blocks(K));
   sa.st_in = st[cur].p;
   sa.st_out = st[1 - cur].p;
   sa.uar = uarena.p;
+  sa.uar4 = uar4.p;
+  sa.hnhe = hnhe.p;
+  sa.msk = skew_msk.p;
   sa.tiles = nullptr;
   sa.tile_first = sa.tile_count = 0;
 }
@@ -3022,7 +3113,11 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
     if (skew_dbg.n < want) skew_dbg.alloc(want);
     sa.dbg = skew_dbg.p;
   }
-  sa.stamps = stamp_buffer(8 * ((nt + 7) / 8));
+  {
+    const size_t g = 8 * ((size_t)(nt + 7) / 8);
+    sa.stamps = stamp_buffer((1 + 2 * (size_t)K) * g);      // [4 g] stamps, then [8 K g] phase sums per level
+    sa.phases = sa.stamps ? sa.stamps + 4 * g : nullptr;
+  }
   skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, stream);
   if (flip_and_halo) after_subcycle(ksub + K - 1);
 }
@@ -4047,6 +4142,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     const int K = skew_levels(), seg = skew_seg_rows(K);
     build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
+  if ((can_skew() || can_skew_fold()) && !skew_packed) skew_pack();   // (sweeps switched on after prepare(): allocations outside any capture)
   if (can_skew() && can_trim()) build_split(skew_levels());   // (uploads tables: outside any capture)
   bool replayed = false;
   loop_launches = 0;
