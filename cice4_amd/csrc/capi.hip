@@ -863,6 +863,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "skew")) *value = c_->evp->can_skew() || c_->evp->can_skew_fold() ? 1 : 0;
   else if (!std::strcmp(key, "skew_fold")) *value = !c_->evp->can_skew() && c_->evp->can_skew_fold() ? 1 : 0;
   else if (!std::strcmp(key, "skew_levels")) *value = c_->evp->skew_levels();
+  else if (!std::strcmp(key, "skew_pairs")) *value = c_->evp->pairs_ok() ? 1 : 0;
   else if (!std::strcmp(key, "skew_trim_ext")) *value = (c_->evp->can_skew() && c_->evp->can_trim()) ? 1 : 0;
   else if (!std::strcmp(key, "skew_split")) *value = (c_->evp->can_skew() && c_->evp->can_split()) ? 1 : 0;
   else if (!std::strcmp(key, "skew_strips")) *value = c_->evp->skew_strips(c_->evp->skew_levels(), nullptr);

@@ -57,6 +57,7 @@ class Evp {
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
   bool can_split() const;    // ... and the sweep in front of a wide-halo refresh as edge + interior launches
   bool can_trim() const;     // sweeps on wide-halo slabs over tile lists (extension rows trimmed)
+  bool pairs_ok() const;     // the sweep's pair layout of the state applies to this domain
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
@@ -163,6 +164,11 @@ class Evp {
   DevBuf<int32_t> skew_msk;    // bit 0: icetmask == 1, bit 1: iceumask != 0
   bool skew_packed = false;    // ... built for the current prepare()
   void skew_pack();
+  // the sweep's pair layout of the state (k_subcycle_skew<.., PAIRS>)
+  DevBuf<double> st2[2];
+  bool pairs_on = true, in_pairs = false, copies_identical = false;
+  void to_pairs();
+  void to_planes();
   // in
   DevBuf<double> aice, vice, vsno, aice0, aicen, vicen, strairxT, strairyT, uocn, vocn, ss_tltx,
       ss_tlty;

@@ -592,6 +592,12 @@ typedef double dbl2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ dbl2 ld16(const double* p, unsigned off) {   // p + off is 16-byte aligned
   return *(const dbl2*)((const char*)p + off);
 }
+__device__ __forceinline__ void st16(double* p, unsigned off, double x, double y) {
+  dbl2 v;
+  v.x = x;
+  v.y = y;
+  *(dbl2*)((char*)p + off) = v;
+}
 
 template <bool DERIVE>
 __device__ __forceinline__ void load_uin_o(const SubArgs& a, size_t base, unsigned qo, UIn& x) {
@@ -948,9 +954,15 @@ namespace {
 // Addressing: every array of the launch is (one uniform base) + (one 32-bit byte offset per lane); the 14 planes of
 // the state and the 8 planes of the momentum inputs are reached by adding plane * n * 8 to the lane offset
 // (Evp::can_skew checks that 14 planes stay below 4 GB), so the kernel holds a handful of base pointers, not forty.
-template <int K, bool LAST, bool DAMP, int WS>
+// PAIRS: u | v and the stresses two by two live interleaved cell by cell in the sweep's own copies of the state
+// (Evp::st2: 7 planes of pairs {u, v} {s1, s2} ... {s11, s12}): level 0 fetches a row with 7 loads of 16 bytes instead of
+// 14 of 8, the last level stores it with 7.  The levels at the two ends of the pipeline are the ones every step waits
+// for (profiles/r04_sweep_phases*.txt), and what makes them slow is the NUMBER of vector-memory instructions they issue.
+// The sweep that ends evp(dt) (LAST) stores in the ordinary plane layout, so that nothing has to be converted back.
+template <int K, bool LAST, bool DAMP, int WS, bool PAIRS = false>
 __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa) {
   const SubArgs& a = sa.a;
+  constexpr bool PIN = PAIRS, POUT = PAIRS && !LAST;
   // Columns: a level loses one lane per side (the stress needs the western neighbour's velocity, the momentum equation
   // the eastern neighbour's stress), so after K levels lanes K .. 63-K are right: a strip owns OWNW = 64 - 2K columns.
   // Strip 0 starts at the ring's seam: its first owned lane is ilo, whose western neighbour ihi sits TWO lanes away (G in
@@ -1000,8 +1012,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const int nx = a.nx;
   const unsigned n8 = (unsigned)(a.n * 8);                  // bytes between two planes
   const size_t base = (size_t)b * nx * a.ny;
-  const double* const u_in = sa.st_in + base;               // block planes: u, v at +n, stress c at +(2+c) n
-  double* const s_out = sa.st_out + base;
+  const double* const u_in = sa.st_in + (PIN ? 2 : 1) * base;    // block planes: u, v at +n, stress c at +(2+c) n; PAIRS: see above
+  double* const s_out = sa.st_out + (POUT ? 2 : 1) * base;
   const double* const uar = sa.uar + base;
   const double* const htn = a.HTN + base;
   const double* const hte = a.HTE + base;
@@ -1013,6 +1025,25 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const double* const hnhe = sa.hnhe + 2 * base;
   const int32_t* const msk = sa.msk + base;
   const unsigned n16 = (unsigned)(a.n * 16);               // bytes between two planes of pairs
+  // u, v of the cell at (8-byte layout) byte offset q8 of the state a sweep reads / writes
+  auto ld_uv = [&](unsigned q8, double& u, double& v) {
+    if (PIN) {
+      const dbl2 t = ld16(u_in, 2u * q8);
+      u = t.x;
+      v = t.y;
+    } else {
+      u = ld8(u_in, q8);
+      v = ld8(u_in, q8 + n8);
+    }
+  };
+  auto st_uv = [&](unsigned q8, double u, double v) {
+    if (POUT) {
+      st16(s_out, 2u * q8, u, v);
+    } else {
+      st8(s_out, q8, u);
+      st8(s_out, q8 + n8, v);
+    }
+  };
   const bool cyc = a.ew_cyclic != 0;
   // column: ring position (0 = ilo, ncol = G) -> memory column, as in k_subcycle2
   const int ncol = ihi - ilo + 1;
@@ -1063,13 +1094,9 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   double us = c0, vs = c0, usw = c0, vsw = c0, hn_s = c0;
   if (col_ok) {
     const unsigned q = (unsigned)(jt0 - 2) * nx8 + co;
-    us = ld8(u_in, q);
-    vs = ld8(u_in, q + n8);
+    ld_uv(q, us, vs);
     hn_s = ld8(htn, q);
-    if (col >= 2) {
-      usw = ld8(u_in, q - 8u);
-      vsw = ld8(u_in, q + n8 - 8u);
-    }
+    if (col >= 2) ld_uv(q - 8u, usw, vsw);
   }
   double p0 = c0, pe1 = c0, p4 = c0, pe6 = c0;   // str of the previous T-row: (i,j,1) (i+1,j,2) (i,j,5) (i+1,j,7)
   // what the NEXT step works on, fetched one step ahead (the stresses are not: they are wanted halfway through
@@ -1177,8 +1204,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       const int rn = min(max(r + 1, jt0), jt1);
       const unsigned qn = (unsigned)(rn - 1) * nx8 + co;
       if (k == 0) {
-        nun = ld8(u_in, qn);
-        nvn = ld8((const double*)((const char*)u_in + pstride), qn);
+        if (PIN) {
+          ld_uv(qn, nun, nvn);
+        } else {
+          nun = ld8(u_in, qn);
+          nvn = ld8((const double*)((const char*)u_in + pstride), qn);
+        }
       }
       if (TP && k > 0) {
         nhn = s_tin[k - 1][rn & 1][0][lx];
@@ -1215,7 +1246,20 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       } else {
 #else
       if (k == 0) {
-        if (!EARLY) {
+        if (PIN) {
+          size_t ps2 = n16;
+#if SKEW_OPAQUE_STRIDE
+          asm volatile("" : "+s"(ps2));
+#endif
+          const char* ps = (const char*)u_in + ps2;
+#pragma unroll
+          for (int c = 0; c < 6; ++c) {
+            const dbl2 t = ld16((const double*)ps, 2u * q);
+            s[2 * c] = t.x;
+            s[2 * c + 1] = t.y;
+            ps += ps2;
+          }
+        } else if (!EARLY) {
           const char* ps = (const char*)u_in + 2 * pstride;
 #pragma unroll
           for (int c = 0; c < 12; ++c) {
@@ -1249,10 +1293,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       // the rows of the level below (a ghost row never changes: it is read where it lives)
       if (k > 0) {
         if (r > jhi) {
-          if (col_ok) {
-            un = ld8(u_in, q);
-            vn = ld8(u_in, q + n8);
-          }
+          if (col_ok) ld_uv(q, un, vn);
         } else {
           un = s_uv[k - 1][r & 1][0][lx];
           vn = s_uv[k - 1][r & 1][1][lx];
@@ -1274,8 +1315,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
               vw = vw2;
             }
           } else if (at_ilo) {
-            uw = ld8(u_in, q - 8u);
-            vw = ld8(u_in, q + n8 - 8u);
+            ld_uv(q - 8u, uw, vw);
           }
         }
       }
@@ -1303,12 +1343,25 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
                                 diag ? ld8(a.tarear + base, q) : c0, Tiny, St, s, o, diag);
         const bool own_t = own_col && ((r >= ja && r <= jb) || (r == jhi + 1 && jb == jhi));
         if (lastlev && own_t) {
-          char* po = (char*)s_out + 2 * pstride;
+          if (POUT) {
+            size_t ps2 = n16;
+#if SKEW_OPAQUE_STRIDE
+            asm volatile("" : "+s"(ps2));
+#endif
+            char* po = (char*)s_out + ps2;
 #pragma unroll
-          for (int c = 0; c < 12; ++c) {
-            if (SKEW_NT) st8nt((double*)po, q, s[c]);
-            else st8((double*)po, q, s[c]);
-            po += pstride;
+            for (int c = 0; c < 6; ++c) {
+              st16((double*)po, 2u * q, s[2 * c], s[2 * c + 1]);
+              po += ps2;
+            }
+          } else {
+            char* po = (char*)s_out + 2 * pstride;
+#pragma unroll
+            for (int c = 0; c < 12; ++c) {
+              if (SKEW_NT) st8nt((double*)po, q, s[c]);
+              else st8((double*)po, q, s[c]);
+              po += pstride;
+            }
           }
           if (LAST) {
             st8(a.divu + base, q, o.divu);
@@ -1341,8 +1394,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
               stepu_cell(us, vs, x.aiu, x.uocn, x.vocn, x.waterx, x.watery, x.forcex, x.forcey, x.umassdtei, x.fm,
                          x.uarear, sx, sy, ro);
               const unsigned qu = q - nx8;
-              st8(s_out, qu, ro.u);
-              st8(s_out, qu + n8, ro.v);
+              st_uv(qu, ro.u, ro.v);
               if (LAST) {
                 st8(a.strintx + base, qu, ro.strintx);
                 st8(a.strinty + base, qu, ro.strinty);
@@ -1351,8 +1403,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
               }
               if (cyc && (col == ilo || col == ihi)) {
                 const unsigned qg = (unsigned)(ru - 1) * nx8 + (unsigned)(col == ilo ? ihi : ilo - 2) * 8u;
-                st8(s_out, qg, ro.u);
-                st8(s_out, qg + n8, ro.v);
+                st_uv(qg, ro.u, ro.v);
               }
             } else {
               stepu_store_o<LAST>(a, x, base, q - nx8, col, ru, ilo, ihi, jlo, jhi, us, vs, sx, sy);
@@ -2305,6 +2356,31 @@ __global__ __launch_bounds__(256) void k_skew_pack(size_t n, const double* __res
   }
   msk[q] = (tmk[q] == 1 ? 1 : 0) | (umk[q] != 0 ? 2 : 0);
 }
+// plane layout (14 planes of n doubles: u, v, 12 stresses) <-> the sweep's pair layout (7 planes of n pairs)
+__global__ __launch_bounds__(256) void k_to_pairs(size_t n, const double* __restrict__ in, double* __restrict__ out,
+                                                  double* __restrict__ out2) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+#pragma unroll
+  for (int p = 0; p < 7; ++p) {
+    dbl2 t;
+    t.x = in[(size_t)(2 * p) * n + q];
+    t.y = in[(size_t)(2 * p + 1) * n + q];
+    *(dbl2*)(out + 2 * ((size_t)p * n + q)) = t;
+    if (out2) *(dbl2*)(out2 + 2 * ((size_t)p * n + q)) = t;
+  }
+}
+__global__ __launch_bounds__(256) void k_from_pairs(size_t n, const double* __restrict__ in, double* __restrict__ out) {
+  const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n) return;
+#pragma unroll
+  for (int p = 0; p < 7; ++p) {
+    const dbl2 t = *(const dbl2*)(in + 2 * ((size_t)p * n + q));
+    out[(size_t)(2 * p) * n + q] = t.x;
+    out[(size_t)(2 * p + 1) * n + q] = t.y;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_skew_pack_grid(size_t n, const double* __restrict__ HTN, const double* __restrict__ HTE,
                                                         double* __restrict__ hnhe) {
   const size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2427,6 +2503,8 @@ void Evp::set_option(const char* key, int value) {
     stamps_on = value != 0;
   } else if (!std::strcmp(key, "skew_split")) {  // the sweep in front of a wide-halo refresh as edge + interior launches
     split_on = value != 0;
+  } else if (!std::strcmp(key, "skew_pairs")) {   // the sweep's pair layout of u | v and the stresses (16-byte loads and stores)
+    pairs_on = value != 0;
   } else if (!std::strcmp(key, "skew_split_probe")) {   // measurement aid, see Evp::tiles_for (wrong results by design)
     CICE_REQUIRE(value >= 0 && value <= 64, "skew_split_probe must be 0 .. 64");
     split_probe = value;
@@ -2678,6 +2756,8 @@ void Evp::prepare(double dt) {
   // both copies of the double-buffered fields start out identical: cells the subcycle
   // kernel never writes (outside the masks) then hold the same value in either copy
   CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
+  copies_identical = true;   // (until the first subcycle kernel writes one of them)
+  flips = 0;
   skew_packed = false;
   if (can_skew() || can_skew_fold()) skew_pack();   // the sweep kernel's interleaved inputs of this step
   CICE_HIP(hipGetLastError());
@@ -2846,6 +2926,7 @@ void Evp::after_subcycle(int ksub) {
   const bool fwd = halo.fwd_ok();
   cur = 1 - cur;
   ++flips;
+  copies_identical = false;
   // On-rank ghost cells were written by the kernel itself.  Rows owned by other blocks/ranks:
   // classic domain -> every subcycle (:397-402); wide-halo domain -> u, v and sigma every
   // `overlap` subcycles and after the last one (the overlap rows are recomputed in between and
@@ -3047,8 +3128,20 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
 }
 
 template <int K, int WS>
-static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s) {
+static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s, bool pairs = false) {
   const dim3 blk(64 * K);
+  if constexpr (K == 4 && WS == 3) {
+    if (pairs) {   // (the pair layout is built for the default shape only)
+      if (last) {
+        if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, true, true, WS, true>), g, blk, 0, s, sa);
+        else hipLaunchKernelGGL((k_subcycle_skew<K, true, false, WS, true>), g, blk, 0, s, sa);
+      } else {
+        if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, false, true, WS, true>), g, blk, 0, s, sa);
+        else hipLaunchKernelGGL((k_subcycle_skew<K, false, false, WS, true>), g, blk, 0, s, sa);
+      }
+      return;
+    }
+  }
   if (last) {
     if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, true, true, WS>), g, blk, 0, s, sa);
     else hipLaunchKernelGGL((k_subcycle_skew<K, true, false, WS>), g, blk, 0, s, sa);
@@ -3056,6 +3149,34 @@ static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hip
     if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, false, true, WS>), g, blk, 0, s, sa);
     else hipLaunchKernelGGL((k_subcycle_skew<K, false, false, WS>), g, blk, 0, s, sa);
   }
+}
+
+// The sweep's pair layout (k_subcycle_skew<.., PAIRS>): used on domains whose sweeps are the default shape (K = 4), whose
+// east-west ghost copies are the plain wrap, and that have no refresh, no message and no fold between two sweeps (one rank,
+// one full-width block: the 0.1-degree configuration on one GPU) -- the halo lists address planes.
+bool Evp::pairs_ok() const {
+  static const bool env_off = [] { const char* e = std::getenv("CICE4_AMD_SKEW_PAIRS"); return e && e[0] == '0'; }();
+  if (!pairs_on || env_off || !SKEW_WIDE) return false;
+  return can_skew() && skew_levels() == 4 && skew_waves_per_simd(4) == 3 && fwd_is_ew_wrap && !halo.has_refresh() &&
+         !halo.has_fold() && dom.overlap == 0;
+}
+// the state moves into the pair copies (both: cells a sweep never writes have to hold the same value in either copy) ...
+void Evp::to_pairs() {
+  if (in_pairs) return;
+  const dim3 g((unsigned)((n + 255) / 256));
+  if (flips == 0 && copies_identical) {
+    hipLaunchKernelGGL(k_to_pairs, g, dim3(256), 0, stream, n, (const double*)st[cur].p, st2[cur].p, st2[1 - cur].p);
+  } else {
+    hipLaunchKernelGGL(k_to_pairs, g, dim3(256), 0, stream, n, (const double*)st[cur].p, st2[cur].p, (double*)nullptr);
+    hipLaunchKernelGGL(k_to_pairs, g, dim3(256), 0, stream, n, (const double*)st[1 - cur].p, st2[1 - cur].p, (double*)nullptr);
+  }
+  in_pairs = true;
+}
+// ... and back (the current copy; the other one keeps what it held, as after any subcycle)
+void Evp::to_planes() {
+  if (!in_pairs) return;
+  hipLaunchKernelGGL(k_from_pairs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, (const double*)st2[cur].p, st[cur].p);
+  in_pairs = false;
 }
 
 // the arguments every launch of the sweep kernel shares
@@ -3072,8 +3193,8 @@ void Evp::skew_args(SkewArgs& sa, int K) {
   sa.phases = nullptr;
   sa.stagger_ticks = skew_stagger_ns / 10;
   sa.stagger_mod = std::max(1, skew_blocks(K));
-  sa.st_in = st[cur].p;
-  sa.st_out = st[1 - cur].p;
+  sa.st_in = in_pairs ? st2[cur].p : st[cur].p;
+  sa.st_out = st[1 - cur].p;       // (skew_launch: the pair copy unless the sweep is the last of evp(dt))
   sa.uar = uarena.p;
   sa.uar4 = uar4.p;
   sa.hnhe = hnhe.p;
@@ -3082,14 +3203,16 @@ void Evp::skew_args(SkewArgs& sa, int K) {
   sa.tile_first = sa.tile_count = 0;
 }
 
-void Evp::skew_launch(const SkewArgs& sa, int K, bool last, int nt, hipStream_t s) {
+void Evp::skew_launch(const SkewArgs& sa0, int K, bool last, int nt, hipStream_t s) {
   const dim3 g(8 * ((nt + 7) / 8));
   const bool damp = sc.evp_damping != 0;
   const int WS = skew_waves_per_simd(K);
+  SkewArgs sa = sa0;
+  if (in_pairs && !last) sa.st_out = st2[1 - cur].p;
   switch (K * 10 + WS) {
     case 23: launch_skew_kb<2, 3>(sa, last, damp, g, s); break;
     case 33: launch_skew_kb<3, 3>(sa, last, damp, g, s); break;
-    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s); break;
+    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s, in_pairs); break;
     case 42: launch_skew_kb<4, 2>(sa, last, damp, g, s); break;
     case 53: launch_skew_kb<5, 3>(sa, last, damp, g, s); break;
     case 63: launch_skew_kb<6, 3>(sa, last, damp, g, s); break;
@@ -3119,6 +3242,7 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
     sa.phases = sa.stamps ? sa.stamps + 4 * g : nullptr;
   }
   skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, stream);
+  if (in_pairs && ksub + K - 1 == sc.ndte) in_pairs = false;   // the last sweep of evp(dt) stores planes
   if (flip_and_halo) after_subcycle(ksub + K - 1);
 }
 
@@ -4068,6 +4192,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
   }
   cur = 1 - cur;   // the result is in the other copy whatever the parity of nsub
   ++flips;
+  copies_identical = false;
   return true;
 }
 
@@ -4077,6 +4202,7 @@ void Evp::launch_range(int ksub0, int nsub) {
   const bool skew = can_skew(), skew_fold = !skew && can_skew_fold();
   const int K = skew_levels();
   const bool trim = skew && can_trim(), split = trim && can_split();
+  const bool pairs = skew && !trim && split_probe == 0 && pairs_ok();
   const int end = ksub0 + nsub - 1;
   for (int k = ksub0; k <= end;) {
     // a wide-halo refresh falls after subcycles that are multiples of `overlap`: a launch must not straddle one,
@@ -4090,6 +4216,7 @@ void Evp::launch_range(int ksub0, int nsub) {
     };
     if (skew && clear(K)) {
       const int kend = k + K - 1;
+      if (pairs) to_pairs();
       if (split_probe > 0 && !in_capture && dom.overlap == 0 && dom.nblocks() == 1 && !halo.multi_rank()) {
         if (!stream2) {
           (void)tiles_for(K, 0, true);
@@ -4112,13 +4239,16 @@ void Evp::launch_range(int ksub0, int nsub) {
       launch_subcycle_skew_fold(k, K);
       k += K;
     } else if (fuse && clear(2)) {
+      to_planes();
       launch_subcycle_pair(k);
       k += 2;
     } else {
+      to_planes();
       launch_subcycle(k);
       k += 1;
     }
   }
+  to_planes();   // whoever comes next (finish, download, another range) finds the state where it always was
 }
 
 void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
@@ -4142,6 +4272,9 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     const int K = skew_levels(), seg = skew_seg_rows(K);
     build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
   }
+  if (pairs_ok())
+    for (int k = 0; k < 2; ++k)
+      if (st2[k].n < 14 * n) st2[k].alloc(14 * n);
   if ((can_skew() || can_skew_fold()) && !skew_packed) skew_pack();   // (sweeps switched on after prepare(): allocations outside any capture)
   if (can_skew() && can_trim()) build_split(skew_levels());   // (uploads tables: outside any capture)
   bool replayed = false;
@@ -4153,7 +4286,8 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   if (!replayed && graph_ok) {
     const int key[4] = {cur, ksub0, nsub,
                         ((((waves * 100 + rows_per_wave) * 2 + (derive_on ? 1 : 0)) * 64 + (fuse_on ? 32 : 0) + waves2) * 16 +
-                         (can_skew() || can_skew_fold() ? skew_levels() : 0)) * 64 + (halo.generation() & 63)};   // (set_option drops the graph anyway)
+                         (can_skew() || can_skew_fold() ? skew_levels() : 0)) * 128 + (halo.generation() & 63) * 2 +
+                            (copies_identical ? 1 : 0)};   // (set_option drops the graph anyway)
     const int cur0 = cur;
     if (!graph_exec || std::memcmp(key, graph_key, sizeof(key)) != 0) {
       drop_graph();

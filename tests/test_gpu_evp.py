@@ -817,9 +817,28 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
                            ("skew_seg_rows", seg), ("use_graph", graph), ("skew_gen_pct", pct), ("skew_prio", prio)):
                 ctx.evp_set_option(key, v)
             assert ctx.evp_get_info("skew") == 1 and ctx.evp_get_info("skew_levels") == K
+            # K = 4 on a cyclic one-block grid: the state lives in the sweep's pair layout between the first and the last
+            # sweep of evp(dt) (16-byte loads and stores; the last sweep stores planes; a tail of pairs / singles converts back)
+            assert ctx.evp_get_info("skew_pairs") == (1 if K == 4 and ew == 1 else 0)
             ctx.evp(DT, sg)
             for k in keys:
                 assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, pct, prio, k)
+            if K == 4 and ew == 1 and seg == 0 and pct == 0:     # the plane layout all the way: same bits
+                sp = {k: v.copy() for k, v in s.items()}
+                ctx.evp_set_option("skew_pairs", 0)
+                assert ctx.evp_get_info("skew_pairs") == 0
+                ctx.evp(DT, sp)
+                ctx.evp_set_option("skew_pairs", 1)
+                for k in keys:
+                    assert np.array_equal(sp[k], ref[k]), ("planes", ndte, damping, k)
+                # a loop cut into ranges: sweeps, a single subcycle in between (planes), sweeps again
+                if ndte == NDTE:
+                    b = {k: v.copy() for k, v in s.items()}
+                    ctx.evp_upload(b); ctx.evp_prepare(DT)
+                    ctx.evp_subcycles(1, 8); ctx.evp_subcycles(9, 1); ctx.evp_subcycles(10, 3); ctx.evp_subcycles(13, NDTE - 12)
+                    ctx.evp_finish(); ctx.evp_download(b)
+                    for k in EVP_OUT_FIELDS:
+                        assert np.array_equal(b[k], ref[k]), ("ranges in the pair layout", k)
 
 
 @pytest.mark.parametrize("nxg,nyg,ew,ns", [(96, 70, 1, 0), (20, 33, 1, 0), (62, 18, 1, 0), (63, 18, 1, 0), (64, 18, 1, 0),
