@@ -863,6 +863,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "skew")) *value = c_->evp->can_skew() || c_->evp->can_skew_fold() ? 1 : 0;
   else if (!std::strcmp(key, "skew_fold")) *value = !c_->evp->can_skew() && c_->evp->can_skew_fold() ? 1 : 0;
   else if (!std::strcmp(key, "skew_levels")) *value = c_->evp->skew_levels();
+  else if (!std::strcmp(key, "skew_subs")) *value = c_->evp->skew_subs(c_->evp->skew_levels());
   else if (!std::strcmp(key, "skew_pairs")) *value = c_->evp->pairs_ok() ? 1 : 0;
   else if (!std::strcmp(key, "skew_trim_ext")) *value = (c_->evp->can_skew() && c_->evp->can_trim()) ? 1 : 0;
   else if (!std::strcmp(key, "skew_split")) *value = (c_->evp->can_skew() && c_->evp->can_split()) ? 1 : 0;
@@ -1773,6 +1774,19 @@ int cice_transport_remap(cice_ctx* ctx, double dt, const cice_transport_fields* 
   c_->chain_ready = false;
   c_->transport->remap(dt, *f, l_stop, istop, jstop);
   CICE_CATCH
+}
+
+// test aid, no device needed: smallest shift of the sweep kernel's strip layout that is right for a block of ncol columns
+// (K levels, S wavefronts per level), -1 if none; *strips = column strips of the block with it
+int cice_debug_skew_layout(int K, int S, int ncol, int cyclic, int* strips) {
+  if (K < 2 || K > 8 || (S != 1 && S != 3) || ncol < 1) return -2;
+  for (int shift = 0; shift < 2 * K + 4; ++shift)
+    if (evp_skew_layout_ok(K, S, ncol, shift, cyclic != 0)) {
+      const int ownw = 62 * S + 2 - 2 * K, f = ownw - 1 - shift, npos = ncol + 1;
+      if (strips) *strips = npos <= f ? 1 : 1 + (npos - f + ownw - 1) / ownw;
+      return shift;
+    }
+  return -1;
 }
 
 int cice_transport_chain(cice_ctx* ctx, const cice_transport_fields* f) {

@@ -62,6 +62,7 @@ class Evp {
   int skew_levels() const;   // its K
   int skew_seg_rows(int K) const;  // rows a workgroup of the sweep owns
   int skew_strips(int K, int* shift) const;   // column strips of a block
+  int skew_subs(int K) const;                 // wavefronts per level (3: one 12-wavefront workgroup per CU)
   int skew_blocks(int K) const;    // workgroups per CU it is built for
   int skew_waves_per_simd(int K) const;
   bool can_fuse() const;     // two subcycles per launch on this domain
@@ -162,6 +163,8 @@ class Evp {
   DevBuf<double> uarena;   // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear live here (views below)
   DevBuf<double> uar4, hnhe;   // the sweep kernel's interleaved copies: 4 planes of pairs of the above; {HTN, HTE} pairs
   DevBuf<int32_t> skew_msk;    // bit 0: icetmask == 1, bit 1: iceumask != 0
+  int skew_subs_opt = 3;
+  mutable int strips_cache[9][2] = {}, strips_cache_shift[9][2] = {};   // [K][S == 3]: strips of a block (0: not computed yet), shift
   bool skew_packed = false;    // ... built for the current prepare()
   void skew_pack();
   // the sweep's pair layout of the state (k_subcycle_skew<.., PAIRS>)
@@ -212,6 +215,9 @@ class Evp {
   SubArgs make_args() const;
   void drop_graph();
 };
+
+// host-only: is the sweep kernel's column layout right for a ring of ncol + 1 positions with this shift? (evp.hip: skew_layout_ok)
+bool evp_skew_layout_ok(int K, int S, int ncol, int shift, bool cyc);
 
 #ifdef CICE4_AMD_AUSCOM
 // the coupled flavour's namelist variables (ice_dyn_evp.F90:91-97, ice_init.F90:258-264) on the current device

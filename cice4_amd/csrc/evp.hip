@@ -959,29 +959,37 @@ namespace {
 // 14 of 8, the last level stores it with 7.  The levels at the two ends of the pipeline are the ones every step waits
 // for (profiles/r04_sweep_phases*.txt), and what makes them slow is the NUMBER of vector-memory instructions they issue.
 // The sweep that ends evp(dt) (LAST) stores in the ordinary plane layout, so that nothing has to be converted back.
-template <int K, bool LAST, bool DAMP, int WS, bool PAIRS = false>
-__global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa) {
+// S: wavefronts per LEVEL.  S = 3: twelve wavefronts (K = 4), ONE workgroup per CU instead of three -- the same three
+// wavefronts per SIMD and the same LDS (3 x 42 KB), but the three strips of 64 lanes lie side by side and overlap by two
+// columns instead of each losing 2K: a workgroup spans TXW = 62 S + 2 columns and owns TXW - 2K of them (180 of 188
+// against 3 x 56 of 192).  Rows travel from level to level through LDS indexed by the workgroup's COLUMN, so a wavefront
+// finds the velocity of its first lane's western neighbour -- produced by the wavefront beside it -- where it finds its
+// own.  Of the two shared columns the western wavefront owns the first (its lane 62: stress and momentum right), the
+// eastern one the second (its lane 1); lane 63 of the one and lane 0 of the other compute nothing that is kept.
+template <int K, bool LAST, bool DAMP, int WS, bool PAIRS = false, int S = 1>
+__global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew(const SkewArgs sa) {
   const SubArgs& a = sa.a;
   constexpr bool PIN = PAIRS, POUT = PAIRS && !LAST;
+  constexpr int TXW = 62 * S + 2;       // columns a workgroup spans (S = 1: the 64 lanes of its one wavefront per level)
   // Columns: a level loses one lane per side (the stress needs the western neighbour's velocity, the momentum equation
   // the eastern neighbour's stress), so after K levels lanes K .. 63-K are right: a strip owns OWNW = 64 - 2K columns.
   // Strip 0 starts at the ring's seam: its first owned lane is ilo, whose western neighbour ihi sits TWO lanes away (G in
   // between) -- one lane more of rim, it owns lanes K+1 .. 63-K.  If that layout puts G into the east rim of a strip within
   // K-1 lanes of its last owned lane (the dependency path crosses G without gaining a level and would need a lane more),
   // strip 0 gives up sa.own_shift lanes and everything moves west until G sits on that strip's lane 63 (Evp::skew_strips).
-  constexpr int OWNW = 64 - 2 * K;
+  constexpr int OWNW = TXW - 2 * K;
   // EARLY: the hand-off of level 0 has THREE slots (row mod 3), s_sig0; the others two, s_sig[k - 1] for level k >= 1.
   // Level 0 can then put the stresses it has just formed into LDS at the END of its step (the slot was read two steps
   // ago) and fetch those of the next row into the same registers BEFORE the barrier: they are in flight during the
   // barrier and the first third of the next step instead of being waited for in the middle of it.
-  constexpr bool EARLY = SKEW_EARLY && !(SKEW_TPASS && K <= 4);
-  __shared__ double s_sig[EARLY ? (K > 2 ? K - 2 : 1) : K - 1][2][12][TX];
+  constexpr bool EARLY = SKEW_EARLY && !(SKEW_TPASS && K <= 4) && S == 1;
+  __shared__ double s_sig[EARLY ? (K > 2 ? K - 2 : 1) : K - 1][2][12][TXW];
   __shared__ double s_sig0[EARLY ? 3 : 1][EARLY ? 12 : 1][TX];
-  __shared__ double s_uv[K - 1][2][2][TX];
+  __shared__ double s_uv[K - 1][2][2][TXW];
   // TP: the T-cell inputs of a row (HTN, HTE, strength, icetmask, iceumask) ride along with it: only level 0 fetches them
   // from memory, the others find them in LDS a step after the level before them held them (10.5 KB more per workgroup:
   // K = 4 stays at three workgroups per CU, 3 x 52.5 KB of 160)
-  constexpr bool TP = SKEW_TPASS && K <= 4;
+  constexpr bool TP = SKEW_TPASS && K <= 4 && S == 1;
   __shared__ double s_tin[TP ? K - 1 : 1][2][3][TX];
   __shared__ int s_msk[TP ? K - 1 : 1][2][TX];
   const int per_blk = a.tiles_x * a.tiles_y;
@@ -1007,8 +1015,12 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const int ilo = a.blk[6 * b + 0], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
   const int lx = threadIdx.x & 63;
   // time level of this wavefront (uniform); dealt differently from workgroup to workgroup, so that the wavefronts
-  // a SIMD holds are at different levels (level 0 waits for memory, level K-1 stores)
-  const int k = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) + tile_lin) % K;
+  // a SIMD holds are at different levels (level 0 waits for memory, level K-1 stores).  S > 1: wavefront = level x S +
+  // sub-strip, so the S wavefronts of a level land on different SIMDs too
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int sub = S == 1 ? 0 : wv % S;
+  const int k = ((S == 1 ? wv : wv / S) + tile_lin) % K;
+  const int cw = sub * 62 + lx;          // this lane's column of the workgroup
   const int nx = a.nx;
   const unsigned n8 = (unsigned)(a.n * 8);                  // bytes between two planes
   const size_t base = (size_t)b * nx * a.ny;
@@ -1048,7 +1060,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   // column: ring position (0 = ilo, ncol = G) -> memory column, as in k_subcycle2
   const int ncol = ihi - ilo + 1;
   const int own0 = txi == 0 ? K + 1 + sa.own_shift : K;
-  const int kraw = (txi == 0 ? 0 : (OWNW - 1 - sa.own_shift) + (txi - 1) * OWNW) + lx - own0;
+  const int kraw = (txi == 0 ? 0 : (OWNW - 1 - sa.own_shift) + (txi - 1) * OWNW) + cw - own0;
   int col = -1;
   if (cyc) {
     int kk = kraw % (ncol + 1);
@@ -1060,7 +1072,10 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
   const bool col_ok = col >= 1;
   const bool isG = cyc && col == ihi + 1;
   const bool at_ilo = cyc && col == ilo;
-  const bool own_col = lx >= own0 && lx <= 63 - K && kraw >= 0 && kraw <= ncol;
+  // (S > 1: of the two columns neighbouring wavefronts share, lane 62 of the western one owns the first, lane 1 of the
+  //  eastern one the second)
+  const bool own_lane = S == 1 || (lx >= (sub == 0 ? 0 : 1) && lx <= (sub == S - 1 ? 63 : 62));
+  const bool own_col = own_lane && cw >= own0 && cw <= TXW - 1 - K && kraw >= 0 && kraw <= ncol;
   const bool tcol = col_ok && col >= ilo;                 // (col <= ihi + 1 holds)
   const bool ucol = col_ok && col >= ilo && col <= ihi;
   const unsigned co = (unsigned)(col_ok ? col - 1 : 0) * 8u;
@@ -1143,9 +1158,9 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
     const bool urow = act && r > lo;                   // (jlo <= r-1 <= jhi holds then)
     // ---- the stresses of the previous row go to the next level now, not when they were formed: the slot they go
     // into was read by that level during the previous step (two slots, one barrier per step)
-    if (!lastlev && r - 1 >= lo && r - 1 <= hi && !(EARLY && k == 0)) {
+    if (!lastlev && r - 1 >= lo && r - 1 <= hi && !(EARLY && k == 0) && own_lane) {
 #pragma unroll
-      for (int c = 0; c < 12; ++c) s_sig[EARLY ? k - 1 : k][(r - 1) & 1][c][lx] = s[c];
+      for (int c = 0; c < 12; ++c) s_sig[EARLY ? k - 1 : k][(r - 1) & 1][c][cw] = s[c];
     }
     // ---- take over what was fetched for this row.  The empty asm is a use of those registers placed BEFORE this
     // step's loads are issued: the wait for them that the compiler needs (it cannot count loads across the back edge
@@ -1273,7 +1288,7 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
       } else {
 #endif
 #pragma unroll
-        for (int c = 0; c < 12; ++c) s[c] = s_sig[EARLY ? k - 2 : k - 1][r & 1][c][lx];
+        for (int c = 0; c < 12; ++c) s[c] = s_sig[EARLY ? k - 2 : k - 1][r & 1][c][cw];
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -1295,8 +1310,8 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
         if (r > jhi) {
           if (col_ok) ld_uv(q, un, vn);
         } else {
-          un = s_uv[k - 1][r & 1][0][lx];
-          vn = s_uv[k - 1][r & 1][1][lx];
+          un = s_uv[k - 1][r & 1][0][cw];
+          vn = s_uv[k - 1][r & 1][1][cw];
         }
       }
       double uw, vw;
@@ -1426,8 +1441,10 @@ __global__ __launch_bounds__(64 * K, WS) void k_subcycle_skew(const SkewArgs sa)
             v1 = gv;
           }
         }
-        s_uv[k][(r - 1) & 1][0][lx] = u1;
-        s_uv[k][(r - 1) & 1][1][lx] = v1;
+        if (own_lane) {
+          s_uv[k][(r - 1) & 1][0][cw] = u1;
+          s_uv[k][(r - 1) & 1][1][cw] = v1;
+        }
       }
       p0 = o.str[0]; pe1 = e1; p4 = o.str[4]; pe6 = e6;
       us = un; vs = vn; usw = uw; vsw = vw;
@@ -2503,6 +2520,11 @@ void Evp::set_option(const char* key, int value) {
     stamps_on = value != 0;
   } else if (!std::strcmp(key, "skew_split")) {  // the sweep in front of a wide-halo refresh as edge + interior launches
     split_on = value != 0;
+  } else if (!std::strcmp(key, "skew_subs")) {    // wavefronts per level of the sweep kernel: 3 (default shape) or 1
+    CICE_REQUIRE(value == 1 || value == 3, "skew_subs must be 1 or 3");
+    skew_subs_opt = value;
+    std::memset(strips_cache, 0, sizeof(strips_cache));
+    tile_tabs.clear();
   } else if (!std::strcmp(key, "skew_pairs")) {   // the sweep's pair layout of u | v and the stresses (16-byte loads and stores)
     pairs_on = value != 0;
   } else if (!std::strcmp(key, "skew_split_probe")) {   // measurement aid, see Evp::tiles_for (wrong results by design)
@@ -2529,6 +2551,7 @@ void Evp::set_option(const char* key, int value) {
   } else {
     throw Error{CICE_EINVAL, std::string("unknown option ") + key};
   }
+  std::memset(strips_cache, 0, sizeof(strips_cache));   // (the strip layout depends on K and on the workgroup shape)
   drop_graph();
 }
 
@@ -3037,23 +3060,92 @@ bool Evp::can_skew() const {
 
 int Evp::skew_levels() const { return skew_k_opt ? skew_k_opt : 4; }
 
-// Column strips of the sweep kernel (its geometry comment): strip 0 owns 63 - 2K - shift ring positions, every other
-// strip 64 - 2K; positions 0 .. ncol (ncol = the ghost column G, whose T-cell has stresses of its own).  shift = 1
-// where the plain layout would leave ihi (position ncol - 1) on the LAST owned lane of a strip.
-int Evp::skew_strips(int K, int* shift_out) const {
-  const int ncol = dom.nx_block - 2, ownw = 64 - 2 * K;
-  int shift = 0;
-  const int first = ownw - 1;                      // positions of strip 0 without the shift
-  // G (position ncol) d = 1 .. K-1 positions beyond the last owned position of a strip lies in that strip's east rim ON
-  // the dependency path of its last column: the path does not gain a level there (G's velocity is the next lane's), so
-  // it ends one lane beyond lane 63.  Strip 0 gives up K - d lanes: G then sits on lane 63, where only level 0 reads it.
-  if (ncol > first - 1) {
-    const int d = (ncol - (first - 1) - 1) % ownw + 1;   // distance of G from the last owned position at or below it
-    if (d <= K - 1) shift = K - d;
+// Wavefronts per level of the sweep kernel (its template parameter S): three for the default shape -- one 12-wavefront
+// workgroup per CU whose strips lie side by side -- one for every other K (LDS) and where the option says so.
+int Evp::skew_subs(int K) const {
+  static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SUBS"); return e ? std::atoi(e) : 0; }();
+  const int want = env ? env : skew_subs_opt;
+  return (K == 4 && skew_waves_per_simd(4) == 3 && want == 3) ? 3 : 1;
+}
+
+// Is the column layout of the sweep kernel right for a ring of ncol + 1 positions (0 = ilo ... ncol - 1 = ihi, ncol = G)?
+// Lane-level restatement of the kernel's dependencies: a level's stress at a lane needs the velocity of that lane and of
+// its western neighbour (ihi, TWO lanes west, for the lane that holds ilo), G's velocity is the lane to its east, the
+// momentum equation needs the stress of the lane to the east; a wavefront has no neighbour beyond its lanes 0 and 63,
+// what it hands to the next level is what its owner lanes formed.  Every owned position must come out right after K levels.
+static bool skew_layout_ok(int K, int S, int ncol, int shift, bool cyc) {
+  const int txw = 62 * S + 2, ownw = txw - 2 * K, first = ownw - 1 - shift, npos = ncol + 1;
+  if (first < 1) return false;
+  const int nt = npos <= first ? 1 : 1 + (npos - first + ownw - 1) / ownw;
+  std::vector<char> covered(npos, 0);
+  for (int t = 0; t < nt; ++t) {
+    const int own0 = t == 0 ? K + 1 + shift : K, start = t == 0 ? 0 : first + (t - 1) * ownw;
+    auto pos_of = [&](int cw) { return start + cw - own0; };
+    auto ring = [&](int p) { int r = p % npos; return r < 0 ? r + npos : r; };
+    auto valid_col = [&](int cw) { const int p = pos_of(cw); return cyc || (p >= -1 && p <= ncol); };
+    auto is_g = [&](int cw) { return cyc && ring(pos_of(cw)) == ncol; };
+    auto is_ilo = [&](int cw) { return cyc && ring(pos_of(cw)) == 0; };
+    // uo[cw]: the velocity of workgroup column cw handed to the current level is right (level 0: from memory)
+    std::vector<char> uo(txw, 1), sv(txw, 0), un(txw, 0);
+    for (int k = 0; k < K; ++k) {
+      std::fill(sv.begin(), sv.end(), 0);
+      std::fill(un.begin(), un.end(), 0);
+      for (int sub = 0; sub < S; ++sub) {
+        char st[64], mo[64];
+        for (int l = 0; l < 64; ++l) {        // stress: own and western velocity (through the wave shift: inside the wavefront)
+          const int cw = sub * 62 + l, w = is_ilo(cw) ? l - 2 : l - 1;
+          bool self = uo[cw] != 0;
+          if (k > 0 && is_g(cw)) self = l + 1 < 64 && uo[cw + 1];      // G mirrors the lane to its east (formed by the level before)
+          st[l] = valid_col(cw) && w >= 0 && self && uo[sub * 62 + w];
+        }
+        for (int l = 0; l < 64; ++l) mo[l] = l + 1 < 64 && st[l] && st[l + 1];
+        const int l0 = sub == 0 ? 0 : 1, l1 = sub == S - 1 ? 63 : 62;
+        for (int l = l0; l <= l1; ++l) {      // owner lanes hand on
+          sv[sub * 62 + l] = st[l];
+          // (G's own "velocity" is never read: its reader takes the next lane's; a ghost column beyond an open edge keeps
+          //  the velocity it has: the kernel hands it on unchanged)
+          const int p = pos_of(sub * 62 + l);
+          un[sub * 62 + l] = mo[l] || is_g(sub * 62 + l) || (!cyc && (p < 0 || p >= ncol));
+        }
+      }
+      uo = un;
+    }
+    for (int cw = own0; cw <= txw - 1 - K; ++cw) {
+      const int p = pos_of(cw);
+      if (p < 0 || p > ncol) continue;
+      // owned: the last level's stress (T-cell) and momentum (U-cell, not for G) at the owner lane
+      if (!sv[cw] || (!(p == ncol) && !uo[cw])) return false;
+      covered[p] = 1;
+    }
   }
-  if (shift_out) *shift_out = shift;
-  const int f = first - shift, npos = ncol + 1;
-  return npos <= f ? 1 : 1 + (npos - f + ownw - 1) / ownw;
+  for (int p = 0; p < npos; ++p)
+    if (!covered[p]) return false;
+  return true;
+}
+
+// host-only test hook (cice_debug_skew_layout): the layout rule without a device
+bool evp_skew_layout_ok(int K, int S, int ncol, int shift, bool cyc) { return skew_layout_ok(K, S, ncol, shift, cyc); }
+
+// Column strips of the sweep kernel (its geometry comment): strip 0 owns TXW - 2K - 1 - shift ring positions, every other
+// strip TXW - 2K; positions 0 .. ncol (ncol = the ghost column G, whose T-cell has stresses of its own).  shift: the
+// smallest number of lanes strip 0 has to give up for the layout to be right (skew_layout_ok): the seam of the ring
+// (ihi, G, ilo) must not lie where a strip's east rim -- or, S > 1, the two columns neighbouring wavefronts share --
+// would need one lane more.
+int Evp::skew_strips(int K, int* shift_out) const {
+  const int ncol = dom.nx_block - 2, S = skew_subs(K), txw = 62 * S + 2, ownw = txw - 2 * K;
+  int& cached = strips_cache[K][S == 3];
+  int& cshift = strips_cache_shift[K][S == 3];
+  if (cached == 0) {
+    int shift = 0;
+    const bool cyc = dom.ew == BND_CYCLIC;
+    while (shift < 2 * K + 4 && ncol >= K && !skew_layout_ok(K, S, ncol, shift, cyc)) ++shift;
+    if (shift >= 2 * K + 4) shift = 0;     // (blocks narrower than K columns: as before)
+    const int f = ownw - 1 - shift, npos = ncol + 1;
+    cached = npos <= f ? 1 : 1 + (npos - f + ownw - 1) / ownw;
+    cshift = shift;
+  }
+  if (shift_out) *shift_out = cshift;
+  return cached;
 }
 
 // wavefronts per SIMD the kernel is built for (registers), and the workgroups per CU that follow from it and from
@@ -3063,6 +3155,7 @@ int Evp::skew_waves_per_simd(int K) const {
   return K <= 6 ? 3 : 2;
 }
 int Evp::skew_blocks(int K) const {
+  if (skew_subs(K) == 3) return 1;    // twelve wavefronts, 3 x 42 KB of LDS: the CU
   const int by_regs = skew_waves_per_simd(K) * 4 / K;
   const bool tp = SKEW_TPASS && K <= 4, early = SKEW_EARLY && !tp;
   const int by_lds = K > 1 ? (160 * 1024) / ((K - 1) * (tp ? 17920 : 14336) + (early ? 6144 : 0)) : 16;
@@ -3127,10 +3220,27 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
   std::memcpy(skew_rows_key, key, sizeof(key));
 }
 
+template <bool PAIRS>
+static void launch_skew_s3(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s) {
+  const dim3 blk(64 * 4 * 3);
+  if (last) {
+    if (damp) hipLaunchKernelGGL((k_subcycle_skew<4, true, true, 3, PAIRS, 3>), g, blk, 0, s, sa);
+    else hipLaunchKernelGGL((k_subcycle_skew<4, true, false, 3, PAIRS, 3>), g, blk, 0, s, sa);
+  } else {
+    if (damp) hipLaunchKernelGGL((k_subcycle_skew<4, false, true, 3, PAIRS, 3>), g, blk, 0, s, sa);
+    else hipLaunchKernelGGL((k_subcycle_skew<4, false, false, 3, PAIRS, 3>), g, blk, 0, s, sa);
+  }
+}
+
 template <int K, int WS>
-static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s, bool pairs = false) {
+static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s, bool pairs = false, int subs = 1) {
   const dim3 blk(64 * K);
   if constexpr (K == 4 && WS == 3) {
+    if (subs == 3) {   // twelve wavefronts per workgroup: three per level, side by side
+      if (pairs) launch_skew_s3<true>(sa, last, damp, g, s);
+      else launch_skew_s3<false>(sa, last, damp, g, s);
+      return;
+    }
     if (pairs) {   // (the pair layout is built for the default shape only)
       if (last) {
         if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, true, true, WS, true>), g, blk, 0, s, sa);
@@ -3212,7 +3322,7 @@ void Evp::skew_launch(const SkewArgs& sa0, int K, bool last, int nt, hipStream_t
   switch (K * 10 + WS) {
     case 23: launch_skew_kb<2, 3>(sa, last, damp, g, s); break;
     case 33: launch_skew_kb<3, 3>(sa, last, damp, g, s); break;
-    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s, in_pairs); break;
+    case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s, in_pairs, skew_subs(4)); break;
     case 42: launch_skew_kb<4, 2>(sa, last, damp, g, s); break;
     case 53: launch_skew_kb<5, 3>(sa, last, damp, g, s); break;
     case 63: launch_skew_kb<6, 3>(sa, last, damp, g, s); break;

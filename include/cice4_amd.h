@@ -459,6 +459,11 @@ typedef struct {
 int cice_transport_init(cice_ctx *ctx, const cice_transport_config *cfg, const cice_transport_grid *grid);
 int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *f, int32_t *l_stop,
                          int32_t *istop, int32_t *jstop);
+/* Test aid, needs no device: the column layout of the K-subcycle sweep kernel for a block of ncol columns (K time levels,
+ * S = 1 or 3 wavefronts per level; cyclic: east-west boundary).  Returns the number of lanes the strip at the ring's seam
+ * gives up so that every owned column comes out right (checked by a lane-level restatement of the kernel's dependencies),
+ * -1 if there is none; *strips = column strips of the block. */
+int cice_debug_skew_layout(int K, int S, int ncol, int cyclic, int *strips);
 /* evp -> transport WITHOUT a PCIe round trip.  In step_dynamics `call evp(dt)` is followed at once by `call
  * transport_remap(dt)` (source/ice_step_mod.F90:575-584): uvel, vvel come up from the device and go straight down again,
  * aicen, vicen are uploaded twice, and the rest of the state waits for the link while it idles during the subcycle loop.

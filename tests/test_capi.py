@@ -93,3 +93,28 @@ def test_host_model_sizes_are_checked():
     c.domain_create(16, 12, 8, 6)
     with pytest.raises(lib.CiceError):
         c.halo_msgs(7)
+
+
+def test_sweep_kernel_strip_layout_is_right_for_every_width():
+    """cice_debug_skew_layout (no device): for every block width and every K (and both workgroup shapes of K = 4) the strip
+    layout of the K-subcycle sweep kernel has a shift of the seam strip with which a lane-level restatement of the
+    kernel's dependencies -- western velocity for the stress (two lanes for ilo), eastern stress for the momentum, G's
+    velocity from the lane beside it, owner lanes of the shared columns -- leaves every owned column right; the shift is
+    small, and without the shift exactly the widths with the seam in a rim (or on shared columns) fail."""
+    import ctypes as C
+    from cice4_amd import lib
+    L = lib.load()
+    for K in (2, 3, 4, 5, 6, 8):
+        for S in ((1, 3) if K == 4 else (1,)):
+            ownw = 62 * S + 2 - 2 * K
+            shifted = 0
+            for ncol in list(range(K, 420)) + [1440, 3600]:
+                st = C.c_int(0)
+                sh = L.cice_debug_skew_layout(K, S, ncol, 1, C.byref(st))
+                assert 0 <= sh <= K + 1, (K, S, ncol, sh)
+                assert (st.value - 1) * ownw < ncol + 1 + ownw, (K, S, ncol, st.value)      # no strip too many
+                shifted += sh > 0
+                # open east-west edge: no seam, no shift
+                assert L.cice_debug_skew_layout(K, S, ncol, 0, C.byref(st)) == 0, (K, S, ncol)
+            assert 0 < shifted < 60, (K, S, shifted)
+    assert L.cice_debug_skew_layout(9, 1, 100, 1, None) == -2

@@ -781,10 +781,15 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
 @pytest.mark.parametrize("nxg,nyg,ew", [(96, 70, 1), (20, 33, 1), (53, 18, 1), (54, 18, 1), (55, 18, 1), (107, 9, 1),
                                          (109, 41, 1), (119, 5, 1), (200, 50, 1), (96, 70, 0), (130, 27, 2), (7, 6, 1),
                                          (300, 120, 1), (56, 12, 1), (57, 15, 1), (110, 12, 1), (111, 14, 1), (112, 11, 1),
-                                         (167, 13, 1), (111, 14, 2), (115, 12, 1), (103, 12, 1), (95, 14, 1)])
+                                         (167, 13, 1), (111, 14, 2), (115, 12, 1), (103, 12, 1), (95, 14, 1),
+                                         (179, 10, 1), (180, 10, 1), (181, 11, 1), (182, 10, 1), (237, 10, 1), (238, 9, 1),
+                                         (299, 9, 1), (360, 8, 1), (361, 8, 1), (57, 12, 1), (120, 9, 1), (400, 30, 0)])
 def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
     """k_subcycle_skew (K subcycles in one sweep: a pipeline of K time levels, one wavefront each, two rows apart,
     rows handed from level to level through LDS) against one launch per subcycle and the checker: bit for bit.
+    K = 4 in both workgroup shapes (twelve wavefronts, three per level side by side: 180 columns per strip, widths 179 ..
+    182, 360, 361, and 57, 119, 237, 299 where the seam would fall on the columns two wavefronts share; or four
+    wavefronts, one per level).
     Every K; widths around the strip strides (64 - 2K columns, the strip at the ring's seam one less; widths 55, 111, 167
     (K = 4), 119 (K = 2), 115 (K = 3), 53, 107 (K = 5), 103 (K = 6), 95 (K = 8) are the ones where ihi would fall on a strip's
     last owned lane and the layout shifts by one), blocks narrower than a strip (the ring wraps inside
@@ -820,9 +825,19 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
             # K = 4 on a cyclic one-block grid: the state lives in the sweep's pair layout between the first and the last
             # sweep of evp(dt) (16-byte loads and stores; the last sweep stores planes; a tail of pairs / singles converts back)
             assert ctx.evp_get_info("skew_pairs") == (1 if K == 4 and ew == 1 else 0)
+            # K = 4 runs as ONE 12-wavefront workgroup per CU: three wavefronts per level, their strips side by side
+            assert ctx.evp_get_info("skew_subs") == (3 if K == 4 else 1)
             ctx.evp(DT, sg)
             for k in keys:
                 assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, pct, prio, k)
+            if K == 4:       # ... and as three 4-wavefront workgroups per CU, one wavefront per level
+                s1w = {k: v.copy() for k, v in s.items()}
+                ctx.evp_set_option("skew_subs", 1)
+                assert ctx.evp_get_info("skew_subs") == 1
+                ctx.evp(DT, s1w)
+                ctx.evp_set_option("skew_subs", 3)
+                for k in keys:
+                    assert np.array_equal(s1w[k], ref[k]), ("one wavefront per level", ndte, damping, seg, graph, pct, prio, k)
             if K == 4 and ew == 1 and seg == 0 and pct == 0:     # the plane layout all the way: same bits
                 sp = {k: v.copy() for k, v in s.items()}
                 ctx.evp_set_option("skew_pairs", 0)
