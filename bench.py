@@ -798,8 +798,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     # (on a folded grid the sweep runs with a band of top rows beside it: "skew_fold"; the sweep is still the launch that counts)
     skew_k = ctx.evp_get_info("skew_levels") if ctx.evp_get_info("skew") or ctx.evp_get_info("skew_fold") else 0
     if skew_k:
-        tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k} wavefronts (one per time level, two rows apart) x 64 "
-                f"lanes, owns {64 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
+        subs = ctx.evp_get_info("skew_subs")
+        tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k * subs} wavefronts ({subs} per time level, levels two rows "
+                f"apart) x 64 lanes, owns {62 * subs + 2 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
     if skew_k and dom.get("overlap") and dom["overlap"] % skew_k:
         progress(f"{wl}: {dom['overlap']} overlap rows are no multiple of K = {skew_k}: part of every refresh interval "
                  f"runs the pair kernel instead of sweeps (auto_overlap avoids this; --overlap was given)")

@@ -163,7 +163,8 @@ class Evp {
   DevBuf<double> uarena;   // aiu, uocn, vocn, forcex, forcey, umassdtei, fm, uarear live here (views below)
   DevBuf<double> uar4, hnhe;   // the sweep kernel's interleaved copies: 4 planes of pairs of the above; {HTN, HTE} pairs
   DevBuf<int32_t> skew_msk;    // bit 0: icetmask == 1, bit 1: iceumask != 0
-  int skew_subs_opt = 3;
+  int skew_subs_opt = 1;       // wavefronts per level of the sweep kernel: 3 = one 12-wavefront workgroup per CU, measured SLOWER
+                               // (0.1 degree 286 us per subcycle against 266.5: profiles/r04_sweep_ab_three_wavefronts_per_level.txt)
   mutable int strips_cache[9][2] = {}, strips_cache_shift[9][2] = {};   // [K][S == 3]: strips of a block (0: not computed yet), shift
   bool skew_packed = false;    // ... built for the current prepare()
   void skew_pack();

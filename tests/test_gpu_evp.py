@@ -787,9 +787,9 @@ def test_two_subcycles_per_launch(ctx, orc, nxg, nyg, ew):
 def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
     """k_subcycle_skew (K subcycles in one sweep: a pipeline of K time levels, one wavefront each, two rows apart,
     rows handed from level to level through LDS) against one launch per subcycle and the checker: bit for bit.
-    K = 4 in both workgroup shapes (twelve wavefronts, three per level side by side: 180 columns per strip, widths 179 ..
-    182, 360, 361, and 57, 119, 237, 299 where the seam would fall on the columns two wavefronts share; or four
-    wavefronts, one per level).
+    K = 4 in both workgroup shapes (four wavefronts, one per level: the default; or twelve, three per level side by side:
+    180 columns per strip, widths 179 .. 182, 360, 361, and 57, 119, 237, 299 where the seam would fall on the columns two
+    wavefronts share).
     Every K; widths around the strip strides (64 - 2K columns, the strip at the ring's seam one less; widths 55, 111, 167
     (K = 4), 119 (K = 2), 115 (K = 3), 53, 107 (K = 5), 103 (K = 6), 95 (K = 8) are the ones where ihi would fall on a strip's
     last owned lane and the layout shifts by one), blocks narrower than a strip (the ring wraps inside
@@ -825,19 +825,18 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
             # K = 4 on a cyclic one-block grid: the state lives in the sweep's pair layout between the first and the last
             # sweep of evp(dt) (16-byte loads and stores; the last sweep stores planes; a tail of pairs / singles converts back)
             assert ctx.evp_get_info("skew_pairs") == (1 if K == 4 and ew == 1 else 0)
-            # K = 4 runs as ONE 12-wavefront workgroup per CU: three wavefronts per level, their strips side by side
-            assert ctx.evp_get_info("skew_subs") == (3 if K == 4 else 1)
+            assert ctx.evp_get_info("skew_subs") == 1
             ctx.evp(DT, sg)
             for k in keys:
                 assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, pct, prio, k)
-            if K == 4:       # ... and as three 4-wavefront workgroups per CU, one wavefront per level
-                s1w = {k: v.copy() for k, v in s.items()}
-                ctx.evp_set_option("skew_subs", 1)
-                assert ctx.evp_get_info("skew_subs") == 1
-                ctx.evp(DT, s1w)
+            if K == 4:       # ... and as ONE 12-wavefront workgroup per CU: three wavefronts per level, their strips side by side
+                s3w = {k: v.copy() for k, v in s.items()}      # (option "skew_subs": correct, measured slower, off by default)
                 ctx.evp_set_option("skew_subs", 3)
+                assert ctx.evp_get_info("skew_subs") == 3
+                ctx.evp(DT, s3w)
+                ctx.evp_set_option("skew_subs", 1)
                 for k in keys:
-                    assert np.array_equal(s1w[k], ref[k]), ("one wavefront per level", ndte, damping, seg, graph, pct, prio, k)
+                    assert np.array_equal(s3w[k], ref[k]), ("three wavefronts per level", ndte, damping, seg, graph, pct, prio, k)
             if K == 4 and ew == 1 and seg == 0 and pct == 0:     # the plane layout all the way: same bits
                 sp = {k: v.copy() for k, v in s.items()}
                 ctx.evp_set_option("skew_pairs", 0)
