@@ -196,7 +196,7 @@ class Evp {
 
   void launch_subcycle(int ksub);
   void launch_subcycle_pair(int ksub);
-  void launch_subcycle_skew(int ksub, int K, bool flip_and_halo = true);
+  void launch_subcycle_skew(int ksub, int K, bool flip_and_halo = true, hipStream_t on = nullptr);
   void skew_args(SkewArgs& sa, int K);
   void skew_launch(const SkewArgs& sa, int K, bool last, int nt, hipStream_t s);
   // the sweep in front of a wide-halo refresh as two launches: edge segments + refresh on the main stream, interior beside them

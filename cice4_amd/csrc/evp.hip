@@ -3332,7 +3332,7 @@ void Evp::skew_launch(const SkewArgs& sa0, int K, bool last, int nt, hipStream_t
 }
 
 // subcycles ksub .. ksub+K-1
-void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
+void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo, hipStream_t on) {
   ++loop_launches;
   SkewArgs sa{};
   skew_args(sa, K);
@@ -3351,7 +3351,7 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo) {
     sa.stamps = stamp_buffer((1 + 2 * (size_t)K) * g);      // [4 g] stamps, then [8 K g] phase sums per level
     sa.phases = sa.stamps ? sa.stamps + 4 * g : nullptr;
   }
-  skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, stream);
+  skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, on ? on : stream);
   if (in_pairs && ksub + K - 1 == sc.ndte) in_pairs = false;   // the last sweep of evp(dt) stores planes
   if (flip_and_halo) after_subcycle(ksub + K - 1);
 }
@@ -3505,7 +3505,10 @@ void Evp::launch_subcycle_skew_split(int ksub, int K) {
 // (rows above jhi - K come out wrong), and beside it a BAND of the top 2K + 1 rows runs the K subcycles one at a time,
 // k_subcycle + the halo update with its fold, on buffers of its own.  The band's lower rows see a stale row below them
 // and go wrong from the other side, one row per subcycle -- after K subcycles its rows above jhi - K are right.  They
-// replace the sweep's.  Per sweep: 2 + 2K small launches beside one large one.
+// replace the sweep's.  Per sweep: 2 + 2K small launches beside one large one -- BESIDE in time as well: the sweep goes to
+// a second stream (a parallel branch of the captured graph), the band's launches stay on the main one and find room on the
+// CUs the sweep leaves part-empty (737 workgroups on 768 places at 0.1 degree); only the last copy waits for the sweep.
+// CICE4_AMD_SKEW_FOLD_BESIDE=0: one after the other on one stream (round 3's form), for A/B.
 __global__ __launch_bounds__(256) void k_band_rows(double* __restrict__ dst, double* __restrict__ dst2,
                                                    const double* __restrict__ src, size_t n, size_t off, size_t len) {
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // 14 planes x len cells starting at `off` in each
@@ -3544,6 +3547,9 @@ void Evp::ensure_band(int K) {
     CICE_HIP(hipStreamSynchronize(stream));
     band_k = K;
   }
+  if (!stream2) CICE_HIP(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));   // (outside any capture)
+  if (!ev_fork) CICE_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+  if (!ev_join) CICE_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
 }
 
 void Evp::launch_subcycle_skew_fold(int ksub, int K) {
@@ -3557,9 +3563,19 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
     hipLaunchKernelGGL(k_band_rows, dim3((unsigned)((14 * len + 255) / 256)), dim3(256), 0, stream, band[0].p, band[1].p,
                        (const double*)st[cur].p, n, off, len);
   }
-  // 2. the sweep, as on an open north boundary (no halo update after it: the band brings the top rows)
-  launch_subcycle_skew(ksub, K, /*flip_and_halo=*/false);
+  // 2. the sweep, as on an open north boundary (no halo update after it: the band brings the top rows); it reads the
+  //    same copy of the state as step 1 and writes the other one, which the band does not touch before step 4
+  static const bool beside = [] { const char* e = std::getenv("CICE4_AMD_SKEW_FOLD_BESIDE"); return !(e && e[0] == '0'); }();
+  if (beside) {
+    CICE_HIP(hipEventRecord(ev_fork, stream));
+    CICE_HIP(hipStreamWaitEvent(stream2, ev_fork, 0));
+    launch_subcycle_skew(ksub, K, /*flip_and_halo=*/false, stream2);
+    CICE_HIP(hipEventRecord(ev_join, stream2));
+  } else {
+    launch_subcycle_skew(ksub, K, /*flip_and_halo=*/false);
+  }
   // 3. the band, one subcycle at a time
+  bool joined = false;
   for (int s = 0; s < K; ++s) {
     SubArgs a = make_args();
     double* in = band[s & 1].p;
@@ -3574,6 +3590,9 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
     const int nt = a.tiles_x * a.tiles_y;
     const dim3 g(8 * ((nt + 7) / 8));
     const bool last = (ksub + s == sc.ndte), damp = sc.evp_damping != 0;
+    // the last subcycle of evp(dt) also writes the diagnostics (strain rates, stress divergence ...): the sweep writes
+    // them for every row, the band for its rows above jm -- the band's have to land second
+    if (beside && last) { CICE_HIP(hipStreamWaitEvent(stream, ev_join, 0)); joined = true; }
     switch (waves * 100 + rows_per_wave) {
       case 801: launch_wr<8, 1>(a, last, damp, g, stream); break;
       case 802: launch_wr<8, 2>(a, last, damp, g, stream); break;
@@ -3589,6 +3608,7 @@ void Evp::launch_subcycle_skew_fold(int ksub, int K) {
     halo.update_r8(out, 2, n, /*wrap=*/false, LOC_NECORNER, KIND_VECTOR, 0.0, HALO_FOLD);   // the fold (:397-402)
   }
   // 4. rows jm .. jhi+1 of the band replace the sweep's
+  if (beside && !joined) CICE_HIP(hipStreamWaitEvent(stream, ev_join, 0));
   {
     const size_t off = (size_t)(jm - 1) * nx, len = (size_t)(bl.jhi + 1 - jm + 1) * nx;
     hipLaunchKernelGGL(k_band_rows, dim3((unsigned)((14 * len + 255) / 256)), dim3(256), 0, stream, st[1 - cur].p,
