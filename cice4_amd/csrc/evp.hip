@@ -929,6 +929,7 @@ struct SkewArgs {
   int stagger_ticks;       // start delay per workgroup "generation", in 10 ns ticks (see the kernel)
   int stagger_mod;         // generations
   int prio_rotate;         // rotate the issue priority among the workgroups sharing a CU (see the kernel)
+  int level_deal;          // how the time levels are dealt to the wavefronts of a workgroup (see the kernel)
   int fwd_rule;            // the on-rank ghost copies are exactly the east-west wrap of full-width blocks (Evp::init checked)
   long long* dbg;          // test aid: [2 * workgroups] start / end wall-clock ticks (10 ns), or NULL
   long long* stamps;       // -DCICE4_AMD_STAMPS (diagnostic build only): [4 * workgroups], see stamp_at
@@ -1019,7 +1020,9 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
   // sub-strip, so the S wavefronts of a level land on different SIMDs too
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int sub = S == 1 ? 0 : wv % S;
-  const int k = ((S == 1 ? wv : wv / S) + tile_lin) % K;
+  // generation of this workgroup: workgroups are dispatched in blockIdx order, one per CU first
+  const int gen = (int)(blockIdx.x / (gridDim.x / (unsigned)sa.stagger_mod + 1u));
+  const int k = ((S == 1 ? wv : wv / S) + tile_lin + sa.level_deal * gen) % K;
   const int cw = sub * 62 + lx;          // this lane's column of the workgroup
   const int nx = a.nx;
   const unsigned n8 = (unsigned)(a.n * 8);                  // bytes between two planes
@@ -1132,8 +1135,6 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
     while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(2);
   }
   if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x] = wall_clock64();
-  // generation of this workgroup: workgroups are dispatched in blockIdx order, one per CU first
-  const int gen = (int)(blockIdx.x / (gridDim.x / (unsigned)sa.stagger_mod + 1u));
   stamp_at(sa.stamps, 0);
   PHASE_DECL
 #pragma clang loop unroll(disable)
@@ -1476,6 +1477,8 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
   }
   stamp_at(sa.stamps, 1);
 #ifdef CICE4_AMD_STAMPS
+  ph_[6] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
+  ph_[7] = (long long)__builtin_amdgcn_s_getreg(4 | (31 << 11));    // HW_ID: where this wavefront ran (scripts/sweep_placement.py)
   if (sa.phases && lx == 0)
     for (int i_ = 0; i_ < 8; ++i_) sa.phases[8 * ((size_t)blockIdx.x * K + k) + i_] = ph_[i_];
 #endif
@@ -3296,6 +3299,10 @@ void Evp::skew_args(SkewArgs& sa, int K) {
   sa.a.tiles_x = skew_strips(K, &sa.own_shift);
   sa.a.tiles_y = ((dom.ny_block - 2) + sa.seg_rows - 1) / sa.seg_rows;
   sa.prio_rotate = skew_prio;
+  {
+    static const int deal = [] { const char* e = std::getenv("CICE4_AMD_SKEW_DEAL"); return e ? std::atoi(e) : 0; }();
+    sa.level_deal = deal;
+  }
   sa.rows = nullptr;
   sa.fwd_rule = fwd_is_ew_wrap ? 1 : 0;
   sa.dbg = nullptr;
