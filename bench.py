@@ -95,6 +95,9 @@ def parse():
     p.add_argument("--skew-levels", type=int, default=0, help="K of k_subcycle_skew (2, 3, 4, 5, 6, 8); 0 = library's choice")
     p.add_argument("--skew-seg-rows", type=int, default=0, help="rows a workgroup of k_subcycle_skew owns; 0 = auto")
     p.add_argument("--skew-gen-pct", type=int, default=-1, help="longer row segments for the workgroups dispatched first; -1 = library's choice")
+    p.add_argument("--skew-balance", type=int, default=-1, help="segments of the sweep follow the measured cost of their rows (0 / 1); -1 = library's choice")
+    p.add_argument("--cover", choices=("full", "patchy", "caps"), default="full",
+                   help="ice cover of the synthetic state on one GPU (diagnostic; the headline metric is quoted on full cover)")
     p.add_argument("--skew-prio", type=int, default=-1, help="rotate issue priorities among workgroups of a CU; -1 = library's choice")
     p.add_argument("--skew-stagger-ns", type=int, default=-1, help="start delay between workgroups sharing a CU; -1 = library's choice")
     p.add_argument("--skew-split-probe", type=int, default=0,
@@ -468,10 +471,11 @@ def build_case(ctx, wl, rank, world, overlap=-1, slabs=0, peer_loop=False, north
     # uniform 30 km rectangular grid (ice_grid.F90:976); under a fold no land rows close the domain: ocean and ice up to it
     gg = synth.global_grid(nxg, nyg, land_rows=0) if ns else synth.global_grid(nxg, nyg)
     grid = synth.block_fields(gg, dom, north_ocean=bool(ns))
-    state = synth.evp_state(grid, dom, cover="full")
+    state = synth.evp_state(grid, dom, cover=COVER)
     return dom, grid, state, ndte
 
 
+COVER = "full"          # --cover: the ice cover of the synthetic state ("caps": what a global grid looks like, diagnostic)
 THERMO_COHERENCE = 24   # cells; see synth.thermo_columns(coherent=...)
 
 
@@ -788,6 +792,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         ctx.evp_set_option("skew_seg_rows", args.skew_seg_rows)
     if args.skew_gen_pct >= 0:
         ctx.evp_set_option("skew_gen_pct", args.skew_gen_pct)
+    if args.skew_balance >= 0:
+        ctx.evp_set_option("skew_balance", args.skew_balance)
     if args.skew_prio >= 0:
         ctx.evp_set_option("skew_prio", args.skew_prio)
     if args.skew_stagger_ns >= 0:
@@ -1025,7 +1031,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
                 roofline["clock_ghz"] = ghz
                 roofline["clock_source"] = src
                 roofline["frac_valu_issue_at_measured_clock"] = roofline["frac_valu_issue"] * 2.4 / ghz
-    config = {"workload": workload(wl)[3], "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
+    config = {"workload": workload(wl)[3] if COVER == "full" else workload(wl)[3].replace("full ice cover", f"ice cover '{COVER}' (diagnostic)"),
+              "nx_global": dom["nxg"], "ny_global": dom["nyg"], "ndte": ndte,
               "subcycles_per_step": ndte,
               "decomposition": (f"1x{world} classic j-slabs, cross-rank one-launch loop (device-initiated exchange through the "
                                 f"neighbours' IPC-mapped exchange copies)" if peer_loop and resident else
@@ -1099,6 +1106,10 @@ def measure_thermo(ctx, args, wl, dom, world, dist, torch, steps):
 
 def main():
     args = parse()
+    global COVER
+    COVER = args.cover
+    if args.cover != "full":         # diagnostic cover: no CPU leg, no drop-in timing (they are quoted on full cover)
+        args.no_cpu_baseline = args.no_dropin_timing = args.no_peer_try = True
     if args.cpu_baseline_worker:
         cpu_baseline_worker(args)
         return

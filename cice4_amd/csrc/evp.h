@@ -56,6 +56,12 @@ class Evp {
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
   bool can_split() const;    // ... and the sweep in front of a wide-halo refresh as edge + interior launches
+  bool skew_rows_on() const { return (skew_gen_pct > 0 || skew_fill_on() || balance_on()) && skew_seg_opt == 0; }   // segments of unequal length (build_skew_rows)
+  bool skew_fill_on() const;
+  int skew_fill_pct() const;
+  bool rowact_on() const;    // workgroups of the sweep shrink to the rows that hold ice
+  bool balance_on() const;   // the sweep's segments follow the measured cost of their rows (one block per rank)
+  long long balanced_sweeps() const { return bal_sweeps; }
   bool can_trim() const;     // sweeps on wide-halo slabs over tile lists (extension rows trimmed)
   bool pairs_ok() const;     // the sweep's pair layout of the state applies to this domain
   bool can_skew_fold() const;  // the same on a one-block tripole grid: sweeps + a band of top rows per subcycle
@@ -93,10 +99,24 @@ class Evp {
   bool skew_on = true;       // K subcycles per sweep where the domain allows and the grid is large enough
   int skew_blocks_opt = 0;
   bool fwd_is_ew_wrap = false;   // the on-rank ghost list is the east-west wrap of full-width blocks and nothing else
-  int skew_gen_pct = 0;          // see build_skew_rows
+  int skew_gen_pct = 15;         // see build_skew_rows
+  int skew_fill = 26;            // see build_skew_rows: longer segments for workgroups on CUs that hold fewer of them
   DevBuf<int32_t> skew_rows;
-  int skew_rows_key[5] = {0, 0, 0, 0, 0};
+  int skew_rows_key[6] = {0, 0, 0, 0, 0, 0};
   void build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_rows);
+  // segments balanced by MEASURED cost (balance_after_sweep): host copy of the table, the static weight of every tile's
+  // place on the chip, sweeps still to be measured in this tuning phase, loops since the last one
+  std::vector<int32_t> rows_host;
+  std::vector<double> rows_w;
+  int skew_balance = 1, bal_left = 0, bal_every = 96, bal_since = 0, bal_tiles_x = 0, bal_tiles_y = 0;
+  long long bal_sweeps = 0;       // sweeps measured so far (cice_evp_get_info "skew_balanced")
+  void balance_after_sweep(hipStream_t s);
+  DevBuf<unsigned char> rowact;   // k_skew_rowact
+  DevBuf<int32_t> run_next, run_end;   // k_skew_runs
+  int rowact_strips = 0, rowact_k = 0;
+  std::vector<unsigned char> rowact_host;   // (balance_after_sweep)
+  bool rowact_host_stale = true;
+  bool rowact_opt = true;
   int skew_prio = 1;             // rotate the issue priority among the workgroups sharing a CU
   bool skew_debug = false;
   DevBuf<long long> skew_dbg;

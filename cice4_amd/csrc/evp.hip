@@ -946,6 +946,11 @@ struct SkewArgs {
   // to jlo; this launch covers tile_count entries from tile_first on.  NULL: every tile of the (strip x segment) grid.
   const int32_t* tiles;
   int tile_first, tile_count;
+  // [block][strip][row - jlo] != 0: the strip has something to compute in that row (k_skew_rowact), or NULL: a workgroup
+  // shrinks its segment to its first .. last such row and leaves at once if there is none
+  const unsigned char* rowact;
+  const int32_t* run_next;   // [block][strip][row - jlo]: k_skew_runs
+  const int32_t* run_end;
 };
 
 namespace {
@@ -1086,14 +1091,43 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
   const bool has_ilo = __any(at_ilo), has_G = __any(isG);   // most strips hold neither end of the ring
   // rows: this workgroup owns U-rows ja..jb (and T-rows ja..jb, the last segment T-row jhi+1 as well); every level
   // walks T-rows jt0..jt1, level k two rows behind level k-1
-  int ja = jlo + tyi * sa.seg_rows, jb = min(ja + sa.seg_rows - 1, jhi);
+  int ja0 = jlo + tyi * sa.seg_rows, jb0 = min(ja0 + sa.seg_rows - 1, jhi);
   if (sa.tiles) {
-    ja = jlo + ja_rel;
-    jb = jlo + jb_rel;
+    ja0 = jlo + ja_rel;
+    jb0 = jlo + jb_rel;
   } else if (sa.rows) {   // segments of unequal length (Evp::build_skew_rows): per tile of a block
-    ja = jlo + sa.rows[2 * rem];
-    jb = jlo + sa.rows[2 * rem + 1];
+    ja0 = jlo + sa.rows[2 * rem];
+    jb0 = jlo + sa.rows[2 * rem + 1];
   }
+  // Of its segment ja0 .. jb0 a workgroup walks the RUNS of rows that hold anything to compute (k_skew_rowact / k_skew_runs;
+  // gaps of up to 3K rows are bridged: a new run costs the pipeline's fill and drain and its cone of redundant rows), each
+  // as a sweep of its own.  Every wavefront finds the same runs (uniform), so all leave a run -- and the kernel -- together.
+  // Nothing is lost: a cell without ice is never written (both copies of the state hold the same value there).
+  const bool ra = S == 1 && sa.rowact != nullptr;
+  const size_t ro = ((size_t)b * a.tiles_x + txi) * (size_t)(a.ny - 2);
+  const int32_t* const rnext = sa.run_next + ro - jlo;
+  const int32_t* const rend = sa.run_end + ro - jlo;
+  // The workgroups a CU holds are copies of one program started at the same moment: left alone they stay IN PHASE --
+  // all compute together (sharing the SIMDs), then all wait together (barrier, LDS, memory) -- and the waiting of one
+  // hides behind nothing.  Workgroups are dealt to the CUs of an XCD in turn, so consecutive ones (blockIdx / 8) that
+  // share a CU are stagger_mod apart in that count: each starts a fraction of a step later than the one before.
+  if (sa.stagger_ticks > 0) {
+    const long long wait = (long long)((blockIdx.x >> 3) % (unsigned)sa.stagger_mod) * sa.stagger_ticks;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(2);
+  }
+  if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x] = wall_clock64();
+  stamp_at(sa.stamps, 0);
+  PHASE_DECL
+  for (int cursor = ja0; cursor <= jb0;) {
+  int ja = cursor, jb = jb0;
+  if (ra) {
+    const int f = rnext[cursor];               // relative to jlo; uniform addresses: scalar loads
+    if (f < 0 || jlo + f > jb0) break;         // nothing left in this segment
+    ja = jlo + f;
+    jb = min(jlo + rend[ja], jb0);
+  }
+  cursor = jb + 1;
   const int jt0 = max(jlo, ja - (K - 1)), jt1 = min(jhi + 1, jb + K);
   const bool lastlev = k == K - 1;
 #if SKEW_TRIM
@@ -1125,18 +1159,6 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
 #pragma unroll
   for (int c = 0; c < 12; ++c) s[c] = c0;
 
-  // The workgroups a CU holds are copies of one program started at the same moment: left alone they stay IN PHASE --
-  // all compute together (sharing the SIMDs), then all wait together (barrier, LDS, memory) -- and the waiting of one
-  // hides behind nothing.  Workgroups are dealt to the CUs of an XCD in turn, so consecutive ones (blockIdx / 8) that
-  // share a CU are stagger_mod apart in that count: each starts a fraction of a step later than the one before.
-  if (sa.stagger_ticks > 0) {
-    const long long wait = (long long)((blockIdx.x >> 3) % (unsigned)sa.stagger_mod) * sa.stagger_ticks;
-    const long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < wait) __builtin_amdgcn_s_sleep(2);
-  }
-  if (sa.dbg && threadIdx.x == 0) sa.dbg[2 * blockIdx.x] = wall_clock64();
-  stamp_at(sa.stamps, 0);
-  PHASE_DECL
 #pragma clang loop unroll(disable)
   for (int t = -1; t < nsteps; ++t) {
     // The SIMD issues from its OLDEST ready wavefront first: of the workgroups sharing a CU the first one dispatched
@@ -1475,6 +1497,8 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
     __syncthreads();
     PHASE(3)         // 3: barrier
   }
+  if (!ra) break;
+  }   // runs
   stamp_at(sa.stamps, 1);
 #ifdef CICE4_AMD_STAMPS
   ph_[6] = (long long)__builtin_amdgcn_s_getreg(20 | (31 << 11));   // XCC_ID
@@ -2376,6 +2400,60 @@ __global__ __launch_bounds__(256) void k_skew_pack(size_t n, const double* __res
   }
   msk[q] = (tmk[q] == 1 ? 1 : 0) | (umk[q] != 0 ? 2 : 0);
 }
+// Which rows of a column strip of the sweep kernel hold anything to compute (SkewArgs::rowact): one wavefront per (block,
+// strip, row), its lanes laid over the columns exactly as the sweep kernel lays them; a row counts if one of the strip's
+// OWN columns has ice on the T-cell of that row or of the row above (whose stress the row's momentum equation reads), or
+// an active U-cell.  Cells without ice are never written by any subcycle kernel (both copies of the state start out
+// identical: Evp::prepare), so rows outside a workgroup's first .. last such row need no workgroup at all.
+__global__ __launch_bounds__(256) void k_skew_rowact(int K, int strips, int own_shift, int nx, int ny, int ew_cyclic,
+                                                     const int32_t* __restrict__ blk, const int32_t* __restrict__ msk,
+                                                     unsigned char* __restrict__ act) {
+  const int lx = threadIdx.x & 63, rows = ny - 2;
+  const int rr = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6);     // row relative to jlo
+  const int txi = blockIdx.y, b = blockIdx.z;
+  if (rr >= rows) return;
+  const int ilo = blk[6 * b + 0], ihi = blk[6 * b + 1], jlo = blk[6 * b + 2], jhi = blk[6 * b + 3];
+  const int r = jlo + rr;
+  bool f = false;
+  if (r <= jhi) {
+    const int OWNW = 64 - 2 * K, ncol = ihi - ilo + 1;
+    const int own0 = txi == 0 ? K + 1 + own_shift : K;
+    const int kraw = (txi == 0 ? 0 : (OWNW - 1 - own_shift) + (txi - 1) * OWNW) + lx - own0;
+    const bool own_col = lx >= own0 && lx <= 63 - K && kraw >= 0 && kraw <= ncol;
+    if (own_col) {
+      const int col = ilo + kraw;                                   // (<= ihi + 1: the ghost column's T-cell is computed too)
+      const size_t q = (size_t)b * nx * ny + (size_t)(r - 1) * nx + (size_t)(col - 1);
+      const int m0 = msk[q], m1 = msk[q + nx];
+      f = m0 != 0 || (m1 & 1) != 0;
+    }
+    (void)ew_cyclic;
+  }
+  const unsigned long long any = __ballot(f);
+  if (lx == 0) act[((size_t)b * strips + txi) * rows + rr] = any ? 1 : 0;
+}
+// ... and the RUNS of such rows (gaps of up to `gap` rows bridged), so that a workgroup finds its next run with two loads:
+// nxt[row] = the first row >= row that holds anything (or -1), rend[row] = the last row of the run an active row belongs to.
+// One thread per (block, strip), top row down.
+__global__ __launch_bounds__(64) void k_skew_runs(int nstrips, int rows, int gap, const unsigned char* __restrict__ act,
+                                                  int32_t* __restrict__ nxt, int32_t* __restrict__ rend) {
+  const int sidx = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (sidx >= nstrips) return;
+  const unsigned char* a = act + (size_t)sidx * rows;
+  int32_t* nx_ = nxt + (size_t)sidx * rows;
+  int32_t* re_ = rend + (size_t)sidx * rows;
+  int above = -1, above_end = -1;   // the nearest active row above the current one, and where its run ends
+  for (int r = rows - 1; r >= 0; --r) {
+    if (a[r]) {
+      const int e = (above >= 0 && above - r - 1 <= gap) ? above_end : r;
+      re_[r] = e;
+      above = r;
+      above_end = e;
+    } else {
+      re_[r] = -1;
+    }
+    nx_[r] = above;
+  }
+}
 // plane layout (14 planes of n doubles: u, v, 12 stresses) <-> the sweep's pair layout (7 planes of n pairs)
 __global__ __launch_bounds__(256) void k_to_pairs(size_t n, const double* __restrict__ in, double* __restrict__ out,
                                                   double* __restrict__ out2) {
@@ -2517,6 +2595,18 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "skew_gen_pct")) {   // segments of the workgroup dispatched first on a CU this much longer
     CICE_REQUIRE(value >= 0 && value <= 60, "skew_gen_pct must be 0 .. 60");
     skew_gen_pct = value;
+  } else if (!std::strcmp(key, "skew_rowact")) {    // workgroups of the sweep shrink to the rows that hold ice (k_skew_rowact)
+    rowact_opt = value != 0;
+    skew_packed = false;
+  } else if (!std::strcmp(key, "skew_balance")) {   // segments of the sweep follow the measured cost of their rows (balance_after_sweep)
+    skew_balance = value != 0;
+    skew_rows_key[0] = -1;                          // a new table: the static one, measured again if this is on
+  } else if (!std::strcmp(key, "skew_balance_every")) {   // loops between two tuning phases
+    CICE_REQUIRE(value >= 1, "skew_balance_every must be >= 1");
+    bal_every = value;
+  } else if (!std::strcmp(key, "skew_fill")) {      // longer segments for workgroups on CUs that hold fewer of them (build_skew_rows)
+    CICE_REQUIRE(value >= 0 && value <= 100, "skew_fill must be 0 .. 100 (per cent)");
+    skew_fill = value;
   } else if (!std::strcmp(key, "skew_debug")) {  // record start / end ticks of every workgroup of the sweep kernel
     skew_debug = value != 0;
   } else if (!std::strcmp(key, "stamps")) {      // diagnostic build (-DCICE4_AMD_STAMPS): cycle / wall-clock stamps per workgroup
@@ -2801,12 +2891,44 @@ void Evp::skew_pack() {
   }
   hipLaunchKernelGGL(k_skew_pack, grid1(n), dim3(256), 0, stream, n, (const double*)uarena.p, (const int32_t*)icetmask.p,
                      (const int32_t*)iceumask.p, uar4.p, skew_msk.p);
+  // rows with anything to compute, per column strip (this step's masks)
+  rowact_strips = 0;
+  if (rowact_on()) {
+    const int K = skew_levels(), rows = dom.ny_block - 2;
+    int shift = 0;
+    const int strips = skew_strips(K, &shift);
+    const size_t want = (size_t)dom.nblocks() * strips * rows;
+    if (rowact.n < want) rowact.alloc(want);
+    hipLaunchKernelGGL(k_skew_rowact, dim3((unsigned)((rows + 3) / 4), (unsigned)strips, (unsigned)dom.nblocks()), dim3(256), 0,
+                       stream, K, strips, shift, dom.nx_block, dom.ny_block, 0, (const int32_t*)blk.p,
+                       (const int32_t*)skew_msk.p, rowact.p);
+    if (run_next.n < want) { run_next.alloc(want); run_end.alloc(want); }
+    const int ns = dom.nblocks() * strips;
+    hipLaunchKernelGGL(k_skew_runs, dim3((unsigned)((ns + 63) / 64)), dim3(64), 0, stream, ns, rows, 3 * K,
+                       (const unsigned char*)rowact.p, run_next.p, run_end.p);
+    rowact_strips = strips;
+    rowact_k = K;
+    rowact_host_stale = true;
+  }
   skew_packed = true;
+}
+
+// Workgroups of the sweep shrink to the rows that hold ice (SkewArgs::rowact).  Not with three wavefronts per level (its
+// strips are laid out differently).  Option "skew_rowact" / CICE4_AMD_SKEW_ROWACT=0|1.
+bool Evp::rowact_on() const {
+  static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_ROWACT"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  if (!(env >= 0 ? env == 1 : rowact_opt)) return false;
+  return skew_subs(skew_levels()) == 1;
 }
 
 // test aid: start / end wall-clock ticks (10 ns) of the workgroups of the last k_subcycle_skew launch
 long long Evp::debug_read(const char* what, long long* out, long long cap) {
   const bool stamps = !std::strcmp(what, "stamps");
+  if (!std::strcmp(what, "skew_rows")) {   // the sweep's segment table as it stands: [tiles of a block][2] first / last U-row, relative to jlo
+    const long long nn = (long long)rows_host.size();
+    for (long long i = 0; out && i < std::min(nn, cap); ++i) out[i] = rows_host[(size_t)i];
+    return nn;
+  }
   CICE_REQUIRE(stamps || !std::strcmp(what, "skew_times"), "unknown debug array");
   CICE_HIP(hipStreamSynchronize(stream));
   DevBuf<long long>& b = stamps ? stamp_buf : skew_dbg;
@@ -3180,13 +3302,28 @@ int Evp::skew_seg_rows(int K) const {
   return (int)((rows + nseg - 1) / nseg);
 }
 
-// Rows per workgroup when the workgroups of a launch are not treated alike: the SIMD issues from its oldest wavefront
-// first, so of the workgroups sharing a CU the one dispatched first finishes first and the last one late.  Workgroups
-// are dispatched in blockIdx order, one per CU before any CU gets its second; blockIdx -> tile is the XCD remap of the
-// kernel.  The "generation" g of a tile (0: first on its CU) gets a segment of weight 1 + (1 - g) * pct / 100 (two
-// generations: +- pct / 2 ...), normalised per column strip so that the strip's segments still cover its rows exactly.
+// Rows per workgroup when the workgroups of a launch are not treated alike.  Workgroups are dispatched in blockIdx
+// order: blockIdx & 7 is the XCD, and within an XCD the m-th workgroup goes to CU m mod 32 -- a CU holds workgroups m,
+// m + 32, m + 64 of its XCD (measured: scripts/sweep_placement.py finds the triples b, b + 256, b + 512 on one CU);
+// blockIdx -> tile is the XCD remap of the kernel.
+// (1) skew_gen_pct: the SIMD issues from its oldest wavefront first, so of the workgroups sharing a CU the one dispatched
+//     first finishes first: the "generation" g of a tile (0: first on its CU) gets weight 1 + (1 - g) * pct / 100.
+// (2) skew_fill: a launch rarely has exactly as many workgroups as the chip has places -- 0.1 degree: 65 strips x 11
+//     segments = 715 on 768, twelve segments would need 780 -- so some CUs hold one workgroup less than the others, and
+//     their workgroups take shorter steps: T(n) ~ 2.0 + 1.1 n us for n workgroups on a CU.  A
+//     workgroup gets rows in proportion to 1 / T(n of its CU): 26 % more on a CU that holds two instead of three.
+// Both are normalised per column strip, so that the strip's segments still cover its rows exactly; any partition gives
+// the same bits.
+static constexpr int BAL_FIRST = 32, BAL_AGAIN = 8;   // sweeps measured after a new table / in a later tuning phase (balance_after_sweep)
+
+int Evp::skew_fill_pct() const {   // option "skew_fill" / CICE4_AMD_SKEW_FILL: per cent more rows on a CU one workgroup short (0: off)
+  static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_FILL"); return e ? std::atoi(e) : -1; }();
+  return std::max(0, std::min(100, env >= 0 ? env : skew_fill));
+}
+bool Evp::skew_fill_on() const { return skew_fill_pct() > 0; }
+
 void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_rows) {
-  const int key[5] = {K, tiles_x, tiles_y, skew_gen_pct, seg_rows};
+  const int key[6] = {K, tiles_x, tiles_y, skew_gen_pct, seg_rows, skew_fill_pct()};
   if (skew_rows.n && !std::memcmp(key, skew_rows_key, sizeof(key))) return;
   int ncu = 256, dev = 0;
   if (hipGetDevice(&dev) == hipSuccess) {
@@ -3195,16 +3332,31 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
   }
   const int per_blk = tiles_x * tiles_y, nt = per_blk * nblocks, chunk = (nt + 7) >> 3, per_xcd = std::max(1, ncu / 8);
   const int rows = dom.ny_block - 2, gens = std::max(1, skew_blocks(K));
+  const bool fill = skew_fill_on() && nblocks == 1;
   std::vector<int32_t> tab((size_t)2 * per_blk);
+  rows_w.assign((size_t)per_blk, 1.0);
   // one table for all blocks (they have the same shape): generation from the tile's place in block 0's dispatch order
   for (int tx = 0; tx < tiles_x; ++tx) {
     std::vector<double> w(tiles_y);
     double sum = 0;
     for (int ty = 0; ty < tiles_y; ++ty) {
       const int tile_lin = ty * tiles_x + tx;
-      const int g = std::min(gens - 1, (tile_lin % chunk) / per_xcd);
+      const int m = tile_lin % chunk;
+      const int g = std::min(gens - 1, m / per_xcd);
       w[ty] = 1.0 + (0.5 * (gens - 1) - g) * skew_gen_pct / 100.0;
+      if (fill) {
+        const int cnt = std::min(chunk, nt - (tile_lin / chunk) * chunk);    // workgroups of this tile's XCD that do anything
+        int on_cu = 0;
+        for (int q = m % per_xcd; q < cnt; q += per_xcd) ++on_cu;
+        on_cu = std::min(on_cu, gens);                                       // (a second round: as if full)
+        // (the workgroups of a CU that is not full run alike whatever their order: measured, scripts/sweep_placement.py)
+        if (on_cu < gens) w[ty] = 1.0;
+        // T(n) ~ a + b n with the ratio a / b that makes T(gens) / T(gens - 1) = 1 + pct / 100 (26 % <-> 2.0 + 1.1 n at gens = 3)
+        const double f = skew_fill_pct() / 100.0, ab = 1.0 / f - (gens - 1);   // a / b
+        w[ty] *= (ab + gens) / (ab + on_cu);
+      }
       sum += w[ty];
+      rows_w[(size_t)tile_lin] = w[ty];
     }
     double acc = 0;
     int prev = 0;
@@ -3221,6 +3373,112 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
   skew_rows.upload(tab.data(), stream);
   CICE_HIP(hipStreamSynchronize(stream));
   std::memcpy(skew_rows_key, key, sizeof(key));
+  rows_host = tab;
+  bal_tiles_x = tiles_x;
+  bal_tiles_y = tiles_y;
+  bal_left = balance_on() && nblocks == 1 ? BAL_FIRST : 0;   // a new table: measure it
+  bal_since = 0;
+}
+
+// ---- segments by MEASURED cost ---------------------------------------------------------------------------------------
+// The static table above knows the chip; it does not know the rows.  A T-cell without ice costs a wavefront a few
+// instructions, one with ice ~600: on a global grid most rows of a strip are open water and the strip's time is the time of
+// its most ice-covered segment; and even on a fully covered grid the workgroups of a launch differ by more than the static
+// weights say (seam strips, XCDs, the order on the CU: profiles/r04_sweep_wg_times.txt).  So the sweep kernel's start / end
+// ticks per workgroup (SkewArgs::dbg, two clock reads per workgroup) are read back after a sweep and the strip's
+// boundaries move: the cost of a row is taken as uniform within its old segment (duration x static weight / rows), the
+// strip's total is dealt to its tiles in proportion to their static weights, the boundaries go half-way to where the
+// running sum says (damping: a measurement has ~1.5 % of noise).  Any partition gives the same bits (the sweep tests run
+// many), so this is tuning, not arithmetic.  When: the sweeps of the first loop after the table was built (eager, no
+// graph, one synchronisation per sweep), and one loop in every `bal_every` after that (the ice edge moves).  One block
+// per rank, the plain and the tripole-fold sweep (the lists of a wide-halo slab are not balanced).
+// Option "skew_balance" / CICE4_AMD_SKEW_BALANCE=0|1.
+bool Evp::balance_on() const {
+  static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_BALANCE"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
+  return (env >= 0 ? env == 1 : skew_balance != 0) && dom.nblocks() == 1;
+}
+
+void Evp::balance_after_sweep(hipStream_t s) {
+  const int tx_n = bal_tiles_x, ty_n = bal_tiles_y, nt = tx_n * ty_n, chunk = (nt + 7) >> 3;
+  const size_t g = 8 * (size_t)((nt + 7) / 8);
+  CICE_HIP(hipStreamSynchronize(s));
+  std::vector<long long> t(2 * g);
+  CICE_HIP(hipMemcpy(t.data(), skew_dbg.p, t.size() * 8, hipMemcpyDeviceToHost));
+  const int rows = dom.ny_block - 2;
+  const int minrows = rows >= 2 * ty_n ? 2 : (rows >= ty_n ? 1 : 0);
+  bool changed = false;
+  std::vector<double> d(ty_n), w(ty_n), x(ty_n), cost((size_t)std::max(rows, 1));
+  std::vector<int> e(ty_n), ne(ty_n);
+  // the rows that hold ice, per strip (this step's masks: fetched once per loop that is measured)
+  const bool have_act = rowact_on() && rowact_strips == tx_n && rowact.n >= (size_t)tx_n * rows;
+  if (have_act && rowact_host_stale) {
+    rowact_host.resize((size_t)tx_n * rows);
+    CICE_HIP(hipMemcpy(rowact_host.data(), rowact.p, rowact_host.size(), hipMemcpyDeviceToHost));
+    rowact_host_stale = false;
+  }
+  for (int tx = 0; tx < tx_n; ++tx) {
+    bool ok = true;
+    double omega = 0, wsum = 0;
+    for (int ty = 0; ty < ty_n; ++ty) {
+      const int tile = ty * tx_n + tx;
+      const size_t b = ((size_t)(tile % chunk) << 3) | (size_t)(tile / chunk);      // the kernel's XCD remap, inverted
+      d[ty] = (double)(t[2 * b + 1] - t[2 * b]);
+      w[ty] = rows_w.size() == (size_t)nt ? rows_w[tile] : 1.0;
+      e[ty] = rows_host[2 * (size_t)tile + 1] + 1;                                   // exclusive end (empty: = first)
+      if (!(d[ty] >= 0) || d[ty] > 1e9) ok = false;                                  // (0: a workgroup with no row that holds ice)
+      omega += d[ty] * w[ty];
+      wsum += w[ty];
+    }
+    if (!ok || !(omega > 0)) continue;
+    // where the running sum of the cost reaches each tile's share; a segment's cost lies on its rows that hold ice
+    // (k_skew_rowact; on all of them where the table is not in use)
+    const unsigned char* act = have_act ? rowact_host.data() + (size_t)tx * rows : nullptr;
+    {
+      int lo = 0;
+      for (int ty = 0; ty < ty_n; ++ty) {
+        int nact = 0;
+        for (int r = lo; r < e[ty]; ++r) nact += act ? (act[r] != 0) : 1;
+        const double per_row = nact ? d[ty] * w[ty] / nact : 0.0;
+        for (int r = lo; r < e[ty]; ++r) cost[r] = (act ? act[r] != 0 : true) ? per_row : 0.0;
+        if (!nact) omega -= d[ty] * w[ty];        // (a segment of open water: what it took is not the rows' cost)
+        lo = e[ty];
+      }
+    }
+    if (!(omega > 0)) continue;
+    {
+      double acc = 0, cum = 0;
+      int r = 0;
+      for (int ty = 0; ty < ty_n - 1; ++ty) {
+        acc += w[ty];
+        const double want = omega * acc / wsum;
+        while (r < rows && cum + cost[r] < want) cum += cost[r++];
+        x[ty] = r < rows && cost[r] > 0 ? r + (want - cum) / cost[r] : r;
+      }
+    }
+    int prev = 0;
+    for (int ty = 0; ty < ty_n; ++ty) {
+      int end = ty == ty_n - 1 ? rows : (int)std::lround(e[ty] + 0.5 * (x[ty] - e[ty]));
+      end = std::max(end, std::min(rows, prev + minrows));
+      end = std::min(end, rows - minrows * (ty_n - 1 - ty));
+      end = std::max(end, prev);
+      ne[ty] = end;
+      prev = end;
+    }
+    prev = 0;
+    for (int ty = 0; ty < ty_n; ++ty) {
+      const size_t tile = (size_t)ty * tx_n + tx;
+      if (rows_host[2 * tile] != prev || rows_host[2 * tile + 1] != ne[ty] - 1) changed = true;
+      rows_host[2 * tile] = prev;
+      rows_host[2 * tile + 1] = ne[ty] - 1;
+      prev = ne[ty];
+    }
+  }
+  if (changed) {
+    skew_rows.upload(rows_host.data(), s);
+    CICE_HIP(hipStreamSynchronize(s));          // (the host vector changes again after the next sweep)
+  }
+  ++bal_sweeps;
+  if (bal_left > 0) --bal_left;
 }
 
 template <bool PAIRS>
@@ -3318,6 +3576,9 @@ void Evp::skew_args(SkewArgs& sa, int K) {
   sa.msk = skew_msk.p;
   sa.tiles = nullptr;
   sa.tile_first = sa.tile_count = 0;
+  sa.rowact = rowact_on() && rowact_strips == sa.a.tiles_x && rowact_k == K ? rowact.p : nullptr;
+  sa.run_next = run_next.p;
+  sa.run_end = run_end.p;
 }
 
 void Evp::skew_launch(const SkewArgs& sa0, int K, bool last, int nt, hipStream_t s) {
@@ -3343,7 +3604,7 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo, hipStream_t 
   ++loop_launches;
   SkewArgs sa{};
   skew_args(sa, K);
-  if (skew_gen_pct > 0 && skew_seg_opt == 0) {   // (built by subcycles() before any capture: it uploads a table)
+  if (skew_rows_on()) {   // (built by subcycles() before any capture: it uploads a table)
     build_skew_rows(K, sa.a.tiles_x, sa.a.tiles_y, sa.a.nblocks, sa.seg_rows);
     sa.rows = skew_rows.p;
   }
@@ -3358,7 +3619,10 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo, hipStream_t 
     sa.stamps = stamp_buffer((1 + 2 * (size_t)K) * g);      // [4 g] stamps, then [8 K g] phase sums per level
     sa.phases = sa.stamps ? sa.stamps + 4 * g : nullptr;
   }
+  const bool measure = bal_left > 0 && !in_capture && sa.rows && balance_on() && skew_dbg.n >= 2 * (size_t)(8 * ((nt + 7) / 8));
+  if (measure) sa.dbg = skew_dbg.p;
   skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, on ? on : stream);
+  if (measure) balance_after_sweep(on ? on : stream);
   if (in_pairs && ksub + K - 1 == sc.ndte) in_pairs = false;   // the last sweep of evp(dt) stores planes
   if (flip_and_halo) after_subcycle(ksub + K - 1);
 }
@@ -4403,17 +4667,30 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   // would hang instead of raising an error.  Opt in with cice_evp_set_option("comm_graph", 1) or
   // CICE4_AMD_COMM_GRAPH=1 once a multi-GPU parity run has passed.
   static const bool env_comm_graph = std::getenv("CICE4_AMD_COMM_GRAPH") != nullptr;
-  const bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
+  bool graph_ok = use_graph && nsub > 1 && (!halo.multi_rank() || comm_graph || env_comm_graph);
   if (!can_skew() && can_skew_fold()) ensure_band(skew_levels());
-  if ((can_skew() || can_skew_fold()) && skew_gen_pct > 0 && skew_seg_opt == 0) {   // the segment table of the sweep kernel, outside any capture
+  bool tuning = false;
+  if ((can_skew() || can_skew_fold()) && skew_rows_on()) {   // the segment table of the sweep kernel, outside any capture
     const int K = skew_levels(), seg = skew_seg_rows(K);
-    build_skew_rows(K, skew_strips(K, nullptr), ((dom.ny_block - 2) + seg - 1) / seg, dom.nblocks(), seg);
+    const int tiles_x = skew_strips(K, nullptr), tiles_y = ((dom.ny_block - 2) + seg - 1) / seg;
+    build_skew_rows(K, tiles_x, tiles_y, dom.nblocks(), seg);
+    if (balance_on() && !(can_skew() && can_trim()) && nsub >= K && !(nsub >= 2 && (can_reside() || can_reside_peer()))) {
+      // this loop's sweeps are measured (eagerly: no graph) while a tuning phase lasts; a new phase every bal_every loops
+      if (bal_left == 0 && ++bal_since >= bal_every) {
+        bal_left = BAL_AGAIN;
+        bal_since = 0;
+      }
+      const size_t want = 2 * (size_t)(8 * ((tiles_x * tiles_y * dom.nblocks() + 7) / 8));
+      if (bal_left > 0 && skew_dbg.n < want) skew_dbg.alloc(want);
+      tuning = bal_left > 0;
+    }
   }
   if (pairs_ok())
     for (int k = 0; k < 2; ++k)
       if (st2[k].n < 14 * n) st2[k].alloc(14 * n);
   if ((can_skew() || can_skew_fold()) && !skew_packed) skew_pack();   // (sweeps switched on after prepare(): allocations outside any capture)
   if (can_skew() && can_trim()) build_split(skew_levels());   // (uploads tables: outside any capture)
+  if (tuning) graph_ok = false;
   bool replayed = false;
   loop_launches = 0;
   if (nsub >= 2 && (can_reside() || can_reside_peer())) {

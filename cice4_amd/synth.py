@@ -159,7 +159,8 @@ def block_fields(gg, dom, ew_cyclic=True, north_ocean=False, ns_cyclic=False):
 # ----------------------------------------------------------------------------
 def evp_state(grid, dom, seed=20261003, cover="full", moving=True, ice_mask=None):
     """Module-array-shaped inputs of evp(dt) (ice_dyn_evp.F90:119) for the blocks in dom.
-    cover: 'full' (ice on every ocean cell), 'patchy' (ice-free regions, thin-ice edges).
+    cover: 'full' (ice on every ocean cell), 'patchy' (ice-free regions, thin-ice edges), 'caps' (two polar caps with a
+    wavy edge, ~25 % of the rows: what a global grid looks like to the dynamics -- most rows are open water).
     ice_mask: optional boolean (nblocks, ny, nx): ice only there (e.g. the polar caps of a real grid)."""
     rng = np.random.default_rng(seed)
     nb, ny, nx = dom["nblocks"], dom["ny"], dom["nx"]
@@ -183,6 +184,10 @@ def evp_state(grid, dom, seed=20261003, cover="full", moving=True, ice_mask=None
     if cover == "patchy":
         hole = field(1, 0.0, 1.0)
         conc = np.where(hole < 0.35, 0.0, conc * np.clip((hole - 0.35) / 0.15, 0.0, 1.0))
+    if cover == "caps":
+        lat = (gj + 0.5) / nyg + 0.02 * np.sin(2 * np.pi * 5 * gi / nxg) + 0.01 * np.cos(2 * np.pi * 13 * gi / nxg)
+        edge = np.minimum(np.clip((0.10 - lat) / 0.02, 0.0, 1.0) + np.clip((lat - 0.84) / 0.02, 0.0, 1.0), 1.0)
+        conc = conc * edge
     conc = np.where(tm, conc, 0.0)
     if ice_mask is not None:
         conc = np.where(ice_mask, conc, 0.0)

@@ -246,7 +246,10 @@ int cice_evp_peer_connect_ipc(cice_ctx *ctx, int side, const char handles[3][64]
  * (10 ns) of every workgroup of the last K-subcycle sweep launch; "stamps" (after cice_evp_set_option("stamps", 1), in a
  * DIAGNOSTIC build of the library compiled -DCICE4_AMD_STAMPS only -- the product build's kernels hold no stamp and the
  * array comes back zero): per workgroup of the last one-launch loop / sweep {cycles before, cycles after, 100 MHz ticks
- * before, ticks after} its loop (s_memtime / s_memrealtime: the in-kernel clock, scripts/inkernel_clock.py).
+ * before, ticks after} its loop (s_memtime / s_memrealtime: the in-kernel clock, scripts/inkernel_clock.py); "skew_rows":
+ * the sweep's segment table as it stands ([segments][strips][2]: first / last U-row of a workgroup relative to the block's
+ * first row) -- the library re-cuts it from measured workgroup times (option "skew_balance", on by default on one-block
+ * domains; cice_evp_get_info "skew_balance" / "skew_balanced" = sweeps measured so far).
  * *count: in = capacity of out (out may be NULL), out = entries available. */
 int cice_evp_debug(cice_ctx *ctx, const char *what, long long *out, long long *count);
 

@@ -1,0 +1,33 @@
+"""How the sweep's segment table evolves under the measured-cost balancing: usage: sweep_balance_trace.py [cover] [nxg nyg]"""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: F401
+torch.cuda.is_available()
+from cice4_amd import lib, synth
+cover = sys.argv[1] if len(sys.argv) > 1 else "caps"
+nxg = int(sys.argv[2]) if len(sys.argv) > 2 else 3600
+nyg = int(sys.argv[3]) if len(sys.argv) > 3 else 2400
+K, ndte = 4, 240
+ctx = lib.Context(device=0)
+dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+grid = synth.block_fields(synth.global_grid(nxg, nyg), dom)
+state = synth.evp_state(grid, dom, cover=cover)
+ctx.evp_init(grid, ndte=ndte)
+ctx.evp_set_option("skew_debug", 1)
+ctx.evp_upload(state); ctx.evp_prepare(3600.0)
+strips = ctx.evp_get_info("skew_strips")
+print("rowact", ctx.evp_get_info("skew_rowact"), "balance", ctx.evp_get_info("skew_balance"), "strips", strips, flush=True)
+for call in range(6):
+    ms = ctx.evp_subcycles(1, ndte, timed=True)
+    t = ctx.evp_debug("skew_rows").reshape(-1, strips, 2)
+    n = t[:, :, 1] - t[:, :, 0] + 1
+    tm = ctx.evp_debug("skew_times").reshape(-1, 2)
+    nt = n.size; chunk = (nt + 7) >> 3
+    tile = np.arange(nt); b = ((tile % chunk) << 3) | (tile // chunk)
+    d = ((tm[b, 1] - tm[b, 0]) * 0.01).reshape(-1, strips)
+    print(f"call {call}: {ms * 1e3 / ndte:.1f} us per subcycle; measured sweeps so far {ctx.evp_get_info('skew_balanced')}; "
+          f"last sweep: slowest workgroup {d.max():.0f} us, mean of the non-empty {d[d > 0].mean():.0f} us, {int((d > 0).sum())} of {nt} with rows to do")
+    for sx in (0, 7, strips - 1):
+        print(f"   strip {sx}: rows per segment {n[:, sx].tolist()}  last sweep us {np.round(d[:, sx]).astype(int).tolist()}", flush=True)

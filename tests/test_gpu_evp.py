@@ -1042,6 +1042,44 @@ def test_sweeps_on_a_tripole_grid(ctx, nxg, nyg, ns):
                 assert np.array_equal(sg[k], ref[k]), (ns, ndte, damping, K, graph, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
 
 
+@pytest.mark.parametrize("nxg,nyg,ns,cover", [(130, 400, 0, "caps"), (70, 260, 0, "patchy"), (96, 300, 3, "caps")])
+def test_sweep_segments_follow_the_measured_cost(ctx, nxg, nyg, ns, cover):
+    """The sweep's row segments are re-cut after every measured sweep of a tuning phase (Evp::balance_after_sweep: start / end
+    ticks per workgroup -> cost per row -> boundaries): the table stays a partition of every strip's rows, segments over
+    open water grow at the expense of those over ice, and the results are the bits of one launch per subcycle in the loop
+    that tunes (eager), in the graph replay after it and in a later tuning phase -- on a plain and on a tripole grid."""
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=nxg + nyg, land_rows=0 if ns else 1)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=bool(ns))
+    s = synth.evp_state(grid, dom, seed=nxg, cover=cover)
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    ndte, K = 24, 4
+    ref, _ = _evp_with(ctx, grid, s, ndte, False, resident=0, skew=0, skew_fold=0)
+    ctx.evp_init(grid, ndte=ndte, krdg_partic=0, krdg_redist=0)
+    for key, v in (("resident", 0), ("skew", 1), ("skew_fold", 1), ("skew_min_cells", 0), ("skew_levels", K), ("skew_balance", 1),
+                   ("skew_balance_every", 2)):
+        ctx.evp_set_option(key, v)
+    assert ctx.evp_get_info("skew_balance") == 1
+    tables = []
+    for call in range(5):      # 1: tunes (eager); 2: graph; 3: tunes again (every 2 loops); 4, 5: graph / tunes
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp(DT, sg)
+        for k in keys:
+            assert np.array_equal(sg[k], ref[k]), (call, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+        t = ctx.evp_debug("skew_rows").reshape(-1, 2)
+        strips = ctx.evp_get_info("skew_strips")
+        t = t.reshape(-1, strips, 2)
+        rows = nyg
+        for sx in range(strips):   # consecutive, complete
+            assert t[0, sx, 0] == 0 and t[-1, sx, 1] == rows - 1, (call, sx, t[:, sx].tolist())
+            assert np.all(t[1:, sx, 0] == t[:-1, sx, 1] + 1), (call, sx, t[:, sx].tolist())
+        tables.append(t.copy())
+    assert ctx.evp_get_info("skew_balanced") >= ndte // K, "the first loop's sweeps should have been measured"
+    if t.shape[0] >= 3:
+        n0 = tables[0][:, :, 1] - tables[0][:, :, 0] + 1
+        assert n0.max() - n0.min() >= 2, ("segments should have moved away from equal lengths", n0[:, 0].tolist())
+
+
 @pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
 def test_tripole_fold_inside_the_loop_against_the_compiled_reference(ns):
     """the same against `call evp(dt)` of the reference itself on a one-block 100 x 116 domain (own process)"""
