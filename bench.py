@@ -807,6 +807,9 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         subs = ctx.evp_get_info("skew_subs")
         tile = (f"{skew_k} subcycles per sweep; workgroup = {skew_k * subs} wavefronts ({subs} per time level, levels two rows "
                 f"apart) x 64 lanes, owns {62 * subs + 2 - 2 * skew_k} columns x {ctx.evp_get_info('skew_seg_rows')} rows")
+        if ctx.evp_get_info("skew_balance"):
+            tile += (" to begin with; it walks only the runs of rows that hold ice, and the segments are re-cut from the workgroups' "
+                     "measured times in the first loop (places the launch leaves empty go to the slowest strips)")
     if skew_k and dom.get("overlap") and dom["overlap"] % skew_k:
         progress(f"{wl}: {dom['overlap']} overlap rows are no multiple of K = {skew_k}: part of every refresh interval "
                  f"runs the pair kernel instead of sweeps (auto_overlap avoids this; --overlap was given)")

@@ -111,6 +111,14 @@ class Evp {
   int skew_balance = 1, bal_left = 0, bal_every = 96, bal_since = 0, bal_tiles_x = 0, bal_tiles_y = 0;
   long long bal_sweeps = 0;       // sweeps measured so far (cice_evp_get_info "skew_balanced")
   void balance_after_sweep(hipStream_t s);
+  struct BalTile { int strip, first, last; };       // rows relative to jlo; last < first: empty
+  std::vector<BalTile> bal_tiles;                   // by place in the launch (SkewArgs::tiles)
+  std::vector<double> bal_w;                        // static weight of the place
+  DevBuf<int32_t> bal_list;
+  int bal_nt = 0, bal_strips = 0, bal_slots = 0, bal_gens = 1, bal_per_xcd = 32, bal_seen = 0, bal_k = 4;
+  bool bal_recounted = false;
+  void bal_upload(hipStream_t s);
+  double place_weight(int tile_lin, int nt, int gens, int per_xcd, bool fill) const;
   DevBuf<unsigned char> rowact;   // k_skew_rowact
   DevBuf<int32_t> run_next, run_end;   // k_skew_runs
   int rowact_strips = 0, rowact_k = 0;

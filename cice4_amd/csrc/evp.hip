@@ -2924,9 +2924,18 @@ bool Evp::rowact_on() const {
 // test aid: start / end wall-clock ticks (10 ns) of the workgroups of the last k_subcycle_skew launch
 long long Evp::debug_read(const char* what, long long* out, long long cap) {
   const bool stamps = !std::strcmp(what, "stamps");
-  if (!std::strcmp(what, "skew_rows")) {   // the sweep's segment table as it stands: [tiles of a block][2] first / last U-row, relative to jlo
-    const long long nn = (long long)rows_host.size();
-    for (long long i = 0; out && i < std::min(nn, cap); ++i) out[i] = rows_host[(size_t)i];
+  if (!std::strcmp(what, "skew_rows")) {   // the sweep's segments as they stand: [tiles][3] strip, first / last U-row relative to jlo
+    if (bal_nt > 0) {
+      const long long nn = 3LL * bal_nt;
+      for (long long i = 0; out && i < std::min(nn, cap); ++i) {
+        const BalTile& bt = bal_tiles[(size_t)(i / 3)];
+        out[i] = i % 3 == 0 ? bt.strip : (i % 3 == 1 ? bt.first : bt.last);
+      }
+      return nn;
+    }
+    const long long nt = (long long)rows_host.size() / 2, nn = 3 * nt, sx = std::max(1, bal_tiles_x);
+    for (long long i = 0; out && i < std::min(nn, cap); ++i)
+      out[i] = i % 3 == 0 ? (i / 3) % sx : rows_host[(size_t)(2 * (i / 3) + (i % 3 - 1))];
     return nn;
   }
   CICE_REQUIRE(stamps || !std::strcmp(what, "skew_times"), "unknown debug array");
@@ -3314,13 +3323,32 @@ int Evp::skew_seg_rows(int K) const {
 //     workgroup gets rows in proportion to 1 / T(n of its CU): 26 % more on a CU that holds two instead of three.
 // Both are normalised per column strip, so that the strip's segments still cover its rows exactly; any partition gives
 // the same bits.
-static constexpr int BAL_FIRST = 32, BAL_AGAIN = 8;   // sweeps measured after a new table / in a later tuning phase (balance_after_sweep)
+static constexpr int BAL_FIRST = 36, BAL_AGAIN = 8, BAL_RECOUNT = 6;   // sweeps measured after a new table / in a later tuning phase (balance_after_sweep)
 
 int Evp::skew_fill_pct() const {   // option "skew_fill" / CICE4_AMD_SKEW_FILL: per cent more rows on a CU one workgroup short (0: off)
   static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_FILL"); return e ? std::atoi(e) : -1; }();
   return std::max(0, std::min(100, env >= 0 ? env : skew_fill));
 }
 bool Evp::skew_fill_on() const { return skew_fill_pct() > 0; }
+
+// static weight (relative speed) of the workgroup that takes place `tile_lin` of a launch of nt workgroups: see build_skew_rows
+double Evp::place_weight(int tile_lin, int nt, int gens, int per_xcd, bool fill) const {
+  const int chunk = (nt + 7) >> 3, m = tile_lin % chunk;
+  const int g = std::min(gens - 1, m / per_xcd);
+  double w = 1.0 + (0.5 * (gens - 1) - g) * skew_gen_pct / 100.0;
+  if (fill) {
+    const int cnt = std::min(chunk, nt - (tile_lin / chunk) * chunk);    // workgroups of this tile's XCD that do anything
+    int on_cu = 0;
+    for (int q = m % per_xcd; q < cnt; q += per_xcd) ++on_cu;
+    on_cu = std::min(on_cu, gens);                                       // (a second round: as if full)
+    // (the workgroups of a CU that is not full run alike whatever their order: measured, scripts/sweep_placement.py)
+    if (on_cu < gens) w = 1.0;
+    // T(n) ~ a + b n with the ratio a / b that makes T(gens) / T(gens - 1) = 1 + pct / 100 (26 % <-> 2.0 + 1.1 n at gens = 3)
+    const double f = skew_fill_pct() / 100.0, ab = 1.0 / f - (gens - 1);   // a / b
+    w *= (ab + gens) / (ab + on_cu);
+  }
+  return w;
+}
 
 void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_rows) {
   const int key[6] = {K, tiles_x, tiles_y, skew_gen_pct, seg_rows, skew_fill_pct()};
@@ -3330,7 +3358,7 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
     int v = 0;
     if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
   }
-  const int per_blk = tiles_x * tiles_y, nt = per_blk * nblocks, chunk = (nt + 7) >> 3, per_xcd = std::max(1, ncu / 8);
+  const int per_blk = tiles_x * tiles_y, nt = per_blk * nblocks, per_xcd = std::max(1, ncu / 8);
   const int rows = dom.ny_block - 2, gens = std::max(1, skew_blocks(K));
   const bool fill = skew_fill_on() && nblocks == 1;
   std::vector<int32_t> tab((size_t)2 * per_blk);
@@ -3341,20 +3369,7 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
     double sum = 0;
     for (int ty = 0; ty < tiles_y; ++ty) {
       const int tile_lin = ty * tiles_x + tx;
-      const int m = tile_lin % chunk;
-      const int g = std::min(gens - 1, m / per_xcd);
-      w[ty] = 1.0 + (0.5 * (gens - 1) - g) * skew_gen_pct / 100.0;
-      if (fill) {
-        const int cnt = std::min(chunk, nt - (tile_lin / chunk) * chunk);    // workgroups of this tile's XCD that do anything
-        int on_cu = 0;
-        for (int q = m % per_xcd; q < cnt; q += per_xcd) ++on_cu;
-        on_cu = std::min(on_cu, gens);                                       // (a second round: as if full)
-        // (the workgroups of a CU that is not full run alike whatever their order: measured, scripts/sweep_placement.py)
-        if (on_cu < gens) w[ty] = 1.0;
-        // T(n) ~ a + b n with the ratio a / b that makes T(gens) / T(gens - 1) = 1 + pct / 100 (26 % <-> 2.0 + 1.1 n at gens = 3)
-        const double f = skew_fill_pct() / 100.0, ab = 1.0 / f - (gens - 1);   // a / b
-        w[ty] *= (ab + gens) / (ab + on_cu);
-      }
+      w[ty] = place_weight(tile_lin, nt, gens, per_xcd, fill);
       sum += w[ty];
       rows_w[(size_t)tile_lin] = w[ty];
     }
@@ -3376,8 +3391,44 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
   rows_host = tab;
   bal_tiles_x = tiles_x;
   bal_tiles_y = tiles_y;
-  bal_left = balance_on() && nblocks == 1 ? BAL_FIRST : 0;   // a new table: measure it
+  // the same as a LIST of tiles (SkewArgs::tiles), which is what the measured balancing works on: a strip may then hold
+  // more tiles than another
+  bal_tiles.clear();
+  bal_nt = 0;
+  if (balance_on() && nblocks == 1) {
+    bal_strips = tiles_x;
+    bal_slots = std::max(per_blk, ncu * gens);
+    bal_gens = gens;
+    bal_k = K;
+    bal_per_xcd = per_xcd;
+    for (int ty = 0; ty < tiles_y; ++ty)
+      for (int tx = 0; tx < tiles_x; ++tx)
+        bal_tiles.push_back({tx, tab[2 * (size_t)(ty * tiles_x + tx)], tab[2 * (size_t)(ty * tiles_x + tx) + 1]});
+    bal_list.alloc((size_t)4 * bal_slots);
+    bal_upload(stream);
+    bal_left = BAL_FIRST;      // a new table: measure it
+    bal_recounted = false;
+    bal_seen = 0;
+  } else {
+    bal_left = 0;
+  }
   bal_since = 0;
+}
+
+void Evp::bal_upload(hipStream_t s) {
+  bal_nt = (int)bal_tiles.size();
+  std::vector<int32_t> h((size_t)4 * bal_nt);
+  for (int p = 0; p < bal_nt; ++p) {
+    h[4 * (size_t)p] = 0;
+    h[4 * (size_t)p + 1] = bal_tiles[p].strip;
+    h[4 * (size_t)p + 2] = bal_tiles[p].first;
+    h[4 * (size_t)p + 3] = bal_tiles[p].last;
+  }
+  CICE_HIP(hipMemcpyAsync(bal_list.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, s));
+  CICE_HIP(hipStreamSynchronize(s));
+  const bool fill = skew_fill_on();
+  bal_w.resize((size_t)bal_nt);
+  for (int p = 0; p < bal_nt; ++p) bal_w[p] = place_weight(p, bal_nt, bal_gens, bal_per_xcd, fill);
 }
 
 // ---- segments by MEASURED cost ---------------------------------------------------------------------------------------
@@ -3399,84 +3450,147 @@ bool Evp::balance_on() const {
 }
 
 void Evp::balance_after_sweep(hipStream_t s) {
-  const int tx_n = bal_tiles_x, ty_n = bal_tiles_y, nt = tx_n * ty_n, chunk = (nt + 7) >> 3;
+  const int nt = bal_nt, chunk = (nt + 7) >> 3, ns = bal_strips;
   const size_t g = 8 * (size_t)((nt + 7) / 8);
   CICE_HIP(hipStreamSynchronize(s));
   std::vector<long long> t(2 * g);
   CICE_HIP(hipMemcpy(t.data(), skew_dbg.p, t.size() * 8, hipMemcpyDeviceToHost));
   const int rows = dom.ny_block - 2;
-  const int minrows = rows >= 2 * ty_n ? 2 : (rows >= ty_n ? 1 : 0);
-  bool changed = false;
-  std::vector<double> d(ty_n), w(ty_n), x(ty_n), cost((size_t)std::max(rows, 1));
-  std::vector<int> e(ty_n), ne(ty_n);
   // the rows that hold ice, per strip (this step's masks: fetched once per loop that is measured)
-  const bool have_act = rowact_on() && rowact_strips == tx_n && rowact.n >= (size_t)tx_n * rows;
+  const bool have_act = rowact_on() && rowact_strips == ns && rowact.n >= (size_t)ns * rows;
   if (have_act && rowact_host_stale) {
-    rowact_host.resize((size_t)tx_n * rows);
+    rowact_host.resize((size_t)ns * rows);
     CICE_HIP(hipMemcpy(rowact_host.data(), rowact.p, rowact_host.size(), hipMemcpyDeviceToHost));
     rowact_host_stale = false;
   }
-  for (int tx = 0; tx < tx_n; ++tx) {
+  // the tiles of every strip, bottom to top
+  std::vector<std::vector<int>> of(ns);
+  for (int p = 0; p < nt; ++p) of[bal_tiles[p].strip].push_back(p);
+  for (auto& v : of) std::sort(v.begin(), v.end(), [&](int a, int b) { return bal_tiles[a].first < bal_tiles[b].first; });
+  ++bal_seen;
+  // Once per table, after a few measured sweeps: the places the launch leaves empty (715 tiles on 768 at 0.1 degree) go, one
+  // by one, to the strip whose tiles take longest -- the two strips at the seam of the ring do 11 % more per row, and a strip
+  // under more ice than another more still.  Greedy on (strip's cost) / (its tiles) minimises the maximum.
+  const bool recount = !bal_recounted && bal_seen >= BAL_RECOUNT && nt < bal_slots;
+  std::vector<int> want_cnt(ns);
+  std::vector<double> strip_cost(ns, 0.0);
+  std::vector<double> cost((size_t)std::max(rows, 1));
+  std::vector<std::vector<double>> rowcost(recount ? ns : 0);
+  bool changed = false;
+  auto duration = [&](int p) {
+    const size_t b = ((size_t)(p % chunk) << 3) | (size_t)(p / chunk);      // the kernel's XCD remap, inverted
+    return (double)(t[2 * b + 1] - t[2 * b]);
+  };
+  for (int tx = 0; tx < ns; ++tx) {
+    const std::vector<int>& tl = of[tx];
+    const int ty_n = (int)tl.size();
+    want_cnt[tx] = ty_n;
+    if (!ty_n) continue;
+    const int minrows = rows >= 2 * ty_n ? 2 : (rows >= ty_n ? 1 : 0);
     bool ok = true;
     double omega = 0, wsum = 0;
-    for (int ty = 0; ty < ty_n; ++ty) {
-      const int tile = ty * tx_n + tx;
-      const size_t b = ((size_t)(tile % chunk) << 3) | (size_t)(tile / chunk);      // the kernel's XCD remap, inverted
-      d[ty] = (double)(t[2 * b + 1] - t[2 * b]);
-      w[ty] = rows_w.size() == (size_t)nt ? rows_w[tile] : 1.0;
-      e[ty] = rows_host[2 * (size_t)tile + 1] + 1;                                   // exclusive end (empty: = first)
-      if (!(d[ty] >= 0) || d[ty] > 1e9) ok = false;                                  // (0: a workgroup with no row that holds ice)
-      omega += d[ty] * w[ty];
-      wsum += w[ty];
+    std::vector<double> d(ty_n), w(ty_n), x(ty_n);
+    std::vector<int> e(ty_n), ne(ty_n);
+    for (int i = 0; i < ty_n; ++i) {
+      d[i] = duration(tl[i]);
+      w[i] = bal_w[tl[i]];
+      e[i] = bal_tiles[tl[i]].last + 1;                 // exclusive end (an empty tile: = its first row)
+      if (!(d[i] >= 0) || d[i] > 1e9) ok = false;       // (0: a workgroup with no row that holds ice)
+      omega += d[i] * w[i];
+      wsum += w[i];
     }
     if (!ok || !(omega > 0)) continue;
-    // where the running sum of the cost reaches each tile's share; a segment's cost lies on its rows that hold ice
-    // (k_skew_rowact; on all of them where the table is not in use)
+    // a segment's cost lies on its rows that hold ice (k_skew_rowact; on all of them where that table is not in use)
     const unsigned char* act = have_act ? rowact_host.data() + (size_t)tx * rows : nullptr;
     {
       int lo = 0;
-      for (int ty = 0; ty < ty_n; ++ty) {
+      for (int i = 0; i < ty_n; ++i) {
         int nact = 0;
-        for (int r = lo; r < e[ty]; ++r) nact += act ? (act[r] != 0) : 1;
-        const double per_row = nact ? d[ty] * w[ty] / nact : 0.0;
-        for (int r = lo; r < e[ty]; ++r) cost[r] = (act ? act[r] != 0 : true) ? per_row : 0.0;
-        if (!nact) omega -= d[ty] * w[ty];        // (a segment of open water: what it took is not the rows' cost)
-        lo = e[ty];
+        for (int r = lo; r < e[i]; ++r) nact += act ? (act[r] != 0) : 1;
+        const double per_row = nact ? d[i] * w[i] / nact : 0.0;
+        for (int r = lo; r < e[i]; ++r) cost[r] = (act ? act[r] != 0 : true) ? per_row : 0.0;
+        if (!nact) omega -= d[i] * w[i];        // (a segment of open water: what it took is not the rows' cost)
+        lo = e[i];
       }
     }
     if (!(omega > 0)) continue;
+    strip_cost[tx] = omega;
+    if (recount) {
+      rowcost[tx].assign(cost.begin(), cost.begin() + rows);
+      continue;                                 // (the table is re-cut below, with the new numbers of tiles)
+    }
+    // where the running sum of the cost reaches each tile's share; every boundary goes half-way there
     {
       double acc = 0, cum = 0;
       int r = 0;
-      for (int ty = 0; ty < ty_n - 1; ++ty) {
-        acc += w[ty];
+      for (int i = 0; i < ty_n - 1; ++i) {
+        acc += w[i];
         const double want = omega * acc / wsum;
         while (r < rows && cum + cost[r] < want) cum += cost[r++];
-        x[ty] = r < rows && cost[r] > 0 ? r + (want - cum) / cost[r] : r;
+        x[i] = r < rows && cost[r] > 0 ? r + (want - cum) / cost[r] : r;
       }
     }
     int prev = 0;
-    for (int ty = 0; ty < ty_n; ++ty) {
-      int end = ty == ty_n - 1 ? rows : (int)std::lround(e[ty] + 0.5 * (x[ty] - e[ty]));
+    for (int i = 0; i < ty_n; ++i) {
+      int end = i == ty_n - 1 ? rows : (int)std::lround(e[i] + 0.5 * (x[i] - e[i]));
       end = std::max(end, std::min(rows, prev + minrows));
-      end = std::min(end, rows - minrows * (ty_n - 1 - ty));
+      end = std::min(end, rows - minrows * (ty_n - 1 - i));
       end = std::max(end, prev);
-      ne[ty] = end;
+      ne[i] = end;
       prev = end;
     }
     prev = 0;
-    for (int ty = 0; ty < ty_n; ++ty) {
-      const size_t tile = (size_t)ty * tx_n + tx;
-      if (rows_host[2 * tile] != prev || rows_host[2 * tile + 1] != ne[ty] - 1) changed = true;
-      rows_host[2 * tile] = prev;
-      rows_host[2 * tile + 1] = ne[ty] - 1;
-      prev = ne[ty];
+    for (int i = 0; i < ty_n; ++i) {
+      BalTile& bt = bal_tiles[tl[i]];
+      if (bt.first != prev || bt.last != ne[i] - 1) changed = true;
+      bt.first = prev;
+      bt.last = ne[i] - 1;
+      prev = ne[i];
     }
   }
-  if (changed) {
-    skew_rows.upload(rows_host.data(), s);
-    CICE_HIP(hipStreamSynchronize(s));          // (the host vector changes again after the next sweep)
+  if (recount) {
+    bal_recounted = true;
+    int spare = bal_slots - nt;
+    for (; spare > 0; --spare) {
+      int best = -1;
+      double worst = 0;
+      for (int tx = 0; tx < ns; ++tx)
+        if (strip_cost[tx] > 0 && want_cnt[tx] < std::max((int)of[tx].size(), rows / (4 * bal_k)) &&   // (segments not shorter than 4K rows: skew_seg_rows)
+            strip_cost[tx] / want_cnt[tx] > worst) {
+          worst = strip_cost[tx] / want_cnt[tx];
+          best = tx;
+        }
+      if (best < 0) break;
+      ++want_cnt[best];
+    }
+    for (int tx = 0; tx < ns; ++tx) {
+      const int have = (int)of[tx].size(), n = want_cnt[tx];
+      if (n == have || rowcost[tx].empty()) continue;
+      // the strip's rows dealt to n tiles of equal cost (new tiles take the places at the end of the list: weight as found)
+      std::vector<int> tl = of[tx];
+      for (int i = have; i < n; ++i) {
+        tl.push_back((int)bal_tiles.size());
+        bal_tiles.push_back({tx, 0, -1});
+      }
+      const std::vector<double>& rc = rowcost[tx];
+      double total = 0;
+      for (double v : rc) total += v;
+      double cum = 0;
+      int r = 0, prev = 0;
+      for (int i = 0; i < n; ++i) {
+        const double want = total * (i + 1) / n;
+        while (r < rows && cum + rc[r] <= want) cum += rc[r++];
+        int end = i == n - 1 ? rows : std::max(r, std::min(rows, prev + 1));
+        end = std::min(end, rows - (n - 1 - i));
+        end = std::max(end, prev);
+        bal_tiles[tl[i]].first = prev;
+        bal_tiles[tl[i]].last = end - 1;
+        prev = end;
+      }
+      changed = true;
+    }
   }
+  if (changed) bal_upload(s);
   ++bal_sweeps;
   if (bal_left > 0) --bal_left;
 }
@@ -3608,7 +3722,14 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo, hipStream_t 
     build_skew_rows(K, sa.a.tiles_x, sa.a.tiles_y, sa.a.nblocks, sa.seg_rows);
     sa.rows = skew_rows.p;
   }
-  const int nt = sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks;
+  int nt = sa.a.tiles_x * sa.a.tiles_y * sa.a.nblocks;
+  const bool listed = sa.rows && balance_on() && bal_nt > 0 && bal_strips == sa.a.tiles_x;
+  if (listed) {             // the measured table: a list of tiles (a strip may hold more of them than another)
+    sa.rows = nullptr;
+    sa.tiles = bal_list.p;
+    sa.tile_first = 0;
+    sa.tile_count = nt = bal_nt;
+  }
   if (skew_debug) {
     const size_t want = 2 * (size_t)(8 * ((nt + 7) / 8));
     if (skew_dbg.n < want) skew_dbg.alloc(want);
@@ -3619,7 +3740,7 @@ void Evp::launch_subcycle_skew(int ksub, int K, bool flip_and_halo, hipStream_t 
     sa.stamps = stamp_buffer((1 + 2 * (size_t)K) * g);      // [4 g] stamps, then [8 K g] phase sums per level
     sa.phases = sa.stamps ? sa.stamps + 4 * g : nullptr;
   }
-  const bool measure = bal_left > 0 && !in_capture && sa.rows && balance_on() && skew_dbg.n >= 2 * (size_t)(8 * ((nt + 7) / 8));
+  const bool measure = bal_left > 0 && !in_capture && listed && skew_dbg.n >= 2 * (size_t)(8 * ((nt + 7) / 8));
   if (measure) sa.dbg = skew_dbg.p;
   skew_launch(sa, K, ksub + K - 1 == sc.ndte, nt, on ? on : stream);
   if (measure) balance_after_sweep(on ? on : stream);
@@ -4680,7 +4801,7 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
         bal_left = BAL_AGAIN;
         bal_since = 0;
       }
-      const size_t want = 2 * (size_t)(8 * ((tiles_x * tiles_y * dom.nblocks() + 7) / 8));
+      const size_t want = 2 * (size_t)(8 * ((std::max(tiles_x * tiles_y * dom.nblocks(), bal_slots) + 7) / 8));
       if (bal_left > 0 && skew_dbg.n < want) skew_dbg.alloc(want);
       tuning = bal_left > 0;
     }

@@ -21,13 +21,20 @@ strips = ctx.evp_get_info("skew_strips")
 print("rowact", ctx.evp_get_info("skew_rowact"), "balance", ctx.evp_get_info("skew_balance"), "strips", strips, flush=True)
 for call in range(6):
     ms = ctx.evp_subcycles(1, ndte, timed=True)
-    t = ctx.evp_debug("skew_rows").reshape(-1, strips, 2)
-    n = t[:, :, 1] - t[:, :, 0] + 1
+    t = ctx.evp_debug("skew_rows").reshape(-1, 3)        # per tile (place in the launch): strip, first / last row
     tm = ctx.evp_debug("skew_times").reshape(-1, 2)
-    nt = n.size; chunk = (nt + 7) >> 3
-    tile = np.arange(nt); b = ((tile % chunk) << 3) | (tile // chunk)
-    d = ((tm[b, 1] - tm[b, 0]) * 0.01).reshape(-1, strips)
-    print(f"call {call}: {ms * 1e3 / ndte:.1f} us per subcycle; measured sweeps so far {ctx.evp_get_info('skew_balanced')}; "
-          f"last sweep: slowest workgroup {d.max():.0f} us, mean of the non-empty {d[d > 0].mean():.0f} us, {int((d > 0).sum())} of {nt} with rows to do")
+    nt = len(t); chunk = (nt + 7) >> 3
+    p = np.arange(nt); b = ((p % chunk) << 3) | (p // chunk)
+    d = (tm[b, 1] - tm[b, 0]) * 0.01
+    print(f"call {call}: {ms * 1e3 / ndte:.1f} us per subcycle; measured sweeps so far {ctx.evp_get_info('skew_balanced')}; {nt} tiles; "
+          f"last sweep: slowest workgroup {d.max():.0f} us, mean of the non-empty {d[d > 0].mean():.0f} us, {int((d > 0).sum())} with rows to do")
+    ms_ = np.array([d[t[:, 0] == sx].mean() for sx in range(strips)])
+    cnt = np.array([(t[:, 0] == sx).sum() for sx in range(strips)])
+    order = np.argsort(-ms_)
+    print("   strips by mean workgroup time (strip, us, tiles): slowest", [(int(i), int(round(ms_[i])), int(cnt[i])) for i in order[:5]],
+          "median", int(round(np.median(ms_))), "fastest", [(int(i), int(round(ms_[i])), int(cnt[i])) for i in order[-3:]],
+          "| tiles per strip:", dict(zip(*[x.tolist() for x in np.unique(cnt, return_counts=True)])), flush=True)
     for sx in (0, 7, strips - 1):
-        print(f"   strip {sx}: rows per segment {n[:, sx].tolist()}  last sweep us {np.round(d[:, sx]).astype(int).tolist()}", flush=True)
+        ts = np.where(t[:, 0] == sx)[0]
+        ts = ts[np.argsort(t[ts, 1], kind="stable")]
+        print(f"   strip {sx}: rows per segment {(t[ts, 2] - t[ts, 1] + 1).tolist()}  last sweep us {np.round(d[ts]).astype(int).tolist()}", flush=True)
