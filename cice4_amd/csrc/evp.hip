@@ -3558,6 +3558,16 @@ void Evp::balance_after_sweep(hipStream_t s) {
   if (recount) {
     bal_recounted = true;
     int spare = bal_slots - nt;
+    // (costs in steps of 4 % of the largest, ties to the lower strip: strips that cost about the same get their extra tile
+    //  as ONE run of neighbours -- tiles of neighbouring strips that cover the same rows at the same time share the columns
+    //  they overlap in through the L2; scattered, the launch reads 8 % more: profiles/r04_sweep_reads_by_table.txt)
+    {
+      double top = 0;
+      for (double v : strip_cost) top = std::max(top, v);
+      if (top > 0)
+        for (double& v : strip_cost)
+          if (v > 0) v = std::max(1.0, std::floor(v / (0.04 * top))) * (0.04 * top);
+    }
     for (; spare > 0; --spare) {
       int best = -1;
       double worst = 0;

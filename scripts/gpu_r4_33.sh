@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round 4, call 33: HBM reads of the sweep per launch: uniform segments / static weights / measured list of tiles (same box)
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out
+O=gpurun_out/r4_33
+rm -rf $O; mkdir -p $O
+B="--no-cpu-baseline --no-dropin-timing --no-thermo"
+: > gpurun_out/r4_33_reads.txt
+for v in "uniform 0 0 0" "static 26 -1 0" "measured 26 -1 1"; do
+  set -- $v
+  CICE4_AMD_SKEW_FILL=$2 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_$1 -- python bench.py --workload tenth --steps 1 --warmup 0 --ramp-seconds 0 $B --skew-gen-pct $( [ $1 = uniform ] && echo 0 || echo -1 ) --skew-balance $4 > $O/pmc_$1.log 2>&1 || echo "pmc $1 failed"
+  V=$1 python - <<'PY' | tee -a gpurun_out/r4_33_reads.txt
+import csv, glob, collections, os
+v = os.environ["V"]
+f = glob.glob(f"gpurun_out/r4_33/pmc_{v}/**/*counter_collection.csv", recursive=True)
+tot = [0, 0.0]
+for row in csv.DictReader(open(f[0])):
+    if "k_subcycle_skew<4, false" in row["Kernel_Name"] and row["Counter_Name"] == "FETCH_SIZE":
+        tot[0] += 1; tot[1] += float(row["Counter_Value"])
+print(v, tot[0], "launches, reads", round(tot[1] / tot[0] / 1024 * 2, 1), "MB per launch")
+PY
+  CICE4_AMD_SKEW_FILL=$2 timeout -k 10 300 python bench.py --no-thermo --workload tenth --skew-gen-pct $( [ $1 = uniform ] && echo 0 || echo -1 ) --skew-balance $4 > gpurun_out/r4_33.json 2> gpurun_out/r4_33.err || exit 1
+  python -c "
+import json
+d=json.load(open('gpurun_out/r4_33.json'))
+print('$1:', round(1e6/d['value'],1), 'us per subcycle')
+" | tee -a gpurun_out/r4_33_reads.txt
+done
+rm -rf $O

@@ -26,7 +26,7 @@ for call in range(6):
     nt = len(t); chunk = (nt + 7) >> 3
     p = np.arange(nt); b = ((p % chunk) << 3) | (p // chunk)
     d = (tm[b, 1] - tm[b, 0]) * 0.01
-    print(f"call {call}: {ms * 1e3 / ndte:.1f} us per subcycle; measured sweeps so far {ctx.evp_get_info('skew_balanced')}; {nt} tiles; "
+    print(f"call {call}: {ms * 1e3 / ndte:.1f} us per subcycle; measured sweeps so far {ctx.evp_get_info('skew_balanced')}; {int((t[:, 2] >= t[:, 1]).sum())} tiles on {nt} places; "
           f"last sweep: slowest workgroup {d.max():.0f} us, mean of the non-empty {d[d > 0].mean():.0f} us, {int((d > 0).sum())} with rows to do")
     ms_ = np.array([d[t[:, 0] == sx].mean() for sx in range(strips)])
     cnt = np.array([(t[:, 0] == sx).sum() for sx in range(strips)])
