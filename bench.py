@@ -112,6 +112,7 @@ def parse():
     p.add_argument("--no-tenth", action="store_true",
                    help="gx1 run: skip the short 0.1-degree (3600x2400, ndte=240) sub-record")
     p.add_argument("--tenth-steps", type=int, default=3)
+    p.add_argument("--no-caps", action="store_true", help="skip the 0.1-degree run under polar-cap ice cover (diagnostic part of the line)")
     p.add_argument("--thermo-coherence", type=int, default=THERMO_COHERENCE,
                    help="correlation length (cells) of the melting/cold, snow/bare, day/night regions of the synthetic "
                         "thermo columns; 0 = every column drawn independently (white noise)")
@@ -1291,6 +1292,19 @@ def main():
         if not args.no_thermo:
             tenth["thermo"] = measure_thermo(ctx, args, "tenth", t["dom"], world, dist, torch, 2)[0]
         del t
+        # the same grid under the ice cover a global model has -- two polar caps, most rows open water (diagnostic: the
+        # library walks only the rows that hold ice and re-cuts its segment table from measured workgroup times)
+        if world == 1 and COVER == "full" and not args.no_caps:
+            COVER = "caps"
+            try:
+                t = measure_evp(ctx, args, "tenth", rank, world, dist, torch, have_torch_gpu, args.tenth_steps, 1, 0.3, tune=False,
+                                min_timed_s=0.5, max_repeats=4)
+                tenth["polar_caps_cover"] = {"value": t["value"], "unit": "subcycles/s", "us_per_subcycle": 1e6 / t["value"],
+                                             "steps": t["steps"], "timing": t["timing"], "workload": t["config"]["workload"],
+                                             "note": "diagnostic, not the headline workload: ice on 25 % of the rows (synth.evp_state cover='caps')"}
+                del t
+            finally:
+                COVER = "full"
 
     if rank == 0:
         out = {
