@@ -1793,6 +1793,20 @@ int cice_debug_skew_layout(int K, int S, int ncol, int cyclic, int* strips) {
   return -1;
 }
 
+// test aid, no device needed: one strip's step of the measured balancing of the sweep's segments (cice::balance_strip)
+int cice_debug_balance_strip(int rows, int n, const int32_t* ends, const double* durations, const double* weights,
+                             const unsigned char* rows_with_ice, int32_t* new_ends, double* total) {
+  if (rows < 1 || n < 1 || !ends || !durations || !weights || !new_ends) return -2;
+  for (int i = 0; i < n; ++i)
+    if (ends[i] < (i ? ends[i - 1] : 0) || ends[i] > rows) return -2;
+  std::vector<double> cost((size_t)rows);
+  std::vector<int> e(ends, ends + n), ne((size_t)n);
+  const double t = cice::balance_strip(rows, n, e.data(), durations, weights, rows_with_ice, cost.data(), ne.data());
+  if (total) *total = t;
+  for (int i = 0; i < n; ++i) new_ends[i] = t > 0 ? ne[(size_t)i] : ends[i];
+  return 0;
+}
+
 int cice_transport_chain(cice_ctx* ctx, const cice_transport_fields* f) {
   CICE_TRY(ctx)
   c_->chain_ready = false;

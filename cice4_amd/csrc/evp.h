@@ -19,6 +19,10 @@ struct EvpScalars {  // set_evp_parameters, ice_dyn_evp.F90:535-577
   void set(double dt, int ndte_, int damping);
 };
 
+// (evp.hip) one strip's step of the measured balancing of the sweep's segments
+double balance_strip(int rows, int n, const int* e, const double* d, const double* w, const unsigned char* act, double* cost,
+                     int* ne);
+
 class Evp {
  public:
   Evp(const Domain& d, Halo& h, hipStream_t s, CopyFan& f) : dom(d), halo(h), stream(s), fan(f) {}

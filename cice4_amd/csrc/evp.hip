@@ -3456,6 +3456,50 @@ bool Evp::balance_on() const {
   return (env >= 0 ? env == 1 : skew_balance != 0) && dom.nblocks() == 1;
 }
 
+// One strip's step of the measured balancing, as a pure function (Evp::balance_after_sweep; cice_debug_balance_strip for the
+// CPU tests): n tiles with exclusive ends e[] (bottom to top), measured durations d[] and static weights w[] of their places,
+// act[rows] != 0 where a row holds ice (or NULL: every row counts).  cost[rows] <- what a row costs; returns the strip's
+// total (0: nothing to go by) and, if ne, the new ends: every boundary half-way to where the running sum of the cost reaches
+// the tiles' shares.
+double balance_strip(int rows, int n, const int* e, const double* d, const double* w, const unsigned char* act, double* cost,
+                     int* ne) {
+  double omega = 0, wsum = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!(d[i] >= 0) || d[i] > 1e9) return 0.0;          // (0 is fine: a workgroup with no row that holds ice)
+    wsum += w[i];
+  }
+  // a segment's cost lies on its rows that hold ice (a segment of open water: what it took is not the rows' cost)
+  {
+    int lo = 0;
+    for (int i = 0; i < n; ++i) {
+      int nact = 0;
+      for (int r = lo; r < e[i]; ++r) nact += act ? (act[r] != 0) : 1;
+      const double per_row = nact ? d[i] * w[i] / nact : 0.0;
+      for (int r = lo; r < e[i]; ++r) cost[r] = (act ? act[r] != 0 : true) ? per_row : 0.0;
+      if (nact) omega += d[i] * w[i];
+      lo = std::max(lo, e[i]);
+    }
+    for (int r = lo; r < rows; ++r) cost[r] = 0.0;
+  }
+  if (!(omega > 0) || !ne) return omega > 0 ? omega : 0.0;
+  const int minrows = rows >= 2 * n ? 2 : (rows >= n ? 1 : 0);
+  double acc = 0, cum = 0;
+  int r = 0, prev = 0;
+  for (int i = 0; i < n; ++i) {
+    acc += w[i];
+    const double want = omega * acc / wsum;
+    while (r < rows && cum + cost[r] < want) cum += cost[r++];
+    const double x = r < rows && cost[r] > 0 ? r + (want - cum) / cost[r] : r;
+    int end = i == n - 1 ? rows : (int)std::lround(e[i] + 0.5 * (x - e[i]));
+    end = std::max(end, std::min(rows, prev + minrows));
+    end = std::min(end, rows - minrows * (n - 1 - i));
+    end = std::max(end, prev);
+    ne[i] = end;
+    prev = end;
+  }
+  return omega;
+}
+
 void Evp::balance_after_sweep(hipStream_t s) {
   const int nt = bal_nt, chunk = (nt + 7) >> 3, ns = bal_strips;
   const size_t g = 8 * (size_t)((nt + 7) / 8);
@@ -3493,60 +3537,22 @@ void Evp::balance_after_sweep(hipStream_t s) {
     const int ty_n = (int)tl.size();
     want_cnt[tx] = ty_n;
     if (!ty_n) continue;
-    const int minrows = rows >= 2 * ty_n ? 2 : (rows >= ty_n ? 1 : 0);
-    bool ok = true;
-    double omega = 0, wsum = 0;
-    std::vector<double> d(ty_n), w(ty_n), x(ty_n);
+    std::vector<double> d(ty_n), w(ty_n);
     std::vector<int> e(ty_n), ne(ty_n);
     for (int i = 0; i < ty_n; ++i) {
       d[i] = duration(tl[i]);
       w[i] = bal_w[tl[i]];
       e[i] = bal_tiles[tl[i]].last + 1;                 // exclusive end (an empty tile: = its first row)
-      if (!(d[i] >= 0) || d[i] > 1e9) ok = false;       // (0: a workgroup with no row that holds ice)
-      omega += d[i] * w[i];
-      wsum += w[i];
     }
-    if (!ok || !(omega > 0)) continue;
-    // a segment's cost lies on its rows that hold ice (k_skew_rowact; on all of them where that table is not in use)
     const unsigned char* act = have_act ? rowact_host.data() + (size_t)tx * rows : nullptr;
-    {
-      int lo = 0;
-      for (int i = 0; i < ty_n; ++i) {
-        int nact = 0;
-        for (int r = lo; r < e[i]; ++r) nact += act ? (act[r] != 0) : 1;
-        const double per_row = nact ? d[i] * w[i] / nact : 0.0;
-        for (int r = lo; r < e[i]; ++r) cost[r] = (act ? act[r] != 0 : true) ? per_row : 0.0;
-        if (!nact) omega -= d[i] * w[i];        // (a segment of open water: what it took is not the rows' cost)
-        lo = e[i];
-      }
-    }
+    const double omega = balance_strip(rows, ty_n, e.data(), d.data(), w.data(), act, cost.data(), recount ? nullptr : ne.data());
     if (!(omega > 0)) continue;
     strip_cost[tx] = omega;
     if (recount) {
       rowcost[tx].assign(cost.begin(), cost.begin() + rows);
       continue;                                 // (the table is re-cut below, with the new numbers of tiles)
     }
-    // where the running sum of the cost reaches each tile's share; every boundary goes half-way there
-    {
-      double acc = 0, cum = 0;
-      int r = 0;
-      for (int i = 0; i < ty_n - 1; ++i) {
-        acc += w[i];
-        const double want = omega * acc / wsum;
-        while (r < rows && cum + cost[r] < want) cum += cost[r++];
-        x[i] = r < rows && cost[r] > 0 ? r + (want - cum) / cost[r] : r;
-      }
-    }
     int prev = 0;
-    for (int i = 0; i < ty_n; ++i) {
-      int end = i == ty_n - 1 ? rows : (int)std::lround(e[i] + 0.5 * (x[i] - e[i]));
-      end = std::max(end, std::min(rows, prev + minrows));
-      end = std::min(end, rows - minrows * (ty_n - 1 - i));
-      end = std::max(end, prev);
-      ne[i] = end;
-      prev = end;
-    }
-    prev = 0;
     for (int i = 0; i < ty_n; ++i) {
       BalTile& bt = bal_tiles[tl[i]];
       if (bt.first != prev || bt.last != ne[i] - 1) changed = true;

@@ -467,6 +467,13 @@ int cice_transport_remap(cice_ctx *ctx, double dt, const cice_transport_fields *
  * gives up so that every owned column comes out right (checked by a lane-level restatement of the kernel's dependencies),
  * -1 if there is none; *strips = column strips of the block. */
 int cice_debug_skew_layout(int K, int S, int ncol, int cyclic, int *strips);
+/* Test aid, needs no device: one strip's step of the measured balancing of the sweep's row segments:
+ * n tiles with exclusive end rows ends[] (bottom to top, the last one = rows), the workgroups' measured durations[] (any unit),
+ * the static weights[] of their places, rows_with_ice[rows] != 0 where a row holds anything to compute (or NULL: every row).
+ * new_ends[]: every boundary half-way to where the running sum of the rows' cost reaches the tiles' shares; *total (may be
+ * NULL): the strip's cost, 0 if the durations give nothing to go by (new_ends = ends then).  -2: bad arguments. */
+int cice_debug_balance_strip(int rows, int n, const int32_t *ends, const double *durations, const double *weights,
+                             const unsigned char *rows_with_ice, int32_t *new_ends, double *total);
 /* evp -> transport WITHOUT a PCIe round trip.  In step_dynamics `call evp(dt)` is followed at once by `call
  * transport_remap(dt)` (source/ice_step_mod.F90:575-584): uvel, vvel come up from the device and go straight down again,
  * aicen, vicen are uploaded twice, and the rest of the state waits for the link while it idles during the subcycle loop.

@@ -118,3 +118,67 @@ def test_sweep_kernel_strip_layout_is_right_for_every_width():
                 assert L.cice_debug_skew_layout(K, S, ncol, 0, C.byref(st)) == 0, (K, S, ncol)
             assert 0 < shifted < 60, (K, S, shifted)
     assert L.cice_debug_skew_layout(9, 1, 100, 1, None) == -2
+
+
+@pytest.mark.parametrize("cover", ["full", "caps", "blobs"])
+def test_sweep_segments_converge_on_a_model_of_the_kernel(cover):
+    """cice_debug_balance_strip (no device): the per-strip step of the measured balancing, iterated against a model of the
+    sweep kernel -- a workgroup takes (rows with ice in its runs + what each run costs to start) / (speed of its place),
+    with 1.5 % of noise -- reaches tiles of equal time from equal segments within the sweeps one loop measures, keeps a
+    partition of the strip's rows at every step, and stays there."""
+    import ctypes as C
+    from cice4_amd import lib
+    L = lib.load()
+    rng = np.random.default_rng(7)
+    rows, n, K = 2400, 11, 4
+    act = np.ones(rows, np.uint8)
+    if cover == "caps":
+        act[:] = 0; act[:250] = 1; act[2010:] = 1
+    elif cover == "blobs":
+        act[:] = 0
+        for lo, hi in ((100, 380), (700, 760), (1200, 1800), (2250, 2390)):
+            act[lo:hi] = 1
+    speed = np.array([1.15, 1.0, 0.85, 1.15, 1.0, 0.85, 1.26, 1.26, 1.0, 0.85, 1.15])     # what the place really does
+    w = np.array([1.15, 1.0, 0.85, 1.15, 1.0, 0.85, 1.26, 1.26, 1.0, 0.85, 1.15]) * rng.uniform(0.93, 1.07, n)   # what the table believes
+
+    def kernel_model(ends):
+        d = np.zeros(n)
+        lo = 0
+        for i, e in enumerate(ends):
+            a = act[lo:e]
+            if a.any():
+                idx = np.flatnonzero(a)
+                gaps = np.diff(idx) - 1
+                runs = 1 + int((gaps > 3 * K).sum())
+                bridged = int(gaps[gaps <= 3 * K].sum())
+                d[i] = (len(idx) + bridged + runs * (4 * K - 1)) / speed[i] * rng.normal(1.0, 0.015)
+            lo = e
+        return d
+
+    ends = np.array([(i + 1) * rows // n for i in range(n)], np.int32)
+    ends[-1] = rows
+    worst = []
+    for it in range(36):
+        d = kernel_model(ends)
+        busy = d[d > 0]
+        worst.append(d.max() / busy.mean())
+        ne = np.zeros(n, np.int32)
+        tot = C.c_double(0)
+        rc = L.cice_debug_balance_strip(rows, n, ends.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                                        w.ctypes.data_as(C.c_void_p), act.ctypes.data_as(C.c_void_p), ne.ctypes.data_as(C.c_void_p),
+                                        C.byref(tot))
+        assert rc == 0 and tot.value > 0
+        assert ne[-1] == rows and np.all(np.diff(np.concatenate([[0], ne])) >= 2), ne.tolist()     # a partition, no tile below 2 rows
+        ends = ne
+    d = kernel_model(ends)
+    assert (d > 0).sum() == n, "every tile should have got rows with ice"
+    assert d.max() / d.mean() < 1.06, (cover, worst[:3], worst[-3:], d.round(1).tolist())
+    assert worst[0] > 1.12, "the model should start out unbalanced"
+    # nothing to go by: all durations zero (a strip of open water) -> the ends stay
+    z = np.zeros(n)
+    rc = L.cice_debug_balance_strip(rows, n, ends.ctypes.data_as(C.c_void_p), z.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                    act.ctypes.data_as(C.c_void_p), ne.ctypes.data_as(C.c_void_p), C.byref(tot))
+    assert rc == 0 and tot.value == 0 and np.array_equal(ne, ends)
+    bad = ends.copy(); bad[3] = bad[2] - 1
+    assert L.cice_debug_balance_strip(rows, n, bad.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), w.ctypes.data_as(C.c_void_p),
+                                      None, ne.ctypes.data_as(C.c_void_p), None) == -2
