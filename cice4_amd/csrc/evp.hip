@@ -290,7 +290,7 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #define SKEW_LOADPRIO 1  // (0.1 degree: 278-283 us per subcycle against 281-285, A/B of round 4)
 #endif
 #ifndef SKEW_TPASS       // HTN, HTE, strength and the two masks of a row travel from level to level through LDS (K <= 4)
-#define SKEW_TPASS 0
+#define SKEW_TPASS 1     // (measured traffic 5.67 -> 4.48 GB per launch at 0.1 degree, time -0.3 %: profiles/r04_sweep_least_traffic_configuration.txt)
 #endif
 #ifndef SKEW_WIDE        // the read-only inputs of a step come interleaved: 16-byte loads, 7 instead of 14 per level and step
 #define SKEW_WIDE 1
