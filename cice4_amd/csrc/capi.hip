@@ -866,6 +866,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "skew_subs")) *value = c_->evp->skew_subs(c_->evp->skew_levels());
   else if (!std::strcmp(key, "skew_pairs")) *value = c_->evp->pairs_ok() ? 1 : 0;
   else if (!std::strcmp(key, "skew_fill")) *value = c_->evp->skew_rows_on() ? c_->evp->skew_fill_pct() : 0;
+  else if (!std::strcmp(key, "resident_map")) *value = c_->evp->resident_map();
   else if (!std::strcmp(key, "skew_rowact")) *value = c_->evp->rowact_on() ? 1 : 0;
   else if (!std::strcmp(key, "skew_balance")) *value = c_->evp->skew_rows_on() && c_->evp->balance_on() ? 1 : 0;
   else if (!std::strcmp(key, "skew_balanced")) *value = (int)std::min<long long>(c_->evp->balanced_sweeps(), 2000000000LL);

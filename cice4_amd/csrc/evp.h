@@ -64,6 +64,7 @@ class Evp {
   bool skew_fill_on() const;
   int skew_fill_pct() const;
   bool rowact_on() const;    // workgroups of the sweep shrink to the rows that hold ice
+  int resident_map();        // the tile map the one-launch loop last chose (k_res_choose_map), -1: none yet
   bool balance_on() const;   // the sweep's segments follow the measured cost of their rows (one block per rank)
   long long balanced_sweeps() const { return bal_sweeps; }
   bool can_trim() const;     // sweeps on wide-halo slabs over tile lists (extension rows trimmed)
@@ -123,6 +124,9 @@ class Evp {
   bool bal_recounted = false;
   void bal_upload(hipStream_t s);
   double place_weight(int tile_lin, int nt, int gens, int per_xcd, bool fill) const;
+  DevBuf<int32_t> res_map;        // k_res_choose_map: the tile map of the one-launch loop, chosen once per evp(dt)
+  bool res_map_stale = true;
+  int res_map_opt = -1;
   DevBuf<unsigned char> rowact;   // k_skew_rowact
   DevBuf<int32_t> run_next, run_end;   // k_skew_runs
   int rowact_strips = 0, rowact_k = 0;

@@ -1574,6 +1574,7 @@ struct ResArgs {
   long long* phases;     // ... [8 * workgroups] cycles per phase of the subcycle, summed over the launch (PHASE)
   int prio_mode;         // issue priority of the workgroups that share a CU (dense shape): 0 none, 1 by generation, 2 rotating
   int prio_div;          // workgroups of one generation per XCD (= CUs per XCD)
+  const int32_t* tile_map;   // one word (k_res_choose_map): which tile a workgroup takes, 0 = the tiles of an XCD are neighbours, 1 = blockIdx
 };
 enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
 
@@ -1592,6 +1593,48 @@ __device__ __forceinline__ double ld_sys(const double* base, unsigned off) {
 }
 __device__ __forceinline__ void st_sys(double* base, unsigned off, double v) {
   __hip_atomic_store((double*)((char*)base + off), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Which tile map of k_evp_resident leaves the busiest CU with fewer tiles that hold ice (one workgroup, once per evp(dt)).
+// A workgroup blockIdx b of the loop runs on XCD b & 7, CU (b >> 3) mod per_xcd; under map 0 it takes tile (b & 7) * chunk +
+// (b >> 3), under map 1 tile b.  force: -1 choose, 0 / 1 that map.
+__global__ __launch_bounds__(1024) void k_res_choose_map(int nt, int tiles_x, int tiles_y, int W, int nx, int ny, int per_xcd,
+                                                         int force, const int32_t* __restrict__ blk,
+                                                         const int32_t* __restrict__ tmk, const int32_t* __restrict__ umk,
+                                                         int32_t* __restrict__ out) {
+  __shared__ int s_ice[1024];
+  __shared__ int s_cnt[2][256];
+  __shared__ int s_max[2];
+  const int t = threadIdx.x;
+  if (t < 256) s_cnt[0][t] = s_cnt[1][t] = 0;
+  if (t < 2) s_max[t] = 0;
+  int ice = 0;
+  if (t < nt) {
+    const int per_blk = tiles_x * tiles_y, b = t / per_blk, rem = t - b * per_blk, tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int ilo = blk[6 * b], ihi = blk[6 * b + 1], jlo = blk[6 * b + 2], jhi = blk[6 * b + 3];
+    const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    for (int j = j0; j <= min(j0 + W - 1, jhi + 1) && !ice; ++j)
+      for (int i = i0; i <= min(i0 + TX - 1, ihi + 1); ++i) {
+        const size_t q = (size_t)b * nx * ny + (size_t)(j - 1) * nx + (i - 1);
+        if (tmk[q] == 1 || umk[q] != 0) { ice = 1; break; }
+      }
+  }
+  s_ice[t] = ice;
+  __syncthreads();
+  const int chunk = (nt + 7) >> 3;
+  if (t < 8 * chunk && per_xcd * 8 <= 256) {     // t as a blockIdx of the loop
+    const int cu = (t & 7) * per_xcd + ((t >> 3) % per_xcd);
+    const int t0 = (t & 7) * chunk + (t >> 3);
+    if (t0 < nt && s_ice[t0]) atomicAdd(&s_cnt[0][cu], 1);
+    if (t < nt && s_ice[t]) atomicAdd(&s_cnt[1][cu], 1);
+  }
+  __syncthreads();
+  if (t < 256) {
+    atomicMax(&s_max[0], s_cnt[0][t]);
+    atomicMax(&s_max[1], s_cnt[1][t]);
+  }
+  __syncthreads();
+  if (t == 0) out[0] = force >= 0 ? force : (s_max[1] < s_max[0] ? 1 : 0);
 }
 
 // PEER: see ResArgs.  Differences to the one-rank loop: progress runs epoch0 + 1 ("this launch has begun: its exchange
@@ -1620,7 +1663,13 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
   const int per_blk = a.tiles_x * a.tiles_y;
   const int nt = per_blk * ((PEER || FOLD) ? 1 : a.nblocks);
   const int chunk = (nt + 7) >> 3;
-  const int tile = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  // Which tile: the workgroups of an XCD are blockIdx & 7 == XCD, and the three that share a CU are 256 apart in blockIdx.
+  // Map 0 gives an XCD a band of neighbouring tile rows (and a CU three tiles a few rows apart); map 1 (tile = blockIdx)
+  // gives a CU three tiles a third of the grid apart -- under an ice cover that comes in latitude bands a CU then holds
+  // one tile with ice and two without instead of three of a kind: gx1 size with ice on two polar caps 4.2 us per subcycle
+  // against 5.45, fully covered 5.51 against 5.44 (profiles/r04_resident_tile_map.txt).  k_res_choose_map picks, once per
+  // evp(dt), the map under which the busiest CU holds fewer tiles with ice.  Everything between tiles goes by TILE number.
+  const int tile = (r.tile_map && *r.tile_map == 1) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (tile >= nt) return;  // whole workgroup
   const int b = (PEER || FOLD) ? 0 : tile / per_blk;
   const int rem = tile - b * per_blk;
@@ -2602,6 +2651,10 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "skew_gen_pct")) {   // segments of the workgroup dispatched first on a CU this much longer
     CICE_REQUIRE(value >= 0 && value <= 60, "skew_gen_pct must be 0 .. 60");
     skew_gen_pct = value;
+  } else if (!std::strcmp(key, "resident_map")) {   // tile map of the one-launch loop: -1 chosen by the ice cover, 0 / 1 fixed (k_res_choose_map)
+    CICE_REQUIRE(value >= -1 && value <= 1, "resident_map must be -1, 0 or 1");
+    res_map_opt = value;
+    res_map_stale = true;
   } else if (!std::strcmp(key, "skew_rowact")) {    // workgroups of the sweep shrink to the rows that hold ice (k_skew_rowact)
     rowact_opt = value != 0;
     skew_packed = false;
@@ -2880,6 +2933,7 @@ void Evp::prepare(double dt) {
   // kernel never writes (outside the masks) then hold the same value in either copy
   CICE_HIP(hipMemcpyAsync(st[1 - cur].p, st[cur].p, 14 * n * 8, hipMemcpyDeviceToDevice, stream));
   copies_identical = true;   // (until the first subcycle kernel writes one of them)
+  res_map_stale = true;      // new masks: the one-launch loop chooses its tile map again
   flips = 0;
   skew_packed = false;
   if (can_skew() || can_skew_fold()) skew_pack();   // the sweep kernel's interleaved inputs of this step
@@ -2918,6 +2972,14 @@ void Evp::skew_pack() {
     rowact_host_stale = true;
   }
   skew_packed = true;
+}
+
+int Evp::resident_map() {
+  if (res_map.n == 0 || res_map_stale) return -1;
+  int32_t v = -1;
+  CICE_HIP(hipStreamSynchronize(stream));
+  CICE_HIP(hipMemcpy(&v, res_map.p, 4, hipMemcpyDeviceToHost));
+  return v;
 }
 
 // Workgroups of the sweep shrink to the rows that hold ice (SkewArgs::rowact).  Not with three wavefronts per level (its
@@ -4660,6 +4722,23 @@ bool Evp::run_resident(int ksub0, int nsub) {
     }
   }
   r.prio_mode = dense ? res_prio : 0;
+  r.tile_map = nullptr;
+  if (!peer && !halo.has_fold() && g.x <= 1024) {     // one choice per evp(dt) (prepare() marks it stale: the masks are new)
+    if (res_map.n == 0) { res_map.alloc(1); res_map_stale = true; }
+    if (res_map_stale) {
+      static const int force = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_MAP"); return e ? std::atoi(e) : -1; }();
+      int ncu = 256, dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ncu = v;
+      }
+      hipLaunchKernelGGL(k_res_choose_map, dim3(1), dim3(1024), 0, stream, r.a.tiles_x * r.a.tiles_y * r.a.nblocks, r.a.tiles_x,
+                         r.a.tiles_y, W, dom.nx_block, dom.ny_block, std::max(1, ncu / 8), res_map_opt >= 0 ? res_map_opt : force,
+                         (const int32_t*)blk.p, (const int32_t*)icetmask.p, (const int32_t*)iceumask.p, res_map.p);
+      res_map_stale = false;
+    }
+    r.tile_map = res_map.p;
+  }
   {
     int ncu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) {
