@@ -1106,6 +1106,30 @@ def test_sweep_segments_follow_the_measured_cost(ctx, nxg, nyg, ns, cover):
     assert len(tables[-1]) >= len(tables[0]) >= strips
 
 
+def test_sweep_segments_cut_for_one_ice_cover_serve_another(ctx):
+    """The rows that hold ice are found anew in every evp(dt); the segment table is re-cut only now and then.  A table cut
+    for polar caps, then ice in blobs, then a full cover, and back -- one context, no re-initialisation, a tuning phase every
+    third loop: every call gives the bits of one launch per subcycle on that state."""
+    nxg, nyg, ndte, K = 130, 400, 24, 4
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=nxg + nyg)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    states, refs = {}, {}
+    for cover in ("caps", "patchy", "full"):
+        states[cover] = synth.evp_state(grid, dom, seed=nxg, cover=cover)
+        refs[cover], _ = _evp_with(ctx, grid, states[cover], ndte, False, resident=0, skew=0)
+    ctx.evp_init(grid, ndte=ndte, krdg_partic=0, krdg_redist=0)
+    for key, v in (("resident", 0), ("skew", 1), ("skew_min_cells", 0), ("skew_levels", K), ("skew_balance", 1), ("skew_balance_every", 3)):
+        ctx.evp_set_option(key, v)
+    for call, cover in enumerate(("caps", "caps", "patchy", "full", "caps", "patchy", "patchy", "full", "caps")):
+        sg = {k: v.copy() for k, v in states[cover].items()}
+        ctx.evp(DT, sg)
+        for k in keys:
+            assert np.array_equal(sg[k], refs[cover][k]), (call, cover, k, np.argwhere(sg[k] != refs[cover][k])[:6].tolist())
+    assert ctx.evp_get_info("skew_balanced") > ndte // K
+
+
 @pytest.mark.parametrize("ns", ["tripole", "tripoleT"])
 def test_tripole_fold_inside_the_loop_against_the_compiled_reference(ns):
     """the same against `call evp(dt)` of the reference itself on a one-block 100 x 116 domain (own process)"""
