@@ -212,12 +212,25 @@ int cice_evp_finish(cice_ctx *ctx);
  * three 4-wavefront workgroups per compute unit where that fills the chip exactly -- gx1 -- so that hand-offs of one
  * overlap the arithmetic of the others; a launch that does not get every slot times out and later ones use one workgroup
  * per compute unit), "resident_spin_us" (default 200000: how long a tile of the resident loop waits for a neighbour
- * before the launch gives up and the range is run by the launch-per-pair loop; 0 makes every wait fail -- tests).
+ * before the launch gives up and the range is run by the launch-per-pair loop; 0 makes every wait fail -- tests),
+ * "resident_map" (-1 default: which tile a workgroup of that loop takes is chosen on the device, once per evp(dt), by the ice
+ * cover -- under ice in latitude bands a CU gets one tile with ice and two without; 0 / 1 fix the map).
+ * Sweeps (K subcycles per launch on grids of ~0.1 degree size): "skew" (0/1), "skew_levels" (K: 2, 3, 4 default, 5, 6, 8),
+ * "skew_min_cells", "skew_seg_rows" (rows per workgroup, 0 = as many workgroups as the chip holds), "skew_rowact" (0/1,
+ * default 1: a workgroup walks only the runs of rows of its segment that hold ice), "skew_balance" (0/1, default 1 on
+ * one-block domains: the segment table is re-cut from the workgroups' measured times -- the sweeps of the first loop after
+ * start-up are measured, eagerly; "skew_balance_every", default 96: loops between two later tuning phases of 8 sweeps),
+ * "skew_fill" / "skew_gen_pct" (per cent: static weights of a workgroup's place -- more rows on a CU that holds fewer
+ * workgroups, more for the workgroup dispatched first; defaults 26 / 15), "skew_split" (wide-halo slabs: the refresh beside
+ * the interior sweep), "skew_subs" (1 / 3 wavefronts per level).  DESIGN.md sections 3.1, 3.2, 7.
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
  * (1 if this domain runs two subcycles per launch), "fused_waves", "resident" (1 if the next cice_evp_subcycles
  * of two or more subcycles runs as one launch), "resident_waves", "resident_dense" (1 if with several workgroups per
- * compute unit). */
+ * compute unit), "resident_map" (the map last chosen, -1 before the first loop), "skew" / "skew_fold" (1 if sweeps apply),
+ * "skew_levels", "skew_strips", "skew_seg_rows", "skew_rowact", "skew_balance", "skew_balanced" (sweeps measured so far),
+ * "skew_fill", "skew_pairs", "skew_subs", "skew_split", "skew_trim_ext", "last_launches" (kernel launches of the last
+ * subcycle range: 1 = the one-launch loop). */
 int cice_evp_set_option(cice_ctx *ctx, const char *key, int value);
 int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
