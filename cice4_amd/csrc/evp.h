@@ -158,7 +158,7 @@ class Evp {
   hipEvent_t res_done_ev = nullptr;   // end of the cross-rank loop, polled (run_resident)
   int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
-  int res_occ[5][2][2] = {};     // workgroups of k_evp_resident<W, DAMP, PEER> one CU holds, 0 = not asked yet
+  int res_occ[5][2][3] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD> one CU holds (last index: plain, PEER, FOLD), 0 = not asked yet
   int resident_occupancy(int W, bool damp, bool peer);
   int res_w = 0, res_tiles = 0;  // what res_deps was built for
   unsigned res_epoch = 0;

@@ -1646,7 +1646,7 @@ template <int W, bool DAMP, bool PEER, bool FOLD = false>
 // (second bound: wavefronts per SIMD.  W = 4 runs three workgroups per CU in the dense shape -- one rank only --, W = 11,
 // 12 put three wavefronts of one workgroup on a SIMD: both need the 168-register budget whatever the compiler would
 // like to use)
-__global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
+__global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
   static_assert(!(PEER && FOLD), "the fold is handled on one-rank domains");
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
@@ -1654,7 +1654,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
   __shared__ double s_x[W][8][TX];
   __shared__ double s_m[W][10][TX];             // nine metrics + strength
   __shared__ int s_fd[W][3][TX];
-  __shared__ int s_rfd[PEER || FOLD ? W : 1][4][TX];   // PEER: ghost cells on other ranks mirroring this lane's cell; FOLD: ghost cells the fold fills
+  __shared__ int s_rfd[PEER ? W : 1][4][TX];   // PEER: ghost cells on other ranks mirroring this lane's cell
+  int rfr[4] = {-1, -1, -1, -1};                // FOLD: ghost cells the fold fills from this lane's cell (registers: with them in LDS three
+                                                //       4-wavefront workgroups need 165 KB of a CU's 160)
   __shared__ int s_pub[2];                      // PEER: this tile publishes to the south / north rank
   __shared__ int s_abort;
   // tiles are numbered block by block (a one-rank domain of several blocks: every block is cut into tiles_x x tiles_y
@@ -1760,7 +1762,10 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
         }
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) s_rfd[w][c][lx] = rf[c];
+      for (int c = 0; c < 4; ++c) {
+        if (PEER) s_rfd[w][c][lx] = rf[c];
+        else rfr[c] = rf[c];
+      }
       edge = edge || rf[0] >= 0;
     }
   }
@@ -1989,7 +1994,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
       if (FOLD) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          const int rf = s_rfd[w][c][lx];
+          const int rf = rfr[c];
           if (rf >= 0) {                          // a ghost cell the fold fills: this cell's value, negated or not
             const bool neg = (rf >> 30) & 1;
             const unsigned ro = (unsigned)(rf & 0x3fffffff) * 8u;
@@ -2101,7 +2106,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER && !FOLD ? 3 : (64 * W + 2
     a.v_out[q] = vn;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const int rf = s_rfd[w][c][lx];
+      const int rf = rfr[c];
       if (rf >= 0) {
         const bool neg = (rf >> 30) & 1;
         a.u_out[rf & 0x3fffffff] = neg ? -un : un;
@@ -4168,7 +4173,8 @@ int Evp::resident_waves() const {
   // (the cross-rank and the fold variants carry one more table in LDS and a few more registers: no 12-wavefront
   //  workgroups, no three workgroups per CU)
   const bool plain = !halo.multi_rank() && !halo.has_fold();
-  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && plain;
+  static const bool fold_dense = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_FOLD_DENSE"); return !(e && e[0] == '0'); }();
+  const bool dense_ok = res_dense && res_level == 0 && tiles(4) > ncu && tiles(4) <= 3LL * ncu && (plain || (fold_dense && !halo.multi_rank()));
   if (res_w_opt) return (tiles(res_w_opt) <= ncu || (res_w_opt == 4 && dense_ok)) && !(res_w_opt == 12 && !plain) ? res_w_opt : 0;
   int single = 0;
   for (int w : {4, 6, 8, 11, 12})    // the shortest workgroup that still gives every tile its own CU
@@ -4603,10 +4609,17 @@ static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream
 }
 
 template <int W>
-static int occ_res(bool damp, bool peer) {
+static int occ_res(bool damp, bool peer, bool fold = false) {
   int nb = 0;
   hipError_t e;
-  if (peer) {
+  if (fold && !peer) {
+    if constexpr (W <= 11) {
+      e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, false, true>, 64 * W, 0)
+               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false, true>, 64 * W, 0);
+    } else {
+      return 0;
+    }
+  } else if (peer) {
     if constexpr (W <= 11) {
       e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, true>, 64 * W, 0)
                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, true>, 64 * W, 0);
@@ -4628,15 +4641,16 @@ static int occ_res(bool damp, bool peer) {
 // loop needs every tile resident at once, and a kernel that grew past its budget must not find that out by time-out
 int Evp::resident_occupancy(int W, bool damp, bool peer) {
   const int wi = W == 4 ? 0 : W == 6 ? 1 : W == 8 ? 2 : W == 11 ? 3 : 4;
-  int& c = res_occ[wi][damp][peer];
+  const bool fold = !peer && halo.has_fold();
+  int& c = res_occ[wi][damp][peer ? 1 : (fold ? 2 : 0)];
   if (c == 0) {
     int nb = 0;
     switch (W) {
-      case 4: nb = occ_res<4>(damp, peer); break;
-      case 6: nb = occ_res<6>(damp, peer); break;
-      case 8: nb = occ_res<8>(damp, peer); break;
-      case 11: nb = occ_res<11>(damp, peer); break;
-      case 12: nb = occ_res<12>(damp, peer); break;
+      case 4: nb = occ_res<4>(damp, peer, fold); break;
+      case 6: nb = occ_res<6>(damp, peer, fold); break;
+      case 8: nb = occ_res<8>(damp, peer, fold); break;
+      case 11: nb = occ_res<11>(damp, peer, fold); break;
+      case 12: nb = occ_res<12>(damp, peer, fold); break;
       default: break;
     }
     c = nb > 0 ? nb : -1;
