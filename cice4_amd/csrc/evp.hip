@@ -4737,6 +4737,8 @@ bool Evp::run_resident(int ksub0, int nsub) {
   }
   r.prio_mode = dense ? res_prio : 0;
   r.tile_map = nullptr;
+  // (not under a fold: there the period is the top-row tiles' second hand-off, not the arithmetic -- gx1 tripole with polar caps
+  //  6.37 us per subcycle with the map against 6.31 without)
   if (!peer && !halo.has_fold() && g.x <= 1024) {     // one choice per evp(dt) (prepare() marks it stale: the masks are new)
     if (res_map.n == 0) { res_map.alloc(1); res_map_stale = true; }
     if (res_map_stale) {

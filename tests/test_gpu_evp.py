@@ -1043,18 +1043,18 @@ def test_sweeps_on_a_tripole_grid(ctx, nxg, nyg, ns):
 
 
 @pytest.mark.parametrize("cover,expect", [("caps", 1), ("full", 0)])
-def test_one_launch_loop_chooses_its_tile_map_by_the_ice_cover(ctx, cover, expect):
+def test_one_launch_loop_chooses_its_tile_map_by_the_ice_cover(ctx, cover, expect, ns=0):
     """Which tile a workgroup of the one-launch loop takes is free (everything between tiles goes by tile number): under an
     ice cover in latitude bands the loop deals the tiles so that a CU holds one tile with ice and two without (k_res_choose_map,
     once per evp(dt), on the device); a fully covered grid keeps the tiles of an XCD together.  Both maps and the choice:
     the bits of one launch per subcycle, gx1 size (768 tiles: the dense shape)."""
     nxg, nyg = 320, 384
-    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
-    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.04, seed=5)
-    grid = synth.block_fields(gg, dom, ew_cyclic=True)
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.04, seed=5, land_rows=0 if ns else 1)
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=bool(ns))
     s = synth.evp_state(grid, dom, seed=9, cover=cover)
     keys = EVP_OUT_FIELDS + ("iceumask",)
-    ref, _ = _evp_with(ctx, grid, s, 24, False, resident=0, skew=0)
+    ref, _ = _evp_with(ctx, grid, s, 24, False, resident=0, skew=0, skew_fold=0)
     for m in (-1, 0, 1):
         sg = {k: v.copy() for k, v in s.items()}
         ctx.evp_init(grid, ndte=24, krdg_partic=0, krdg_redist=0)
