@@ -3988,8 +3988,10 @@ void Evp::launch_subcycle_skew_split(int ksub, int K) {
 // k_subcycle + the halo update with its fold, on buffers of its own.  The band's lower rows see a stale row below them
 // and go wrong from the other side, one row per subcycle -- after K subcycles its rows above jhi - K are right.  They
 // replace the sweep's.  Per sweep: 2 + 2K small launches beside one large one -- BESIDE in time as well: the sweep goes to
-// a second stream (a parallel branch of the captured graph), the band's launches stay on the main one and find room on the
-// CUs the sweep leaves part-empty (737 workgroups on 768 places at 0.1 degree); only the last copy waits for the sweep.
+// a second stream (a parallel branch of the captured graph) AFTER the band's first copy, so that its workgroups are placed
+// first; the band's launches stay on the main stream and run where and when the sweep leaves room -- in practice in its tail,
+// as its workgroups finish (letting the band start ahead of the sweep displaces sweep workgroups into a second round: +29 %,
+// DESIGN.md section 3.2); only the last copy waits for the sweep.
 // CICE4_AMD_SKEW_FOLD_BESIDE=0: one after the other on one stream (round 3's form), for A/B.
 __global__ __launch_bounds__(256) void k_band_rows(double* __restrict__ dst, double* __restrict__ dst2,
                                                    const double* __restrict__ src, size_t n, size_t off, size_t len) {
