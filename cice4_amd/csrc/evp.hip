@@ -1574,6 +1574,7 @@ struct ResArgs {
   long long* phases;     // ... [8 * workgroups] cycles per phase of the subcycle, summed over the launch (PHASE)
   int prio_mode;         // issue priority of the workgroups that share a CU (dense shape): 0 none, 1 by generation, 2 rotating
   int prio_div;          // workgroups of one generation per XCD (= CUs per XCD)
+  int prio_top;          // FOLD, dense shape: the tiles of the top row always issue first on their CU
   const int32_t* tile_map;   // one word (k_res_choose_map): which tile a workgroup takes, 0 = the tiles of an XCD are neighbours, 1 = blockIdx
 };
 enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
@@ -1812,7 +1813,11 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
 #pragma clang loop unroll(disable)
   for (int k = 0; k < r.nsub; ++k) {
     const bool lastk = r.last && k == r.nsub - 1;
-    if (r.prio_mode == 2) {
+    if (FOLD && toptile && r.prio_top) {
+      // the tiles of the top row have a second hand-off per subcycle (the raw velocities across the fold) and everybody
+      // waits for them: they issue first on their CU, always
+      __builtin_amdgcn_s_setprio(3);
+    } else if (r.prio_mode == 2) {
       const int p = (k + gen) % 3;
       if (p == 0) __builtin_amdgcn_s_setprio(3);
       else if (p == 1) __builtin_amdgcn_s_setprio(1);
@@ -4738,6 +4743,10 @@ bool Evp::run_resident(int ksub0, int nsub) {
     }
   }
   r.prio_mode = dense ? res_prio : 0;
+  {
+    static const bool top = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_PRIO_TOP"); return !(e && e[0] == '0'); }();
+    r.prio_top = dense && top ? 1 : 0;
+  }
   r.tile_map = nullptr;
   // (not under a fold: there the period is the top-row tiles' second hand-off, not the arithmetic -- gx1 tripole with polar caps
   //  6.37 us per subcycle with the map against 6.31 without)
