@@ -765,6 +765,21 @@ int cice_comm_init_shm(cice_ctx* ctx, const char* name, int rank, int nranks, lo
   CICE_CATCH
 }
 
+// TIMING AID (halo.hip: MirrorLink): this context is rank `rank` of `nranks`, alone; its messages come back to it.
+int cice_comm_init_mirror(cice_ctx* ctx, int rank, int nranks) {
+  CICE_TRY(ctx)
+  CICE_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "cice_comm_init_mirror: bad arguments");
+  CICE_REQUIRE(!c_->comm && !c_->link, "cice_comm_init_mirror: this context already has a communicator");
+  c_->need_halo();
+  c_->link = mirror_link_new(nranks);
+  c_->link_owned = true;
+  c_->comm_rank = rank;
+  c_->comm_nranks = nranks;
+  c_->halo->set_link(c_->link, rank, nranks);
+  if (c_->frame_halo) c_->frame_halo->set_link(c_->link, rank, nranks);
+  CICE_CATCH
+}
+
 // Ranks of this context's communicator as RCCL itself counts them (ncclCommCount); 0 before cice_comm_init.
 int cice_comm_count(cice_ctx* ctx, int* nranks) {
   CICE_TRY(ctx)
@@ -791,32 +806,33 @@ int cice_evp_init(cice_ctx* ctx, const cice_evp_config* cfg, const cice_evp_grid
 #define NEED_EVP CICE_REQUIRE(c_->evp != nullptr, "cice_evp_init has not been called")
 
 int cice_evp_upload(cice_ctx* ctx, const cice_evp_fields* f) {
-  CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->upload(*f); CICE_CATCH
+  CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->upload(*f); CICE_CATCH
 }
 int cice_evp_download(cice_ctx* ctx, cice_evp_fields* f) {
   CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->download(*f); CICE_CATCH
 }
-int cice_evp_step(cice_ctx* ctx, double dt) { CICE_TRY(ctx) NEED_EVP; c_->evp->step(dt); CICE_CATCH }
+int cice_evp_step(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->step(dt); CICE_CATCH }
 int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   CICE_TRY(ctx)
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
-  c_->evp->upload(*f);
   c_->chain_ready = false;
-  if (c_->chain_on && c_->transport) {
+  c_->evp->upload(*f);
+  const bool chain = c_->chain_on && c_->transport;
+  if (chain) {
     // the rest of the transport's state travels while the subcycle loop runs (the link idles then); see cice_transport_chain
     c_->transport->prefetch(c_->chain);
     c_->chain_aicen = f->aicen; c_->chain_vicen = f->vicen; c_->chain_u = f->uvel; c_->chain_v = f->vvel;
-    c_->chain_ready = true;
   }
   c_->evp->step(dt);
   c_->evp->download(*f);
+  c_->chain_ready = chain;   // only a call that got this far leaves device copies the transport may take over
   CICE_CATCH
 }
 // f1 hand-off: the state the batched thermodynamic step left on the device becomes the dynamics' input without crossing
 // PCIe (valid when nothing on the host has changed aicen / vicen / vsnon since: the caller's statement).
 int cice_evp_adopt_thermo_state(cice_ctx* ctx) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   NEED_EVP;
   auto& t = c_->tb;
   CICE_REQUIRE(t.nb > 0, "cice_thermo_batch_alloc has not been called");
@@ -843,11 +859,11 @@ int cice_evp_pin_fields(cice_ctx* ctx, const cice_evp_fields* f) {
   pin(f->iceumask, n * 4);
   CICE_CATCH
 }
-int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) NEED_EVP; c_->evp->prepare(dt); CICE_CATCH }
+int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->prepare(dt); CICE_CATCH }
 int cice_evp_subcycles(cice_ctx* ctx, int ksub0, int nsub, float* ms) {
-  CICE_TRY(ctx) NEED_EVP; c_->evp->subcycles(ksub0, nsub, ms); CICE_CATCH
+  CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->subcycles(ksub0, nsub, ms); CICE_CATCH
 }
-int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) NEED_EVP; c_->evp->finish(); CICE_CATCH }
+int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->finish(); CICE_CATCH }
 int cice_evp_set_option(cice_ctx* ctx, const char* key, int value) {
   CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(key, "NULL key"); c_->evp->set_option(key, value); CICE_CATCH
 }
@@ -878,6 +894,7 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "resident_peer")) *value = c_->evp->can_reside_peer() ? 1 : 0;
   else if (!std::strcmp(key, "last_launches")) *value = c_->evp->last_launches;
   else if (!std::strcmp(key, "resident_peer_fine")) *value = c_->evp->peer_buffers_fine() ? 1 : 0;
+  else if (!std::strcmp(key, "resident_granules")) *value = c_->evp->granules_in_use() ? 1 : 0;
   else if (!std::strcmp(key, "resident_waves")) *value = c_->evp->resident_waves();
   else if (!std::strcmp(key, "resident_dense")) *value = c_->evp->can_reside() && c_->evp->resident_dense() ? 1 : 0;
   else throw Error{CICE_EINVAL, std::string("unknown info key ") + key};
@@ -1104,7 +1121,7 @@ int cice_thermo_vertical(cice_ctx* ctx, int nx, int ny, double dt, int icells, c
                          double* fhocnn, double* meltt, double* melts, double* meltb, double* congel,
                          double* snoice, double* mlt_onset, double* frz_onset, double yday,
                          int32_t* l_stop, int32_t* istop, int32_t* jstop) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   CICE_REQUIRE(c_->have_thermo, "cice_thermo_init has not been called");
   CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
   CICE_REQUIRE(nx >= 1 && ny >= 1, "bad dimensions");
@@ -1357,7 +1374,7 @@ static void batch_upload(cice_ctx* c_, const cice_thermo_fields* h, bool with_fb
 }
 
 int cice_thermo_batch_upload(cice_ctx* ctx, const cice_thermo_fields* h) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   batch_upload(c_, h, true);
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
@@ -1479,7 +1496,7 @@ int cice_thermo_set_option(cice_ctx* ctx, const char* key, int value) {
 int cice_thermo_batch_step(cice_ctx* ctx, double dt, double yday, long long* n_updates,
                            int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
                            int32_t* bstop, float* elapsed_ms) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   CICE_REQUIRE(l_stop && istop && jstop, "NULL status pointer");
   unsigned long long h[THERMO_STATUS_WORDS];
   hipEvent_t ev[2] = {nullptr, nullptr};
@@ -1523,7 +1540,7 @@ static void batch_download(cice_ctx* c_, cice_thermo_fields* h) {
 }
 
 int cice_thermo_batch_download(cice_ctx* ctx, cice_thermo_fields* h) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   batch_download(c_, h);
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
@@ -1571,7 +1588,7 @@ static void batch_merge(cice_ctx* c_, const cice_merge_fields* f, const double* 
 }
 
 int cice_thermo_batch_merge(cice_ctx* ctx, const cice_merge_fields* f) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   batch_merge(c_, f, nullptr);
   CICE_HIP(hipStreamSynchronize(c_->stream));
   CICE_CATCH
@@ -1659,7 +1676,7 @@ static void step_therm1(cice_ctx* c_, double dt, double yday, cice_thermo_fields
 int cice_step_therm1(cice_ctx* ctx, double dt, double yday, cice_thermo_fields* st,
                      const cice_frzmlt_fields* fz, const cice_merge_fields* mg, long long* n_updates,
                      int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop, int32_t* bstop) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   step_therm1(c_, dt, yday, st, fz, mg, nullptr, n_updates, l_stop, istop, jstop, nstop, bstop);
   CICE_CATCH
 }
@@ -1670,7 +1687,7 @@ int cice_step_therm1_abl(cice_ctx* ctx, double dt, double yday, cice_thermo_fiel
                          const cice_frzmlt_fields* fz, const cice_merge_fields* mg, const cice_atmo_fields* atm,
                          long long* n_updates, int32_t* l_stop, int32_t* istop, int32_t* jstop, int32_t* nstop,
                          int32_t* bstop) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   CICE_REQUIRE(atm != nullptr, "NULL argument");
   step_therm1(c_, dt, yday, st, fz, mg, atm, n_updates, l_stop, istop, jstop, nstop, bstop);
   CICE_CATCH
@@ -1833,7 +1850,7 @@ int cice_transport_upwind_init(cice_ctx* ctx, const cice_transport_config* cfg, 
 }
 
 int cice_transport_upwind(cice_ctx* ctx, double dt, const cice_transport_fields* f) {
-  CICE_TRY(ctx)
+  CICE_TRY(ctx) c_->chain_ready = false;
   CICE_REQUIRE(c_->upwind != nullptr, "cice_transport_upwind_init has not been called");
   CICE_REQUIRE(f, "NULL argument");
   c_->upwind->step(dt, *f);

@@ -23,6 +23,8 @@ LocalLink* local_link_get(int link_id, int nranks);   // the link of that id (cr
 // the same between PROCESSES of one host through a file under /dev/shm (rank 0 creates it); owned by the caller
 LocalLink* shm_link_open(const char* name, int rank, int nranks, size_t box_bytes);
 void link_close(LocalLink* l);
+// timing aid: no partner at all -- what a rank would send comes back as what it would receive (halo.hip: MirrorLink); owned by the caller
+LocalLink* mirror_link_new(int nranks);
 
 enum HaloParts { HALO_COPIES = 1, HALO_FOLD = 2, HALO_ALL = 3 };
 

@@ -36,6 +36,7 @@ constexpr int LINK_WAIT_S = 60;   // a rank whose partner never shows up fails i
 
 struct LocalLink {
   int nranks = 0;
+  bool mirror = false;   // MirrorLink: no partner at all (see below)
   virtual ~LocalLink() = default;
   virtual void post(int src, int dst, const void* data, size_t bytes) = 0;   // blocks until the mailbox is free
   virtual void take(int src, int dst, void* data, size_t bytes) = 0;         // blocks until the message is there
@@ -98,6 +99,20 @@ struct InProcLink : LocalLink {
     return mx;
   }
 };
+
+// TIMING AID, not a communicator: ONE rank of an N-rank decomposition alone on its device.  Every message the rank
+// would send comes straight back as the message it would receive from that neighbour (a slab's two neighbours get and
+// send messages of the same shape), device to device, without a host round trip: the rank runs exactly the kernels,
+// tile lists, pack / unpack and launch sequence it would run in the N-rank job, with nobody else on the chip -- the
+// per-rank cost that a node with one GPU per rank would see, minus the link.  The RESULTS are those of a mirror
+// boundary and mean nothing.  (bench.py --as-rank R --of N)
+struct MirrorLink : LocalLink {
+  explicit MirrorLink(int n) { nranks = n; mirror = true; }
+  void post(int, int, const void*, size_t) override {}
+  void take(int, int, void*, size_t) override {}
+  unsigned all_max(int, unsigned v) override { return v; }
+};
+LocalLink* mirror_link_new(int nranks) { return new MirrorLink(nranks); }
 
 LocalLink* local_link_get(int link_id, int nranks) {
   static std::mutex gm;
@@ -485,6 +500,12 @@ void Halo::link_exchange(const T* sb, T* rb, int nfields, const std::vector<int>
                          const std::vector<int>& scnt, int ns, const std::vector<int>& rpeer,
                          const std::vector<int>& roff, const std::vector<int>& rcnt, int nr) {
   LocalLink& L = *link_;
+  if (L.mirror) {   // what would be sent comes back as what would be received (message m of either list: the same neighbour)
+    for (int m = 0; m < std::min(ns, nr); ++m)
+      CICE_HIP(hipMemcpyAsync(rb + (size_t)nfields * roff[m], sb + (size_t)nfields * soff[m],
+                              (size_t)nfields * std::min(scnt[m], rcnt[m]) * sizeof(T), hipMemcpyDeviceToDevice, stream_));
+    return;
+  }
   CICE_HIP(hipStreamSynchronize(stream_));   // the pack kernel has run
   std::vector<char> tmp;
   for (int m = 0; m < ns; ++m) {

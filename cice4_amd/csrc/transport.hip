@@ -674,6 +674,8 @@ void Transport::adopt(const double* d_uv, const double* d_aicen, const double* d
 }
 
 void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop, int32_t* istop, int32_t* jstop) {
+  const bool was_chained = chained;   // (read and reset before anything can throw: a failed call must not leave the NEXT one chained)
+  chained = false;
   CICE_REQUIRE(n > 0, "cice_transport_init has not been called");
   CICE_REQUIRE(f.aice0 && f.aicen && f.trcrn && f.vicen && f.vsnon && f.eicen && f.esnon && f.uvel && f.vvel,
                "cice_transport_remap: NULL field");
@@ -689,12 +691,11 @@ void Transport::remap(double dt, const cice_transport_fields& f, int32_t* l_stop
                                 hipMemcpyDeviceToHost, fan.next()));
   };
   fan.fork(stream);
-  if (!chained) {   // (chained: five arrays were prefetched during evp, four came from the dynamics' device buffers)
+  if (!was_chained) {   // (chained: five arrays were prefetched during evp, four came from the dynamics' device buffers)
     up(aice0.p, f.aice0, 1); up(aicen.p, f.aicen, NCAT); up(trcrn.p, f.trcrn, NCAT * NTRCR); up(vicen.p, f.vicen, NCAT);
     up(vsnon.p, f.vsnon, NCAT); up(eicen.p, f.eicen, NCAT * NILYR); up(esnon.p, f.esnon, NCAT * NSLYR);
     up(uv.p, f.uvel, 1); up(uv.p + n, f.vvel, 1);
   }
-  chained = false;
   fan.join();   // (also behind prefetched copies still in flight on the side streams)
   CICE_HIP(hipMemsetAsync(key.p, 0xff, 8, stream));
   a.dt = dt;

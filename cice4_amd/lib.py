@@ -327,6 +327,10 @@ class Context:
         """the same between processes of one host (a file under /dev/shm)"""
         self._ck(self.lib.cice_comm_init_shm(self.h, name.encode(), rank, nranks, C.c_longlong(box_bytes)))
 
+    def comm_init_mirror(self, rank, nranks):
+        """timing aid: this context is rank `rank` of `nranks`, alone on its device; its messages come back to it"""
+        self._ck(self.lib.cice_comm_init_mirror(self.h, rank, nranks))
+
     def comm_count(self):
         """ranks of this context's communicator as RCCL counts them (0 before comm_init)"""
         n = C.c_int(0)

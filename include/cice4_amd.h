@@ -132,6 +132,12 @@ int cice_comm_init_local(cice_ctx *ctx, int link_id, int rank, int nranks);
  * ranks; rank 0 creates it, the others wait for it.  For running a multi-process job (bench.py --gpus N with all ranks on
  * one device, the MPI build of the Fortran driver) on a box with one GPU.  Tests only. */
 int cice_comm_init_shm(cice_ctx *ctx, const char *name, int rank, int nranks, long long box_bytes);
+/* TIMING AID, not a communicator: this context is rank `rank` of an `nranks`-rank decomposition and is ALONE -- every
+ * message it would send to a neighbour comes back as the message it would receive from that neighbour, device to device.
+ * The rank runs the kernels, tile lists, pack / unpack and launch sequence of the nranks-rank job with nobody else on the
+ * chip: what one GPU of a node would spend per subcycle, minus the link (no counterpart in the reference; DESIGN.md
+ * section 7, bench.py --as-rank).  The fields it computes are those of a mirror boundary and mean nothing. */
+int cice_comm_init_mirror(cice_ctx *ctx, int rank, int nranks);
 /* ranks of the communicator as RCCL counts them (ncclCommCount; = MPI_COMM_SIZE of mpi/ice_communicate.F90:109-136);
  * 0 before cice_comm_init */
 int cice_comm_count(cice_ctx *ctx, int *nranks);
@@ -498,8 +504,12 @@ int cice_debug_balance_strip(int rows, int n, const int32_t *ends, const double 
  * CONTRACT (the caller's statement, as for cice_evp_adopt_thermo_state): between the START of a cice_evp call and the
  * transport call that follows it, nothing writes to the seven state arrays, and uvel, vvel, aicen, vicen are the arrays
  * cice_evp was given -- true for step_dynamics of every driver under drivers/.  A transport call that does not follow a
- * cice_evp call (or is given other arrays) uploads as usual.  fields = NULL ends the chain.  The Fortran drop-in sets it up
- * in init_transport when CICE4_AMD_CHAIN=1 is in the environment. */
+ * cice_evp call (or is given other arrays) uploads as usual: the library enforces "follows": only a cice_evp call that
+ * RETURNED CICE_OK arms the chain, and every other entry that touches or implies a newer host state (cice_evp_upload /
+ * _prepare / _subcycles / _finish / _step, cice_evp_adopt_thermo_state, every cice_thermo_* / cice_step_therm1* entry,
+ * cice_transport_upwind, a failed cice_transport_remap) disarms it.  fields = NULL ends the chain.  The Fortran drop-in
+ * sets it up on its FIRST transport_remap call (the first step's evp is therefore unchained) when CICE4_AMD_CHAIN=1 is in
+ * the environment. */
 int cice_transport_chain(cice_ctx *ctx, const cice_transport_fields *fields);
 /* advection = 'upwind' (source/ice_transport_driver.F90:672-834 transport_upwind with state_to_work :1570, upwind_field
  * :1796, work_to_state :1686 and compute_tracers, source/ice_itd.F90:1482): first-order donor-cell transport of aice0, of

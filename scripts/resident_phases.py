@@ -13,8 +13,11 @@ from cice4_amd import synth
 NAMES = ["stress (LDS reads, wave shifts, 460 fp64 instructions)", "barrier (C): str rows of the wavefront above", "momentum",
          "edge stores issued (agent scope)", "stores drained (s_waitcnt vmcnt(0))", "barrier (D)",
          "progress word + poll of the producers' words + barrier (E)", "agent-scope loads of the exchanged velocities (drained)"]
+NAMES_G = ["row below seen in LDS + stress", "str row of the wavefront above seen in LDS", "momentum, granule stores issued, row posted",
+           "first pass of the poll", "PASSES of the poll (a count, not cycles)", "TICKS of 10 ns from the store of lane 0's granules to their arrival (not cycles)",
+           "rest of the poll of the granules this wavefront needs", "(top of the loop)"]
 rows = []
-for W, dense in ((0, 1), (11, 0)):
+for W, dense, gran in ((0, 1, 1), (0, 1, 0), (11, 0, 1), (12, 0, 1), (11, 0, 0)):
     ctx = lib.Context(device=0)
     nxg, nyg, ndte = 320, 384, 120
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
@@ -22,6 +25,7 @@ for W, dense in ((0, 1), (11, 0)):
     state = synth.evp_state(grid, dom, cover="full")
     ctx.evp_init(grid, ndte=ndte)
     ctx.evp_set_option("use_graph", 0); ctx.evp_set_option("resident_waves", W); ctx.evp_set_option("resident_dense", dense)
+    ctx.evp_set_option("resident_granules", gran)
     ctx.evp_upload(state); ctx.evp_prepare(3600.0)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 2.0:
@@ -38,9 +42,9 @@ for W, dense in ((0, 1), (11, 0)):
     ghz = np.median((st[ok, 1] - st[ok, 0]) / (st[ok, 3] - st[ok, 2]) * 0.1)
     per = ph[ok] / ndte                      # cycles per subcycle
     tot = per.sum(axis=1)
-    print(f"gx1, W = {ctx.evp_get_info('resident_waves')}, dense {ctx.evp_get_info('resident_dense')}: {ok.sum()} workgroups, step {ms * 1e3:.1f} us "
+    print(f"gx1, W = {ctx.evp_get_info('resident_waves')}, dense {ctx.evp_get_info('resident_dense')}, granules {gran}: {ok.sum()} workgroups, step {ms * 1e3:.1f} us "
           f"= {ms * 1e3 / ndte:.2f} us per subcycle (with the stamps and the extra drain), clock {ghz:.3f} GHz; per subcycle, median over workgroups:")
-    for i, n in enumerate(NAMES):
+    for i, n in enumerate(NAMES_G if gran else NAMES):
         med = np.median(per[:, i])
         print(f"   {i}: {med:8.0f} cycles = {med / ghz / 1e3:6.3f} us  (p10 {np.percentile(per[:, i], 10):7.0f}, p90 {np.percentile(per[:, i], 90):7.0f})  {n}")
         rows.append((ctx.evp_get_info('resident_waves'), dense, i, n, med, med / ghz / 1e3))

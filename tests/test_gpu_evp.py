@@ -884,22 +884,27 @@ def test_whole_loop_in_one_launch(ctx, orc, nxg, nyg, ew, ns):
             orc.set_strength_parameters()
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
-        # (W, dense): at gx1 size the default is "dense" -- three 4-wavefront workgroups on every CU
-        for W, dense in (((0, 1), (4, 1), (0, 0), (8 if nxg == 250 else 11, 0), (12, 0)) if big else
-                         ((0, 1), (4, 1), (6, 1), (8, 1), (11, 1), (12, 1))):
+        # (W, dense, granules): at gx1 size the default is "dense" -- three 4-wavefront workgroups on every CU; the edge
+        # velocities travel as data-tagged granules (round 5, the default) or behind progress words (granules = 0)
+        for W, dense, gran in (((0, 1, 1), (0, 1, 0), (4, 1, 1), (0, 0, 1), (8 if nxg == 250 else 11, 0, 1), (12, 0, 1), (12, 0, 0)) if big else
+                               ((0, 1, 1), (0, 1, 0), (4, 1, 1), (6, 1, 1), (8, 1, 0), (8, 1, 1), (11, 1, 1), (12, 1, 1))):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
-            ctx.evp_set_option("resident_dense", dense)
+            ctx.evp_set_option("resident_dense", dense); ctx.evp_set_option("resident_granules", gran)
             assert ctx.evp_get_info("resident") == 1, (W, dense, "grid should fit")
-            assert ctx.evp_get_info("resident_dense") == (1 if big and dense else 0)
+            # the granule loop runs with ONE workgroup per CU (its automatic shape where one fits); three workgroups per CU keep
+            # the progress words
+            is_dense = 1 if big and dense and (W == 4 or not gran) else 0
+            assert ctx.evp_get_info("resident_granules") == (1 if gran and not is_dense else 0)
+            assert ctx.evp_get_info("resident_dense") == is_dense
             if big and W == 0:
-                assert ctx.evp_get_info("resident_waves") == (4 if dense else (6 if nxg == 250 else 11))
+                assert ctx.evp_get_info("resident_waves") == (4 if is_dense else (6 if nxg == 250 else 11))
             ctx.evp(DT, sg)
-            assert ctx.evp_get_info("resident") == 1 and ctx.evp_get_info("resident_dense") == (1 if big and dense else 0), \
+            assert ctx.evp_get_info("resident") == 1 and ctx.evp_get_info("resident_dense") == is_dense, \
                 "the resident loop timed out and fell back"
             for k in keys:
-                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, dense, k)
+                assert np.array_equal(sg[k], ref[k]), (ndte, damping, W, dense, gran, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
     # a loop cut into ranges: 1..5 (one launch), 6 (single subcycle: the ordinary kernel), 7..NDTE
     b = {k: v.copy() for k, v in s.items()}
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
@@ -1143,7 +1148,8 @@ def test_tripole_fold_inside_the_loop_against_the_compiled_reference(ns):
     assert p.returncode == 0 and "TRIPOLE-EVP-OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
-def test_resident_loop_is_repeatable(ctx):
+@pytest.mark.parametrize("gran", [1, 0], ids=["granules", "progress-words"])
+def test_resident_loop_is_repeatable(ctx, gran):
     """300 one-launch loops (36,000 subcycles, 768 tiles, ~90 exchanged velocities per tile and subcycle) from the same
     state: every call must return the bits of the first one, which are those of the launch-per-pair loop.  A hand-off
     that once in a while let a stale velocity through would show here: one wrong ulp grows to 1e-2 within a step."""
@@ -1154,8 +1160,8 @@ def test_resident_loop_is_repeatable(ctx):
     s = synth.evp_state(grid, dom, seed=8, cover="patchy")
     ref, _ = _evp_with(ctx, grid, s, NDTE, False, fuse=1, resident=0)
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
-    ctx.evp_set_option("resident", 2)
-    assert ctx.evp_get_info("resident_dense") == 1
+    ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_granules", gran)
+    assert ctx.evp_get_info("resident_dense") == 1 - gran and ctx.evp_get_info("resident_granules") == gran
     ctx.evp_upload({k: v.copy() for k, v in s.items()})
     out = {k: np.empty_like(v) for k, v in s.items()}
     for rep in range(300):
@@ -1175,11 +1181,13 @@ def test_resident_loop_is_repeatable(ctx):
     assert ctx.evp_get_info("resident") == 1
 
 
-def test_resident_loop_gives_up_cleanly(ctx, orc):
+@pytest.mark.parametrize("gran", [1, 0], ids=["granules", "progress-words"])
+def test_resident_loop_gives_up_cleanly(ctx, orc, gran):
     """A tile of the one-launch loop that does not hear from a neighbour in time raises the abort word, every
     workgroup leaves, and the caller's state is as it was: the range is then run by the launch-per-pair loop.  With
-    resident_spin_us = 0 every wait fails: the dense shape (gx1 size) falls back to one workgroup per CU for the next
-    call, that one falls back for good -- and all three calls give the bits of the ordinary loop."""
+    resident_spin_us = 0 every wait fails: the dense shape (gx1 size, progress words) falls back to one workgroup per CU
+    for the next call, that one falls back for good -- and all three calls give the bits of the ordinary loop.  The granule
+    loop starts with one workgroup per CU and falls back for good at once."""
     nxg, nyg = 320, 384
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
     gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=5)
@@ -1187,8 +1195,8 @@ def test_resident_loop_gives_up_cleanly(ctx, orc):
     s = synth.evp_state(grid, dom, seed=3, cover="patchy")
     ref, _ = _evp_with(ctx, grid, s, 12, False, fuse=1, resident=0)
     ctx.evp_init(grid, ndte=12, krdg_partic=0, krdg_redist=0)
-    ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_spin_us", 0)
-    want = [(1, 1, 4), (1, 0, 11), (0, 0, None)]            # (resident, dense, waves) before each call
+    ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_spin_us", 0); ctx.evp_set_option("resident_granules", gran)
+    want = [(1, 0, 11), (0, 0, None), (0, 0, None)] if gran else [(1, 1, 4), (1, 0, 11), (0, 0, None)]   # (resident, dense, waves) before each call
     for call in range(3):
         assert (ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")) == want[call][:2], call
         if want[call][2]:
@@ -1197,11 +1205,11 @@ def test_resident_loop_gives_up_cleanly(ctx, orc):
         ctx.evp(DT, sg)
         for k in EVP_OUT_FIELDS + ("iceumask",):
             assert np.array_equal(sg[k], ref[k]), (call, k)
-    ctx.evp_set_option("resident_spin_us", 200000); ctx.evp_set_option("resident", 2)    # forgiven: dense again, and it works
-    assert (ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")) == (1, 1)
+    ctx.evp_set_option("resident_spin_us", 200000); ctx.evp_set_option("resident", 2)    # forgiven: the first shape again, and it works
+    assert (ctx.evp_get_info("resident"), ctx.evp_get_info("resident_dense")) == (1, 1 - gran)
     sg = {k: v.copy() for k, v in s.items()}
     ctx.evp(DT, sg)
-    assert ctx.evp_get_info("resident_dense") == 1
+    assert ctx.evp_get_info("resident_dense") == 1 - gran
     for k in EVP_OUT_FIELDS + ("iceumask",):
         assert np.array_equal(sg[k], ref[k]), ("after", k)
 
@@ -1216,6 +1224,7 @@ def test_resident_loop_is_tried_again_later(ctx):
     ref, _ = _evp_with(ctx, grid, s, 12, False, fuse=1, resident=0)
     ctx.evp_init(grid, ndte=12, krdg_partic=0, krdg_redist=0)
     ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_retry_steps", 2); ctx.evp_set_option("resident_spin_us", 0)
+    ctx.evp_set_option("resident_granules", 0)     # (the dense shape and its fall-back to one workgroup per CU: progress words)
     seen = []
     for call in range(4):
         sg = {k: v.copy() for k, v in s.items()}

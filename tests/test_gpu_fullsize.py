@@ -261,3 +261,80 @@ def test_tenth_degree_width_tripole_grid_on_two_ranks(ctx, ns):
             want = s1[k][0, 1 + g0:1 + g0 + (ohi - olo + 1), 1:-1]
             assert np.array_equal(got, want), (ns, k, r, np.argwhere(got != want)[:5].tolist())
 
+
+
+# ---- BASELINE.json configs[3] and configs[4]: EIGHT ranks -----------------------------------------------------------------
+# Eight ranks = eight contexts of this process on the one GPU, one host thread each (tests/ranks_case.py; the GPU boxes
+# admit six processes on a card).  What never ran before round 5: interior ranks with two neighbours at both sizes,
+# 48-row slabs under bench.auto_overlap's H, eight one-launch loops joined edge to edge, the sweep's tile lists with the
+# extension trimmed on BOTH edges (Evp::tiles_for).
+
+@pytest.mark.parametrize("mode", ["classic", "peer", "slabs", "slabs-sweep"])
+def test_gx1_on_eight_ranks(orc, mode):
+    """gx1 320 x 384, ndte 120, as 8 j-slabs of 48 rows (configs[3]) against the checker on the whole grid, bit for bit on
+    every owned cell of u, v, the 12 stresses and the diagnostics:
+      classic      one slab per rank, ghost rows exchanged after every subcycle (what the Fortran drop-in does under MPI,
+                   /root/reference/mpi/ice_boundary.F90:1028-1417);
+      peer         the whole subcycle loop in ONE launch per rank, tiles on a slab's first / last rows store their edge
+                   velocities into the neighbour's exchange copies (6 interior ranks with two neighbours each);
+      slabs        what `bench.py --gpus 8` runs at gx1: wide-halo slabs with bench.auto_overlap's H (24 rows of overlap on
+                   48 owned ones), pairs of subcycles per launch, one refresh of u, v, 12 stresses every H subcycles;
+      slabs-sweep  the 0.1-degree configuration's code path at gx1 size: H = 8, K = 4 sweeps over tile lists."""
+    import importlib
+    import ranks_case
+    bench = importlib.import_module("bench")
+    nxg, nyg, R, ndte = 320, 384, 8, 120
+    gg = synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.03, seed=31)
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, ndte, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    kw = {}
+    if mode == "slabs":
+        H = bench.auto_overlap(nxg, nyg // R)
+        assert H == 24
+        kw = dict(overlap=H)
+    elif mode == "slabs-sweep":
+        kw = dict(overlap=8, skew_k=4, min_cells=0, split=0)
+    out = ranks_case.run_ranks(gg, R, mode.split("-")[0], ndte, DT, seed=31, cover="patchy", **kw)
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in PRIMARY + ("divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig"):
+        want, got = ranks_case.owned(one, s1[k]), ranks_case.assemble(out, k, nxg, nyg)
+        assert np.array_equal(got, want), (mode, k, np.argwhere(got != want)[:5].tolist())
+    assert np.abs(s1["uvel"]).max() > 0.01
+
+
+@pytest.mark.parametrize("split", [0, 1], ids=["one-launch", "refresh-beside-interior"])
+def test_tenth_degree_on_eight_ranks(orc, split):
+    """0.1 degree 3600 x 2400 as 8 wide-halo slabs of 300 rows (configs[4]'s decomposition: H = 8 overlap rows, K = 4 sweeps,
+    refresh of u, v and the 12 stresses every 8 subcycles in one message per neighbour), ndte = 8 -- one sweep after a refresh
+    and one in front of the next, i.e. both tile lists of Evp::tiles_for on top, bottom and interior ranks -- against the
+    checker on the whole grid, bit for bit on every owned cell.  (ndte = 240 on one rank's slab against the checker:
+    test_tenth_degree_rank_slab_against_checker; the 24-hour run: test_tenth_degree_24_hours.)"""
+    import importlib
+    import ranks_case
+    bench = importlib.import_module("bench")
+    nxg, nyg, R, ndte = 3600, 2400, 8, 8
+    assert bench.auto_overlap(nxg, nyg // R) == 8
+    gg = synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.02, seed=31)
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="full")
+    orc.set_evp_parameters(DT, ndte, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    del grid1
+    info = {}
+    out = ranks_case.run_ranks(gg, R, "slabs", ndte, DT, seed=31, cover="full", overlap=8, skew_k=4, split=split, info=info, timeout=900)
+    assert info["skew"] == 1 and info["skew_levels"] == 4
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in PRIMARY + ("divu", "shear", "prs_sig", "strintx"):
+        want, got = ranks_case.owned(one, s1[k]), ranks_case.assemble(out, k, nxg, nyg)
+        assert np.array_equal(got, want), (split, k, np.argwhere(got != want)[:5].tolist())
+    assert 1e-4 < np.abs(s1["uvel"]).max() < 5.0
