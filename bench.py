@@ -650,6 +650,31 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     return out
 
 
+KERNEL_SOURCES = ("evp.hip", "evp.h", "therm.hip", "therm.h", "common.h", "libm_exact.h")
+
+
+def kernel_source_sha():
+    """Hash of the sources the EVP / thermo kernels are compiled from.  The archived counter passes under profiles/ carry the
+    hash of the tree they were taken from (scripts/profiles_r05.py); a pass whose hash differs from this tree's describes
+    OTHER kernels: the line then says `counters_stale: true` (tests/test_profiles.py holds the committed tree to it)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cice4_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+STALE = []      # archived passes used by this run whose source hash is not this tree's
+
+
+def _fresh(row, path):
+    ok = row.get("source_sha", "") == kernel_source_sha()
+    if not ok and path not in STALE:
+        STALE.append(path)
+    return ok
+
+
 def pmc_traffic(workload, kernel_substr):
     """HBM bytes per launch of a kernel from an ARCHIVED rocprofv3 PMC pass (profiles/r0N_pmc_hbm_traffic*.csv:
     separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled as MI355X_MICROARCH.md
@@ -661,7 +686,9 @@ def pmc_traffic(workload, kernel_substr):
         try:
             for row in csv.DictReader(open(path)):
                 if row["workload"] == workload and kernel_substr in row["kernel"]:
-                    return float(row["total_MB_per_launch"]) * 1e6, "archived PMC pass " + os.path.relpath(path, ROOT)
+                    rel = os.path.relpath(path, ROOT)
+                    return float(row["total_MB_per_launch"]) * 1e6, ("archived PMC pass " + rel +
+                                                                     ("" if _fresh(row, rel) else " (STALE: taken from other kernel sources)"))
         except (OSError, KeyError):
             continue
     return None, None
@@ -678,8 +705,9 @@ def inkernel_clock(workload):
         try:
             for row in csv.DictReader(open(path)):
                 if row["workload"] == workload:
-                    return float(row["clock_ghz_median"]), ("archived in-kernel stamps " + os.path.relpath(path, ROOT) +
-                                                             " (commit " + row.get("commit", "?") + ")")
+                    rel = os.path.relpath(path, ROOT)
+                    return float(row["clock_ghz_median"]), ("archived in-kernel stamps " + rel + " (commit " + row.get("commit", "?") + ")" +
+                                                             ("" if _fresh(row, rel) else " (STALE: taken from other kernel sources)"))
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -696,8 +724,9 @@ def pmc_counters(workload, kernel_substr):
                 name = row.get("kernel") or row.get("kernel (gx1)") or ""
                 if kernel_substr in name and row.get("workload", workload) == workload and row.get("subcycles_per_launch"):
                     per_wave = float(row["VALU_instr_per_wave"])
+                    rel = os.path.relpath(path, ROOT)
                     out = {"valu_per_wave_subcycle": per_wave / float(row["subcycles_per_launch"]),
-                           "source": "archived SQ pass " + os.path.relpath(path, ROOT)}
+                           "source": "archived SQ pass " + rel + ("" if _fresh(row, rel) else " (STALE: taken from other kernel sources)")}
                     if row.get("SQ_INSTS_VALU") and row.get("launches"):
                         out["valu_insts_per_launch"] = float(row["SQ_INSTS_VALU"]) / float(row["launches"])
                     if row.get("commit"):
@@ -955,10 +984,13 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     if peer_verified and not (resident and ctx.evp_get_info("resident_peer") == 1):
         progress(f"{wl}: the cross-rank loop fell back during the timed steps")
         raise SystemExit(22)
-    if resident and ctx.evp_get_info("resident_waves") != rw:     # dense shape gave way to one workgroup per CU
+    if resident and ctx.evp_get_info("resident_waves") != rw:     # the library changed the shape while the steps ran
         rw = ctx.evp_get_info("resident_waves")
+        dense = bool(ctx.evp_get_info("resident_dense"))
         tile = (f"whole subcycle loop in one launch, state in registers; workgroup = {rw} wavefronts x 64 lanes "
-                f"(owns {rw - 1} rows x 63 columns), one workgroup per CU (the dense shape timed out on this box)")
+                f"(owns {rw - 1} rows x 63 columns), " +
+                ("three workgroups per CU (chosen after the first step: the ice cover leaves most tiles empty)" if dense
+                 else "one workgroup per CU (the dense shape timed out on this box)"))
     n_step, main_sub = launches_per_step(ndte, fused, dom.get("overlap", 0), 0 if resident else skew_k)
     n_launch = steps if resident else n_step * steps
     us_per_launch = dev_ms * 1e3 / n_launch
@@ -1339,6 +1371,11 @@ def main():
             out["calibration"] = calib
         if pcie:
             out["pcie_inclusive"] = pcie
+        # the archived counter passes this line quotes (traffic, VALU counts, in-kernel clock): do they describe THIS tree's kernels?
+        out["counters_stale"] = bool(STALE)
+        out["counters"] = {"kernel_source_sha": kernel_source_sha(), "stale_sources": list(STALE),
+                           "note": "traffic, frac_valu_issue and clock_ghz come from archived rocprofv3 passes under profiles/ "
+                                   "(not measured in this run); stale: taken from kernel sources other than this tree's"}
         if world == 1 and not args.no_cpu_baseline:
             progress("cpu baseline (child process)")
             cb = run_cpu_baseline(args)

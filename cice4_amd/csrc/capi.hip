@@ -894,6 +894,11 @@ int cice_evp_get_info(cice_ctx* ctx, const char* key, int* value) {
   else if (!std::strcmp(key, "resident_peer")) *value = c_->evp->can_reside_peer() ? 1 : 0;
   else if (!std::strcmp(key, "last_launches")) *value = c_->evp->last_launches;
   else if (!std::strcmp(key, "resident_peer_fine")) *value = c_->evp->peer_buffers_fine() ? 1 : 0;
+#ifdef CICE4_AMD_EXPERIMENTS
+  else if (!std::strcmp(key, "experiments")) *value = 1;
+#else
+  else if (!std::strcmp(key, "experiments")) *value = 0;     // (the variants measured slower are not in this build: evp.hip)
+#endif
   else if (!std::strcmp(key, "resident_granules")) *value = c_->evp->granules_in_use() ? 1 : 0;
   else if (!std::strcmp(key, "resident_waves")) *value = c_->evp->resident_waves();
   else if (!std::strcmp(key, "resident_dense")) *value = c_->evp->can_reside() && c_->evp->resident_dense() ? 1 : 0;
@@ -910,6 +915,34 @@ int cice_evp_peer_export(cice_ctx* ctx, void* bufs[3], long long* plane) {
 }
 int cice_evp_peer_connect(cice_ctx* ctx, int side, void* xu0, void* xu1, void* rprog, long long plane) {
   CICE_TRY(ctx) NEED_EVP; c_->evp->peer_connect(side, xu0, xu1, rprog, plane); CICE_CATCH
+}
+// Any cartesian layout with one block per rank (round 5): the ranks this rank's block exchanges ghost cells with, and the
+// connection of one of them by its rank.
+int cice_evp_peer_ranks(cice_ctx* ctx, int* n, int32_t ranks[8]) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(n && ranks, "NULL argument");
+  const std::vector<int> v = c_->evp->peer_ranks();
+  CICE_REQUIRE(v.size() <= 8, "cice_evp_peer_ranks: more than eight neighbouring ranks");
+  *n = (int)v.size();
+  for (size_t k = 0; k < v.size(); ++k) ranks[k] = v[k];
+  CICE_CATCH
+}
+int cice_evp_peer_connect_rank(cice_ctx* ctx, int rank, void* xu0, void* xu1, void* rprog, long long plane) {
+  CICE_TRY(ctx) NEED_EVP; c_->evp->peer_connect_rank(rank, xu0, xu1, rprog, plane); CICE_CATCH
+}
+int cice_evp_peer_connect_rank_ipc(cice_ctx* ctx, int rank, const char handles[3][64], long long plane) {
+  CICE_TRY(ctx)
+  NEED_EVP;
+  CICE_REQUIRE(handles, "NULL argument");
+  void* p[3];
+  for (int k = 0; k < 3; ++k) {
+    hipIpcMemHandle_t h;
+    std::memcpy(&h, handles[k], 64);
+    CICE_HIP(hipIpcOpenMemHandle(&p[k], h, hipIpcMemLazyEnablePeerAccess));
+  }
+  c_->evp->peer_connect_rank(rank, p[0], p[1], p[2], plane);
+  CICE_CATCH
 }
 // The same buffers as IPC handles (3 x 64 bytes) for a neighbour in ANOTHER process, and their opening on the other
 // side.  (Across processes / GPUs; not exercised on the one-GPU test boxes, where two contexts of one process exchange

@@ -49,6 +49,8 @@ class Evp {
   bool can_reside_peer() const;  // the same on one slab of a domain cut across ranks, neighbours' buffers mapped (peer_connect)
   void peer_export(void* out[3]);  // this rank's exchange copies and remote-progress words (device pointers)
   void peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n);
+  void peer_connect_rank(int rank, void* xu0, void* xu1, void* rprog, long long peer_n);   // any neighbouring rank (cartesian layouts)
+  std::vector<int> peer_ranks() const;   // the ranks this rank's block exchanges ghost cells with, ascending
   int resident_waves() const;  // its wavefronts per workgroup (0: grid too large)
   // device copies the transport may take over right after evp(dt) (cice_transport_chain): u | v of the current state,
   // aicen, vicen as uploaded (host layout)
@@ -160,7 +162,8 @@ class Evp {
   int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
   int res_occ[5][2][4] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN), 0 = not asked yet
-  bool res_gran = true;          // one-rank domains without a fold: edge velocities travel as data-tagged granules (option "resident_granules")
+  int res_gran = 1;              // one-rank domains without a fold: edge velocities travel as data-tagged granules (option "resident_granules": 0 never, 1 by the ice cover, 2 always)
+  bool res_sparse = false;       // the last step's ice cover left most tiles of the loop empty (run_resident reads k_res_choose_map's count)
   bool granules_on() const;
   DevBuf<int32_t> res_src;       // [cells] the owned U-cell whose velocity a cell holds, -1: nobody's
   DevBuf<double> res_xg;         // [2][cells][4] the granule copies (32 bytes per cell and parity)
@@ -185,7 +188,8 @@ class Evp {
   DevBuf<double> res_xraw[2];
   void build_resident_peer(int W);
   void peer_alloc();
-  struct Peer { double* xu[2] = {nullptr, nullptr}; unsigned* rprog = nullptr; unsigned n = 0; } peers[2];
+  struct Peer { double* xu[2] = {nullptr, nullptr}; unsigned* rprog = nullptr; unsigned n = 0; } peers[8];   // by place in peer_ranks()
+  std::vector<int> peer_back = std::vector<int>(8, 0);   // this rank's place in neighbour s's own list of neighbours
   DevBuf<int32_t> res_rslot, res_rfwd, res_pub;
   DevBuf<unsigned> res_rprog;    // [2 sides][RP_MAX tiles][RES_STRIDE]: progress of the neighbours' tiles, written by them
   bool res_peer_built = false, res_peer_agree = true;

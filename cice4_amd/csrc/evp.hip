@@ -270,18 +270,6 @@ __device__ __forceinline__ double down1(double x) {
   return __hiloint2double(hi, lo);
 }
 
-#ifndef SKEW_NT
-#define SKEW_NT 0
-#endif
-__device__ __forceinline__ double ld8nt(const double* p, unsigned off) {
-  return __builtin_nontemporal_load((const double*)((const char*)p + off));
-}
-__device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
-  __builtin_nontemporal_store(v, (double*)((char*)p + off));
-}
-#ifndef SKEW_FAKE_SIGMA_LOAD
-#define SKEW_FAKE_SIGMA_LOAD 0
-#endif
 #ifndef SKEW_OPAQUE_STRIDE
 #define SKEW_OPAQUE_STRIDE 1
 #endif
@@ -297,7 +285,12 @@ __device__ __forceinline__ void st8nt(double* p, unsigned off, double v) {
 #ifndef SKEW_WIDE        // the read-only inputs of a step come interleaved: 16-byte loads, 7 instead of 14 per level and step
 #define SKEW_WIDE 1
 #endif
-#ifndef SKEW_EARLY       // a third slot for the hand-off of level 0: its stresses of the NEXT row are fetched before the barrier
+// Variants that were built, are bit-exact, measured SLOWER and are therefore not part of the product build: compile with
+// -DCICE4_AMD_EXPERIMENTS to get them back (scripts/build_ab.sh; the numbers are in DESIGN.md section 3.2 / HISTORY.md) --
+// three wavefronts per level in one 12-wavefront workgroup (S = 3), K = 5, 6, 8, two wavefronts per SIMD at K = 4, and
+// SKEW_EARLY: a third slot for the hand-off of level 0, its stresses of the NEXT row fetched before the barrier.
+#if !defined(CICE4_AMD_EXPERIMENTS) || !defined(SKEW_EARLY)
+#undef SKEW_EARLY
 #define SKEW_EARLY 0
 #endif
 // The same shifts with bound_ctrl: the lane without a source (lane 0 / lane 63) reads zero instead of keeping its own
@@ -1289,12 +1282,6 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
     }
     // ... and, youngest, the stresses of this row: whoever waits for them waits for everything, which has arrived by then
     if (act) {
-#if SKEW_FAKE_SIGMA_LOAD   // timing experiment only (wrong results): what the sweep costs if level 0 never waits for memory
-      if (k == 0) {
-#pragma unroll
-        for (int c = 0; c < 12; ++c) s[c] = s_sig[0][r & 1][c][lx];
-      } else {
-#else
       if (k == 0) {
         if (PIN) {
           size_t ps2 = n16;
@@ -1313,7 +1300,7 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
           const char* ps = (const char*)u_in + 2 * pstride;
 #pragma unroll
           for (int c = 0; c < 12; ++c) {
-            s[c] = SKEW_NT ? ld8nt((const double*)ps, q) : ld8((const double*)ps, q);
+            s[c] = ld8((const double*)ps, q);
             ps += pstride;
           }
         }   // (EARLY: fetched at the end of the previous step)
@@ -1321,7 +1308,6 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
 #pragma unroll
         for (int c = 0; c < 12; ++c) s[c] = s_sig0[r3][c][lx];
       } else {
-#endif
 #pragma unroll
         for (int c = 0; c < 12; ++c) s[c] = s_sig[EARLY ? k - 2 : k - 1][r & 1][c][cw];
       }
@@ -1413,8 +1399,7 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
             char* po = (char*)s_out + 2 * pstride;
 #pragma unroll
             for (int c = 0; c < 12; ++c) {
-              if (SKEW_NT) st8nt((double*)po, q, s[c]);
-              else st8((double*)po, q, s[c]);
+              st8((double*)po, q, s[c]);
               po += pstride;
             }
           }
@@ -1549,6 +1534,7 @@ __global__ __launch_bounds__(64 * K * S, (S == 1 ? WS : 1)) void k_subcycle_skew
 // raised, every workgroup leaves, nothing of the caller's state has been touched (inputs are read from st[cur],
 // results go to st[1-cur] after the last subcycle) and the host falls back to the launch-per-pair loop.
 constexpr int RES_MAXDEP = 16;
+constexpr int RES_NPEER = 8;     // neighbouring ranks of a block in a cartesian layout (edges and corners)
 constexpr int RES_STRIDE = 32;   // progress words 128 B apart
 
 struct ResArgs {
@@ -1564,12 +1550,12 @@ struct ResArgs {
   // of the neighbouring ranks through the SAME protocol, the neighbour's exchange copies and progress words being
   // mapped into this address space (Evp::peer_connect): side 0 = the rank to the south, 1 = to the north
   const int32_t* rslot;  // [cells] -1: nothing; -2: a ghost cell whose source lives on another rank; >= 0: slot in rfwd
-  const int32_t* rfwd;   // [slots][4] ghost cells on other ranks that mirror a cell: (side << 30) | address, -1 padded
-  double* pxu[2][2];     // [side][parity]: the neighbour's exchange copies (v at + pn[side])
-  unsigned pn[2];        // the neighbour's plane size
-  unsigned* prp[2];      // [side]: where this rank's tiles publish their progress on the neighbour ([tile * RES_STRIDE])
+  const int32_t* rfwd;   // [slots][4] ghost cells on other ranks that mirror a cell: (neighbour << 28) | address, -1 padded
+  double* pxu[RES_NPEER][2];   // [neighbour][parity]: the neighbour's exchange copies (v at + pn[neighbour])
+  unsigned pn[RES_NPEER];      // the neighbour's plane size
+  unsigned* prp[RES_NPEER];    // [neighbour]: where this rank's tiles publish their progress on it ([tile * RES_STRIDE])
   const unsigned* rprog; // progress words the neighbours' tiles publish here: deps <= -2 index it (-2 - dep)
-  const int32_t* pub;    // [tiles] bit 0 / 1: cells of this tile are mirrored on the rank to the south / north
+  const int32_t* pub;    // [tiles] bit s: cells of this tile are mirrored on neighbour s
   // FOLD: a tripole north boundary on a one-block, one-rank domain (serial/ice_boundary.F90:705-869) for the velocity
   // (NE-corner location, vector kind).  The ghost cells the fold fills mirror, up to the sign, the final value of an owned
   // cell: they ride on rslot / rfwd (entries: (negate << 30) | address in THIS block).  The owned cells of the top row are
@@ -1591,6 +1577,7 @@ struct ResArgs {
   void* xg;              // two copies (subcycle parity) of [cells][2][2] granules {low half | tag, high half | tag} of u, then of v: 32 bytes per cell
   unsigned xg_half;      // bytes of one copy
   int poll_delay, poll_sleep;   // GRAN: s_sleep(8) units (~0.2 us each) before the first poll of a subcycle / between two polls
+  int fake_ew;                  // TIMING EXPERIMENT ONLY (wrong results): the wavefronts between the first and the last row never poll
 };
 enum { F_LO = 1, F_HI = 2, F_NEG = 4, F_SELF = 8, F_MIRROR = 16 };
 
@@ -1680,6 +1667,12 @@ __global__ __launch_bounds__(1024) void k_res_choose_map(int nt, int tiles_x, in
   }
   __syncthreads();
   if (t == 0) out[0] = force >= 0 ? force : (s_max[1] < s_max[0] ? 1 : 0);
+  // how many tiles hold ice at all (read by the host behind the loop: the NEXT evp(dt) picks its shape by it, run_resident)
+  const int cnt = __syncthreads_count(ice);
+  if (t == 0) {
+    out[1] = cnt;
+    out[2] = nt;
+  }
 }
 
 // PEER: see ResArgs.  Differences to the one-rank loop: progress runs epoch0 + 1 ("this launch has begun: its exchange
@@ -1709,7 +1702,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
   __shared__ int s_rfd[PEER ? W : 1][4][TX];   // PEER: ghost cells on other ranks mirroring this lane's cell
   int rfr[4] = {-1, -1, -1, -1};                // FOLD: ghost cells the fold fills from this lane's cell (registers: with them in LDS three
                                                 //       4-wavefront workgroups need 165 KB of a CU's 160)
-  __shared__ int s_pub[2];                      // PEER: this tile publishes to the south / north rank
+  __shared__ int s_pub[RES_NPEER];              // PEER: this tile publishes to neighbour s
   __shared__ int s_abort;
   __shared__ int s_uf[GRAN ? W : 1], s_sf[GRAN ? W : 1];   // GRAN: subcycles whose row of u | v (s_uv) / of str (s_edge) a wavefront has put into LDS
   // tiles are numbered block by block (a one-rank domain of several blocks: every block is cut into tiles_x x tiles_y
@@ -1754,8 +1747,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
   if (threadIdx.x == 0) {
     s_abort = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (PEER) {   // by geometry, whether or not the cells carry ice: the neighbour's tiles wait for this tile's progress
-      s_pub[0] = r.pub[tile] & 1;
-      s_pub[1] = (r.pub[tile] >> 1) & 1;
+      for (int sd = 0; sd < RES_NPEER; ++sd) s_pub[sd] = (r.pub[tile] >> sd) & 1;
     }
   }
   __syncthreads();
@@ -1868,6 +1860,10 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     };
     if (want_w) lend(q0g - 32u, lw, lw_a);
     if (want_q) lend(q0g - nxg - 32u, lq, lq_a);
+    if (r.fake_ew && w > 0 && w < W - 1) {   // (timing experiment: what the loop would cost if interior wavefronts had nothing to wait for)
+      nA = nB = false;
+      lw = lq = -1;
+    }
   }
   StressOut o;
   StepuOut ro{};
@@ -1881,7 +1877,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     const unsigned begun = r.epoch0 + 1u;
     if (threadIdx.x == 0)
       __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (threadIdx.x < 2 && s_pub[threadIdx.x])
+    if (threadIdx.x < RES_NPEER && s_pub[threadIdx.x])
       __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, begun, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   stamp_at(r.stamps, 0);
@@ -1909,10 +1905,20 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     // other wavefronts of its SIMD compute: the hand-off latency no longer adds to the arithmetic of three wavefronts.
     // Every wait is bounded; a wavefront that gives up raises s_abort and the abort word and every wavefront leaves.
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(r.xg, 0, 2 * r.xg_half, 0x00020000);
+    const bool prio_work = r.prio_mode >= 5;     // issue priority by what a wavefront is doing: waiting 0, computing 2 (chain rows 3 in mode 5)
+    const bool chain_hi = r.prio_mode == 5 && (w == 0 || w >= W - 2);
+    auto prio_wait = [&]() { if (prio_work) __builtin_amdgcn_s_setprio(0); };
+    auto prio_compute = [&]() {
+      if (prio_work) {
+        if (chain_hi) __builtin_amdgcn_s_setprio(3);
+        else __builtin_amdgcn_s_setprio(2);
+      }
+    };
     auto wait_row = [&](int* flag, int want) -> bool {
       long long t0 = 0;
       for (int it = 0;; ++it) {
         if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= want) break;
+        if (it == 0) prio_wait();
         if (__hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return false;
         if (it == 0) t0 = wall_clock64();
         else if ((it & 63) == 0 && wall_clock64() - t0 > 2 * r.spin_ticks) {   // (twice: whoever waits for memory reports first)
@@ -1926,6 +1932,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
         __builtin_amdgcn_s_sleep(1);
       }
       asm volatile("" ::: "memory");   // (the rows are read after the flag)
+      prio_compute();
       return true;
     };
     auto post_row = [&](int* flag, int value) {
@@ -1939,6 +1946,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
       if (chain) __builtin_amdgcn_s_setprio(3);
       else __builtin_amdgcn_s_setprio(1);
     }
+    prio_compute();
 #pragma clang loop unroll(disable)
     for (int k = 0; k < r.nsub; ++k) {
       const bool lastk = r.last && k == r.nsub - 1;
@@ -2046,6 +2054,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
       // (E) this wavefront polls the cells its own lanes need
       bool pa = nA, pb = nB;
       if (__any(pa || pb)) {
+        prio_wait();
         const long long t0 = wall_clock64();
         int it = 0;
         for (int d = 0; d < r.poll_delay; ++d) __builtin_amdgcn_s_sleep(8);
@@ -2096,6 +2105,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
           const double xu_ = __shfl(lq_a ? au : bu, lq), xv_ = __shfl(lq_a ? av : bv, lq);
           if (lx == 0) { uswh = xu_; vswh = xv_; }
         }
+        prio_compute();
       }
       TRACE(5)
       PHASE(6)       // 6: poll of the granules
@@ -2228,7 +2238,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     // (D) publish the edge velocities of subcycle k, then the progress word
     double* xu = r.xu[k & 1];
     double* xv = xu + a.n;
-    if (PEER && k == 0 && (s_pub[0] | s_pub[1])) {
+    if (PEER && k == 0 && r.pub[tile] != 0) {
       // nothing may be stored into a neighbour's exchange copies before its launch has initialised them
       if (w == 0) {
         const int dep = lx < RES_MAXDEP ? r.deps[tile * RES_MAXDEP + lx] : -1;
@@ -2279,8 +2289,8 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
         for (int c = 0; c < 4; ++c) {
           const int rf = s_rfd[w][c][lx];
           if (rf >= 0) {
-            const int side = (rf >> 30) & 1;
-            const unsigned ro = (unsigned)(rf & 0x3fffffff) * 8u;
+            const int side = (rf >> 28) & 7;
+            const unsigned ro = (unsigned)(rf & 0x0fffffff) * 8u;
             double* pu = r.pxu[side][k & 1];
             st_sys(pu, ro, un);
             st_sys(pu + r.pn[side], ro, vn);
@@ -2308,7 +2318,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     const unsigned target = r.epoch0 + (unsigned)k + (PEER ? 2u : 1u);
     if (threadIdx.x == 0)
       __hip_atomic_store(r.prog + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (PEER && threadIdx.x < 2 && s_pub[threadIdx.x])
+    if (PEER && threadIdx.x < RES_NPEER && s_pub[threadIdx.x])
       __hip_atomic_store(r.prp[threadIdx.x] + (size_t)tile * RES_STRIDE, target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // (E) wait until every producer of this tile's halo has published subcycle k
     if (w == 0) {
@@ -2933,12 +2943,13 @@ void Evp::set_option(const char* key, int value) {
     CICE_REQUIRE(value >= 0, "resident_spin_us must be >= 0");
     res_spin_us = value;
   } else if (!std::strcmp(key, "resident_prio")) {    // issue priority among the workgroups of a CU (dense shape): 0, 1, 2
-    CICE_REQUIRE(value >= 0 && value <= 4, "resident_prio must be 0 .. 4");
+    CICE_REQUIRE(value >= 0 && value <= 6, "resident_prio must be 0 .. 6");
     res_prio = value;
   } else if (!std::strcmp(key, "resident_dense")) {   // three 4-wavefront workgroups per CU where that fills the chip
     res_dense = value != 0;
-  } else if (!std::strcmp(key, "resident_granules")) {   // edge velocities as data-tagged granules (one rank, no fold); 0: progress words
-    res_gran = value != 0;
+  } else if (!std::strcmp(key, "resident_granules")) {   // edge velocities as data-tagged granules (one rank, no fold); 0: progress words,
+    CICE_REQUIRE(value >= 0 && value <= 2, "resident_granules must be 0, 1 or 2");   // 1: by the ice cover of the last step, 2: always
+    res_gran = value;
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
                  "resident_waves must be 0, 4, 6, 8, 11 or 12");
@@ -2946,8 +2957,13 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "skew")) {          // K subcycles per sweep (k_subcycle_skew) where the domain allows
     skew_on = value != 0;
   } else if (!std::strcmp(key, "skew_levels")) {   // 0 = auto
+#ifdef CICE4_AMD_EXPERIMENTS
     CICE_REQUIRE(value == 0 || value == 2 || value == 3 || value == 4 || value == 5 || value == 6 || value == 8,
                  "skew_levels must be 0, 2, 3, 4, 5, 6 or 8");
+#else
+    CICE_REQUIRE(value == 0 || value == 2 || value == 3 || value == 4,
+                 "skew_levels must be 0, 2, 3 or 4 (5, 6, 8: measured slower, in -DCICE4_AMD_EXPERIMENTS builds only)");
+#endif
     skew_k_opt = value;
   } else if (!std::strcmp(key, "skew_stagger_ns")) {   // start delay between the workgroups that share a CU
     CICE_REQUIRE(value >= 0 && value <= 100000, "skew_stagger_ns must be 0 .. 100000");
@@ -2978,7 +2994,11 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "skew_split")) {  // the sweep in front of a wide-halo refresh as edge + interior launches
     split_on = value != 0;
   } else if (!std::strcmp(key, "skew_subs")) {    // wavefronts per level of the sweep kernel: 3 (default shape) or 1
+#ifdef CICE4_AMD_EXPERIMENTS
     CICE_REQUIRE(value == 1 || value == 3, "skew_subs must be 1 or 3");
+#else
+    CICE_REQUIRE(value == 1, "skew_subs must be 1 (3: measured slower, in -DCICE4_AMD_EXPERIMENTS builds only)");
+#endif
     skew_subs_opt = value;
     std::memset(strips_cache, 0, sizeof(strips_cache));
     tile_tabs.clear();
@@ -2993,7 +3013,11 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "skew_prio")) {   // rotate issue priorities among the workgroups of a CU
     skew_prio = value;
   } else if (!std::strcmp(key, "skew_blocks")) {   // 0 = default: workgroups per CU the sweep kernel is built for
+#ifdef CICE4_AMD_EXPERIMENTS
     CICE_REQUIRE(value >= 0, "skew_blocks must be >= 0");
+#else
+    CICE_REQUIRE(value == 0 || value == 3, "skew_blocks must be 0 or 3 (2: in -DCICE4_AMD_EXPERIMENTS builds only)");
+#endif
     skew_blocks_opt = value;
   } else if (!std::strcmp(key, "skew_seg_rows")) { // 0 = auto: rows a workgroup owns
     CICE_REQUIRE(value >= 0, "skew_seg_rows must be >= 0");
@@ -3573,7 +3597,12 @@ int Evp::skew_levels() const { return skew_k_opt ? skew_k_opt : 4; }
 int Evp::skew_subs(int K) const {
   static const int env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_SUBS"); return e ? std::atoi(e) : 0; }();
   const int want = env ? env : skew_subs_opt;
+#ifdef CICE4_AMD_EXPERIMENTS
   return (K == 4 && skew_waves_per_simd(4) == 3 && want == 3) ? 3 : 1;
+#else
+  (void)want; (void)K;
+  return 1;
+#endif
 }
 
 // Is the column layout of the sweep kernel right for a ring of ncol + 1 positions (0 = ilo ... ncol - 1 = ihi, ncol = G)?
@@ -3994,6 +4023,7 @@ void Evp::balance_after_sweep(hipStream_t s) {
   if (bal_left > 0) --bal_left;
 }
 
+#ifdef CICE4_AMD_EXPERIMENTS
 template <bool PAIRS>
 static void launch_skew_s3(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s) {
   const dim3 blk(64 * 4 * 3);
@@ -4005,16 +4035,20 @@ static void launch_skew_s3(const SkewArgs& sa, bool last, bool damp, dim3 g, hip
     else hipLaunchKernelGGL((k_subcycle_skew<4, false, false, 3, PAIRS, 3>), g, blk, 0, s, sa);
   }
 }
+#endif
 
 template <int K, int WS>
 static void launch_skew_kb(const SkewArgs& sa, bool last, bool damp, dim3 g, hipStream_t s, bool pairs = false, int subs = 1) {
   const dim3 blk(64 * K);
   if constexpr (K == 4 && WS == 3) {
+#ifdef CICE4_AMD_EXPERIMENTS
     if (subs == 3) {   // twelve wavefronts per workgroup: three per level, side by side
       if (pairs) launch_skew_s3<true>(sa, last, damp, g, s);
       else launch_skew_s3<false>(sa, last, damp, g, s);
       return;
     }
+#endif
+    (void)subs;
     if (pairs) {   // (the pair layout is built for the default shape only)
       if (last) {
         if (damp) hipLaunchKernelGGL((k_subcycle_skew<K, true, true, WS, true>), g, blk, 0, s, sa);
@@ -4104,10 +4138,12 @@ void Evp::skew_launch(const SkewArgs& sa0, int K, bool last, int nt, hipStream_t
     case 23: launch_skew_kb<2, 3>(sa, last, damp, g, s); break;
     case 33: launch_skew_kb<3, 3>(sa, last, damp, g, s); break;
     case 43: launch_skew_kb<4, 3>(sa, last, damp, g, s, in_pairs, skew_subs(4)); break;
+#ifdef CICE4_AMD_EXPERIMENTS
     case 42: launch_skew_kb<4, 2>(sa, last, damp, g, s); break;
     case 53: launch_skew_kb<5, 3>(sa, last, damp, g, s); break;
     case 63: launch_skew_kb<6, 3>(sa, last, damp, g, s); break;
     case 82: launch_skew_kb<8, 2>(sa, last, damp, g, s); break;
+#endif
     default: throw Error{CICE_EINVAL, "unsupported (skew_levels, skew_blocks) combination"};
   }
 }
@@ -4475,7 +4511,8 @@ bool Evp::can_reside() const {
 // does not place them all, the launch times out and the next one uses one workgroup per CU (res_level).
 bool Evp::granules_on() const {
   static const int env = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_GRANULES"); return e ? (e[0] == '0' ? 0 : 1) : -1; }();
-  return env >= 0 ? env == 1 : res_gran;
+  if (env >= 0) return env == 1;
+  return res_gran == 2 || (res_gran == 1 && !res_sparse);     // 1: unless the last step's ice cover left most tiles empty (run_resident)
 }
 
 bool Evp::resident_dense() const {   // more tiles than CUs: several workgroups per CU
@@ -4535,8 +4572,10 @@ int Evp::resident_waves() const {
 }
 
 // ---- the resident loop across ranks (PEER) ----------------------------------------------------------------------
-// One full-width slab per rank (cice_domain_create with npx = 1), ghost rows owned by the ranks to the south and north.
-// The tiles on a slab's first / last rows exchange their edge velocities with the neighbouring rank's tiles exactly as
+// One block per rank in ANY cartesian layout (round 5; before: one full-width slab per rank): full-width j-slabs, i-slabs
+// (bld/config.nci.access-om.360x300: 6 x 1), 2 x 2 tasks (comp_ice:34-46) -- up to eight neighbouring ranks, the ones
+// across a cyclic edge and the diagonal ones included.
+// The tiles on a block's edges exchange their edge velocities with the neighbouring rank's tiles exactly as
 // tiles of one rank do -- stores into the reader's exchange copy, a progress word, a poll -- only that the reader's
 // exchange copy and progress words live in another device's memory, mapped into this address space (peer_connect: a
 // plain device pointer for two contexts on one GPU, a pointer obtained from the neighbour's IPC handle across GPUs).
@@ -4566,41 +4605,68 @@ void Evp::peer_alloc() {
     }
   }
   if (res_rprog.n == 0) {
-    if (coarse) res_rprog.alloc((size_t)2 * RP_MAX * RES_STRIDE);
-    else res_rprog.alloc_fine((size_t)2 * RP_MAX * RES_STRIDE);
+    if (coarse) res_rprog.alloc((size_t)RES_NPEER * RP_MAX * RES_STRIDE);
+    else res_rprog.alloc_fine((size_t)RES_NPEER * RP_MAX * RES_STRIDE);
     res_rprog.zero(stream);
     CICE_HIP(hipStreamSynchronize(stream));
   }
 }
 
+// The ranks this rank's block exchanges ghost cells with, ascending: the order of the `neighbour` index everywhere in the
+// loop (ResArgs::pxu, the blocks of res_rprog, bit numbers of `pub`).
+std::vector<int> Evp::peer_ranks() const {
+  std::vector<int> v;
+  for (const HaloMsg& m : dom.recv) v.push_back(m.peer);
+  for (const HaloMsg& m : dom.send) v.push_back(m.peer);
+  std::sort(v.begin(), v.end());
+  v.erase(std::unique(v.begin(), v.end()), v.end());
+  return v;
+}
+
+void Evp::peer_connect_rank(int prank, void* xu0, void* xu1, void* rprog, long long peer_n) {
+  CICE_REQUIRE(ready, "cice_evp_peer_connect before cice_evp_init");
+  CICE_REQUIRE(xu0 && xu1 && rprog && peer_n > 0 && peer_n < (1ll << 28), "bad peer buffers");
+  const std::vector<int> pr = peer_ranks();
+  CICE_REQUIRE((int)pr.size() <= RES_NPEER, "resident EVP loop across ranks: more than eight neighbouring ranks");
+  const auto it = std::find(pr.begin(), pr.end(), prank);
+  CICE_REQUIRE(it != pr.end(), "cice_evp_peer_connect: that rank is not a neighbour of this rank's block");
+  peer_alloc();
+  Peer& p = peers[it - pr.begin()];
+  p.xu[0] = (double*)xu0;
+  p.xu[1] = (double*)xu1;
+  p.rprog = (unsigned*)rprog;
+  p.n = (unsigned)peer_n;
+  res_w = 0;   // rebuild the dependency lists
+}
+
+// the older form: side 0 = the rank that owns the block to the south, 1 = to the north (one full-width slab per rank)
 void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long peer_n) {
   CICE_REQUIRE(ready, "cice_evp_peer_connect before cice_evp_init");
   CICE_REQUIRE(side == 0 || side == 1, "side must be 0 (south) or 1 (north)");
-  CICE_REQUIRE(xu0 && xu1 && rprog && peer_n > 0 && peer_n < (1ll << 28), "bad peer buffers");
-  peer_alloc();
-  peers[side].xu[0] = (double*)xu0;
-  peers[side].xu[1] = (double*)xu1;
-  peers[side].rprog = (unsigned*)rprog;
-  peers[side].n = (unsigned)peer_n;
-  res_w = 0;   // rebuild the dependency lists
+  const Block& bl = dom.all[dom.local[0]];
+  int jb = bl.jb + (side == 0 ? -1 : 1);
+  if (dom.ns == BND_CYCLIC) jb = (jb + dom.nby) % dom.nby;
+  CICE_REQUIRE(jb >= 0 && jb < dom.nby, "cice_evp_peer_connect: this slab has no neighbour on that side");
+  int prank = -1;
+  for (const Block& b : dom.all)
+    if (b.ib == bl.ib && b.jb == jb) prank = b.owner;
+  CICE_REQUIRE(prank >= 0 && prank != dom.rank, "cice_evp_peer_connect: no other rank owns the block on that side");
+  peer_connect_rank(prank, xu0, xu1, rprog, peer_n);
 }
 
 bool Evp::can_reside_peer() const {
   if (!resident_on || resident_failed || !halo.multi_rank()) return false;
-  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold() || dom.nbx != 1) return false;
+  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold()) return false;
   if (dom.tripole()) return false;
-  const Block& bl = dom.all[dom.local[0]];
-  if (dom.from_map) {
-    // a block -> task map (the Fortran boundary module hands over the model's own distribution): full-width slabs stacked
-    // in task order, one per task -- the neighbours the caller connected as "south" / "north" are the tasks rank -+ 1
-    for (const Block& b : dom.all)
-      if (b.owner != b.jb) return false;
-  } else if (dom.npx != 1) {
-    return false;
-  }
-  // every neighbour this slab has must be connected
-  const bool has_s = bl.jb > 0 || dom.ns == BND_CYCLIC, has_n = bl.jb < dom.nby - 1 || dom.ns == BND_CYCLIC;
-  if ((has_s && !peers[0].rprog) || (has_n && !peers[1].rprog)) return false;
+  // one block per rank, every block of the same size (a neighbour's tiles are numbered by OUR tile grid)
+  for (const Block& b : dom.all)
+    if (b.owner < 0) return false;         // (an eliminated land block: its neighbours' ghost cells have no producer -- the one-rank loop handles that, this one does not)
+  if ((long long)dom.nbx * dom.nby != dom.nranks) return false;
+  // every neighbour this block has must be connected
+  const std::vector<int> pr = peer_ranks();
+  if (pr.empty() || (int)pr.size() > RES_NPEER) return false;
+  for (size_t k = 0; k < pr.size(); ++k)
+    if (!peers[k].rprog) return false;
   return resident_waves() > 0;
 }
 
@@ -4633,7 +4699,9 @@ void Evp::build_resident_peer(int W) {
       if (m.peer == peer) return &m;
     return nullptr;
   };
-  // my ghost cell -> (side, the neighbour's tile that produces it); my edge cell -> ghost cells of neighbours
+  // my ghost cell -> (neighbour, its tile that produces it); my edge cell -> ghost cells of neighbours
+  const std::vector<int> pranks = peer_ranks();
+  auto slot_of = [&](int prank) { return (int)(std::find(pranks.begin(), pranks.end(), prank) - pranks.begin()); };
   std::vector<int32_t> rsrc_tile(np, -1);            // dep code (<= -2) of a ghost cell owned by another rank
   std::vector<int32_t> rslot(np, -1), rfwd;
   for (const HaloMsg& m : dom.recv) {
@@ -4641,10 +4709,10 @@ void Evp::build_resident_peer(int W) {
     const HaloMsg* ps = msg_with(d.send, dom.rank);
     CICE_REQUIRE(ps && ps->addr.size() == m.addr.size(), "resident EVP loop across ranks: message lists do not pair up");
     const Block& pb = d.all[d.local[0]];
-    CICE_REQUIRE(d.nblocks() == 1 && d.nx_block == nx, "resident EVP loop across ranks: the neighbour is not one full-width slab");
+    CICE_REQUIRE(d.nblocks() == 1 && d.nx_block == nx && d.ny_block == ny, "resident EVP loop across ranks: the neighbour does not hold one block of this size");
+    const int side = slot_of(m.peer);
     for (size_t e = 0; e < m.addr.size(); ++e) {
-      const int q = m.addr[e], gj = q / nx + 1;
-      const int side = gj < jlo ? 0 : 1;
+      const int q = m.addr[e];
       const int sq = ps->addr[e], si = sq % nx + 1, sj = sq / nx + 1;
       const int ptile = ((sj - pb.jlo) / (W - 1)) * tiles_x + (si - pb.ilo) / (TX - 1);
       CICE_REQUIRE(ptile >= 0 && ptile < RP_MAX, "resident EVP loop across ranks: neighbour tile out of range");
@@ -4656,12 +4724,11 @@ void Evp::build_resident_peer(int W) {
     const Domain& d = peer_dom(m.peer);
     const HaloMsg* pr = msg_with(d.recv, dom.rank);
     CICE_REQUIRE(pr && pr->addr.size() == m.addr.size(), "resident EVP loop across ranks: message lists do not pair up");
-    const Block& pb = d.all[d.local[0]];
+    const int side = slot_of(m.peer);
     for (size_t e = 0; e < m.addr.size(); ++e) {
       const int q = m.addr[e];
-      const int gq = pr->addr[e], gj = gq / d.nx_block + 1;
-      const int side = gj > pb.jhi ? 0 : 1;          // on the neighbour's TOP ghost row: the neighbour lies to the south
-      CICE_REQUIRE(gq < (1 << 30), "resident EVP loop across ranks: neighbour plane too large");
+      const int gq = pr->addr[e];
+      CICE_REQUIRE(gq < (1 << 28), "resident EVP loop across ranks: neighbour plane too large");
       int32_t& sl = rslot[q];
       if (sl < 0) {
         sl = (int32_t)(rfwd.size() / 4);
@@ -4670,7 +4737,7 @@ void Evp::build_resident_peer(int W) {
       int k = 0;
       while (k < 4 && rfwd[4 * sl + k] >= 0) ++k;
       CICE_REQUIRE(k < 4, "resident EVP loop across ranks: a cell is mirrored by more than four remote ghost cells");
-      rfwd[4 * sl + k] = (side << 30) | gq;
+      rfwd[4 * sl + k] = (side << 28) | gq;
     }
   }
   if (rfwd.empty()) rfwd.assign(4, -1);
@@ -4706,14 +4773,28 @@ void Evp::build_resident_peer(int W) {
         if (!uown) add(i, j);
       }
   }
-  std::vector<int32_t> pub(nt, 0);   // tiles whose OWNED U-cells are mirrored on the rank to the south (1) / north (2)
+  std::vector<int32_t> pub(nt, 0);   // tiles whose OWNED U-cells are mirrored on neighbour s: bit s
+  // where this rank's tiles publish their progress on neighbour s: the block of ITS res_rprog that belongs to US, i.e. the
+  // place of this rank in the neighbour's own ascending list of neighbours
+  peer_back.assign(RES_NPEER, 0);
+  for (size_t k = 0; k < pranks.size(); ++k) {
+    const Domain& d = peer_dom(pranks[k]);
+    std::vector<int> v;
+    for (const HaloMsg& m : d.recv) v.push_back(m.peer);
+    for (const HaloMsg& m : d.send) v.push_back(m.peer);
+    std::sort(v.begin(), v.end());
+    v.erase(std::unique(v.begin(), v.end()), v.end());
+    const auto it = std::find(v.begin(), v.end(), dom.rank);
+    CICE_REQUIRE(it != v.end(), "resident EVP loop across ranks: a neighbour does not list this rank");
+    peer_back[k] = (int)(it - v.begin());
+  }
   for (int j = jlo; j <= jhi; ++j)
     for (int i = ilo; i <= ihi; ++i) {
       const int sl = rslot[(size_t)(j - 1) * nx + (i - 1)];
       if (sl < 0) continue;
       const int t = ((j - jlo) / (W - 1)) * tiles_x + (i - ilo) / (TX - 1);
       for (int k = 0; k < 4; ++k)
-        if (rfwd[4 * sl + k] >= 0) pub[t] |= 1 << ((rfwd[4 * sl + k] >> 30) & 1);
+        if (rfwd[4 * sl + k] >= 0) pub[t] |= 1 << ((rfwd[4 * sl + k] >> 28) & 7);
     }
   res_pub.alloc(pub.size());
   res_pub.upload(pub.data(), stream);
@@ -5041,6 +5122,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
   const bool peer = halo.multi_rank();
   const int W = resident_waves();
   if (W != res_w || res_deps.n == 0 || peer != res_peer_built) {
+    res_map_stale = true;     // another tiling: the tile map is chosen again
     try {
       if (peer) build_resident_peer(W);
       else build_resident(W);
@@ -5086,12 +5168,12 @@ bool Evp::run_resident(int ksub0, int nsub) {
     r.rfwd = res_rfwd.p;
     r.rprog = res_rprog.p;
     r.pub = res_pub.p;
-    for (int sd = 0; sd < 2; ++sd) {
+    for (int sd = 0; sd < RES_NPEER; ++sd) {
       r.pxu[sd][0] = peers[sd].xu[0];
       r.pxu[sd][1] = peers[sd].xu[1];
       r.pn[sd] = peers[sd].n;
-      // on the neighbour to the south we are the neighbour to the north (side 1), and vice versa
-      r.prp[sd] = peers[sd].rprog ? peers[sd].rprog + (size_t)(1 - sd) * RP_MAX * RES_STRIDE : nullptr;
+      // (on the neighbour we are ITS neighbour number peer_back[sd])
+      r.prp[sd] = peers[sd].rprog ? peers[sd].rprog + (size_t)peer_back[(size_t)sd] * RP_MAX * RES_STRIDE : nullptr;
     }
   }
   const bool dense = !peer && resident_dense();
@@ -5104,6 +5186,8 @@ bool Evp::run_resident(int ksub0, int nsub) {
     static const int ps = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_POLL_SLEEP"); return e ? std::atoi(e) : 0; }();
     r.poll_delay = pd;
     r.poll_sleep = ps;
+    static const int fk = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_FAKE_EW"); return e ? std::atoi(e) : 0; }();
+    r.fake_ew = fk;
   } else {
     for (int k = 0; k < 2; ++k)   // cells nobody publishes keep their value: both exchange copies start as (u, v)
       CICE_HIP(hipMemcpyAsync(res_xu[k].p, uv[cur].p, 2 * n * 8, hipMemcpyDeviceToDevice, stream));
@@ -5135,7 +5219,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
   // (not under a fold: there the period is the top-row tiles' second hand-off, not the arithmetic -- gx1 tripole with polar caps
   //  6.37 us per subcycle with the map against 6.31 without)
   if (!peer && !halo.has_fold() && g.x <= 1024) {     // one choice per evp(dt) (prepare() marks it stale: the masks are new)
-    if (res_map.n == 0) { res_map.alloc(1); res_map_stale = true; }
+    if (res_map.n == 0) { res_map.alloc(4); res_map_stale = true; }
     if (res_map_stale) {
       static const int force = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_MAP"); return e ? std::atoi(e) : -1; }();
       int ncu = 256, dev = 0;
@@ -5188,8 +5272,19 @@ bool Evp::run_resident(int ksub0, int nsub) {
   }
   if (peer && res_peer_agree) halo.all_max_u32(r.abort_flag);   // every rank falls back, or none does
   unsigned why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int32_t cover[3] = {0, 0, 0};
   CICE_HIP(hipMemcpyAsync(why, r.abort_flag, sizeof(why), hipMemcpyDeviceToHost, stream));
+  if (r.tile_map) CICE_HIP(hipMemcpyAsync(cover, res_map.p, sizeof(cover), hipMemcpyDeviceToHost, stream));
   CICE_HIP(hipStreamSynchronize(stream));
+  if (r.tile_map && cover[2] > 0) {
+    // Which shape the NEXT call takes (granules_on): under an ice cover that leaves most tiles empty three barrier-coupled
+    // workgroups per CU win -- a CU then holds one tile with ice and two without (gx1 size, polar caps: 231 k subcycles/s
+    // against 205 k for the granule loop; fully covered 186 k against 200 k).  The cover of one step is the cover of the
+    // next to within a few cells; hysteresis keeps the tables from being rebuilt back and forth.
+    const int pct = (int)(100LL * cover[1] / cover[2]);
+    if (pct < 50) res_sparse = true;
+    else if (pct > 60) res_sparse = false;
+  }
   aborted = why[0];
   res_epoch += (unsigned)nsub + (peer ? 3u : 0u);
   if (aborted && why[1]) {   // this rank's own first time-out (none: the word came from another rank)
@@ -5206,8 +5301,13 @@ bool Evp::run_resident(int ksub0, int nsub) {
         const int d = dl[l];
         const unsigned* wp = d <= -2 ? res_rprog.p + (size_t)(-2 - d) * RES_STRIDE : res_prog.p + (size_t)d * RES_STRIDE;
         CICE_HIP(hipMemcpy(&seen, wp, 4, hipMemcpyDeviceToHost));
-        std::fprintf(stderr, " [%d: %s %d, word now %u]", l, d <= -2 ? ((-2 - d) / RP_MAX ? "north rank's tile" : "south rank's tile") : "own tile",
-                     d <= -2 ? (-2 - d) % RP_MAX : d, seen);
+        if (d <= -2) {
+          const std::vector<int> pr = peer_ranks();
+          const int sd = (-2 - d) / RP_MAX;
+          std::fprintf(stderr, " [%d: rank %d's tile %d, word now %u]", l, sd < (int)pr.size() ? pr[(size_t)sd] : -1, (-2 - d) % RP_MAX, seen);
+        } else {
+          std::fprintf(stderr, " [%d: own tile %d, word now %u]", l, d, seen);
+        }
       }
     std::fprintf(stderr, "\n");
   }

@@ -342,6 +342,19 @@ module cice4_amd_c
          character(kind=c_char), intent(in) :: handles(64,3)
          integer(c_long_long), value :: plane
       end function
+      integer(c_int) function cice_evp_peer_ranks(ctx, n, ranks) bind(C, name='cice_evp_peer_ranks')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), intent(out) :: n
+         integer(c_int), intent(out) :: ranks(8)
+      end function
+      integer(c_int) function cice_evp_peer_connect_rank_ipc(ctx, rank, handles, plane) bind(C, name='cice_evp_peer_connect_rank_ipc')
+         import
+         type(c_ptr), value :: ctx
+         integer(c_int), value :: rank
+         character(kind=c_char), intent(in) :: handles(64,3)
+         integer(c_long_long), value :: plane
+      end function
       integer(c_int) function cice_evp_peer_export(ctx, bufs, plane) bind(C, name='cice_evp_peer_export')
          import
          type(c_ptr), value :: ctx
@@ -538,24 +551,27 @@ contains
       call cice_gpu_check(cice_comm_init(cice_gpu_ctx, uid, my_task, nprocs), 'cice_comm_init')
    end subroutine cice_gpu_comm_setup
 
-   ! The one-launch subcycle loop ACROSS tasks (DESIGN.md section 7): where every task holds one full-width slab, the tasks
-   ! hand each other the IPC handles of their exchange copies / progress words (control plane: MPI on the model's
-   ! communicator) and the library maps them -- after that the two ice_HaloUpdate calls per subcycle of evp need no message.
-   ! Called after cice_evp_init by the drop-in ice_dyn_evp; where the decomposition is another one the library simply keeps
-   ! the message path.  CICE4_AMD_PEER_LOOP=0 in the environment skips it; CICE4_AMD_PEER_SHARE=n tells the library that n
-   ! tasks share one device (tests on a one-GPU box, with CICE4_AMD_LINK=shm).
-   subroutine cice_gpu_peer_setup(my_task, nprocs, comm, nblocks_local, full_width)
+   ! The one-launch subcycle loop ACROSS tasks (DESIGN.md section 7): where every task holds ONE block (any cartesian layout:
+   ! j-slabs, i-slabs, 2 x 2 ...), the tasks hand each other the IPC handles of their exchange copies / progress words
+   ! (control plane: MPI on the model's communicator) and the library maps those of the tasks it exchanges ghost cells with
+   ! (cice_evp_peer_ranks: up to eight, the diagonal ones included) -- after that the two ice_HaloUpdate calls per subcycle of
+   ! evp need no message.  Called after cice_evp_init by the drop-in ice_dyn_evp; where the decomposition is another one the
+   ! library simply keeps the message path.  CICE4_AMD_PEER_LOOP=0 in the environment skips it; CICE4_AMD_PEER_SHARE=n tells
+   ! the library that n tasks share one device (tests on a one-GPU box, with CICE4_AMD_LINK=shm).
+   subroutine cice_gpu_peer_setup(my_task, nprocs, comm, nblocks_local)
       integer, intent(in) :: my_task, nprocs, comm, nblocks_local
-      logical, intent(in) :: full_width
       include 'mpif.h'
-      character(kind=c_char) :: mine(64,3), south(64,3), north(64,3)
-      integer(c_long_long) :: plane(1), plane_s(1), plane_n(1)
-      integer :: ierr, stat(MPI_STATUS_SIZE), ok, allok, share
+      character(kind=c_char) :: mine(64,3)
+      character(kind=c_char), allocatable :: every(:,:,:)
+      integer(c_long_long) :: plane(1)
+      integer(c_long_long), allocatable :: planes(:)
+      integer(c_int) :: nn, ranks(8)
+      integer :: ierr, ok, allok, share, k
       character(len=16) :: txt
       call get_environment_variable('CICE4_AMD_PEER_LOOP', txt)
       if (trim(txt) == '0') return
       ok = 0
-      if (nprocs > 1 .and. nblocks_local == 1 .and. full_width) ok = 1
+      if (nprocs > 1 .and. nblocks_local == 1) ok = 1
       call MPI_ALLREDUCE(ok, allok, 1, MPI_INTEGER, MPI_MIN, comm, ierr)
       if (allok /= 1) return
       call get_environment_variable('CICE4_AMD_PEER_SHARE', txt)
@@ -564,19 +580,15 @@ contains
          call cice_gpu_check(cice_evp_set_option(cice_gpu_ctx, 'resident_peer_share'//c_null_char, share), 'resident_peer_share')
       endif
       call cice_gpu_check(cice_evp_peer_export_ipc(cice_gpu_ctx, mine, plane(1)), 'cice_evp_peer_export_ipc')
-      ! slabs are stacked south to north in task order (cartesian distribution with one task column)
-      if (my_task < nprocs-1) call MPI_SEND(mine, 192, MPI_CHARACTER, my_task+1, 71, comm, ierr)
-      if (my_task > 0)        call MPI_RECV(south, 192, MPI_CHARACTER, my_task-1, 71, comm, stat, ierr)
-      if (my_task < nprocs-1) call MPI_SEND(plane, 1, MPI_INTEGER8, my_task+1, 72, comm, ierr)
-      if (my_task > 0)        call MPI_RECV(plane_s, 1, MPI_INTEGER8, my_task-1, 72, comm, stat, ierr)
-      if (my_task > 0)        call MPI_SEND(mine, 192, MPI_CHARACTER, my_task-1, 73, comm, ierr)
-      if (my_task < nprocs-1) call MPI_RECV(north, 192, MPI_CHARACTER, my_task+1, 73, comm, stat, ierr)
-      if (my_task > 0)        call MPI_SEND(plane, 1, MPI_INTEGER8, my_task-1, 74, comm, ierr)
-      if (my_task < nprocs-1) call MPI_RECV(plane_n, 1, MPI_INTEGER8, my_task+1, 74, comm, stat, ierr)
-      if (my_task > 0) &
-         call cice_gpu_check(cice_evp_peer_connect_ipc(cice_gpu_ctx, 0_c_int, south, plane_s(1)), 'cice_evp_peer_connect_ipc')
-      if (my_task < nprocs-1) &
-         call cice_gpu_check(cice_evp_peer_connect_ipc(cice_gpu_ctx, 1_c_int, north, plane_n(1)), 'cice_evp_peer_connect_ipc')
+      allocate(every(64,3,nprocs), planes(nprocs))
+      call MPI_ALLGATHER(mine, 192, MPI_CHARACTER, every, 192, MPI_CHARACTER, comm, ierr)
+      call MPI_ALLGATHER(plane, 1, MPI_INTEGER8, planes, 1, MPI_INTEGER8, comm, ierr)
+      call cice_gpu_check(cice_evp_peer_ranks(cice_gpu_ctx, nn, ranks), 'cice_evp_peer_ranks')
+      do k = 1, nn
+         call cice_gpu_check(cice_evp_peer_connect_rank_ipc(cice_gpu_ctx, ranks(k), every(:,:,ranks(k)+1), planes(ranks(k)+1)), &
+                             'cice_evp_peer_connect_rank_ipc')
+      enddo
+      deallocate(every, planes)
       call MPI_BARRIER(comm, ierr)
       if (my_task == 0) write(*,*) 'EVP subcycling as one launch per task: exchange buffers of the neighbouring tasks connected'
    end subroutine cice_gpu_peer_setup

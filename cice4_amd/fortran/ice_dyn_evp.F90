@@ -199,8 +199,8 @@
       cfg%mu_rdg = mu_rdg
       call cice_gpu_check(cice_evp_init(cice_gpu_ctx, cfg, g), 'cice_evp_init')
 #ifdef CICE4_AMD_MPI
-      ! one full-width slab per task: connect the neighbours' exchange buffers (the one-launch loop across tasks)
-      call cice_gpu_peer_setup(my_task, get_num_procs(), MPI_COMM_ICE, nblocks, block_size_x == nx_global)
+      ! one block per task (any cartesian layout): connect the neighbouring tasks' exchange buffers (the one-launch loop across tasks)
+      call cice_gpu_peer_setup(my_task, get_num_procs(), MPI_COMM_ICE, nblocks)
 #endif
       end subroutine evp_gpu_setup
 

@@ -426,6 +426,20 @@ class Context:
     def evp_peer_connect_ipc(self, side, peer):
         self._ck(self.lib.cice_evp_peer_connect_ipc(self.h, side, C.c_char_p(peer[0]), C.c_longlong(peer[1])))
 
+    def evp_peer_ranks(self):
+        """the ranks this rank's block exchanges ghost cells with (ascending; any cartesian layout, one block per rank)"""
+        n = C.c_int(0); r = (C.c_int32 * 8)()
+        self._ck(self.lib.cice_evp_peer_ranks(self.h, C.byref(n), r))
+        return [int(r[k]) for k in range(n.value)]
+
+    def evp_peer_connect_rank(self, rank, peer):
+        """`peer` (an evp_peer_export tuple) are the buffers of neighbouring rank `rank`"""
+        self._ck(self.lib.cice_evp_peer_connect_rank(self.h, rank, C.c_void_p(peer[0]), C.c_void_p(peer[1]), C.c_void_p(peer[2]),
+                                                     C.c_longlong(peer[3])))
+
+    def evp_peer_connect_rank_ipc(self, rank, peer):
+        self._ck(self.lib.cice_evp_peer_connect_rank_ipc(self.h, rank, C.c_char_p(peer[0]), C.c_longlong(peer[1])))
+
     def evp_debug(self, what):
         n = C.c_longlong(0)
         self._ck(self.lib.cice_evp_debug(self.h, what.encode(), None, C.byref(n)))

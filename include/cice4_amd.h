@@ -242,13 +242,17 @@ int cice_evp_get_info(cice_ctx *ctx, const char *key, int *value);
 /* number of T-cells with icetmask = 1 and U-cells with iceumask on this rank after prepare
  * (= sum of icellt / icellu, ice_dyn_evp.F90:160-162) */
 int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucells);
-/* The one-launch subcycle loop ACROSS RANKS: one full-width slab per rank (cice_domain_create with npx = 1); the tiles on
- * a slab's first / last rows exchange their edge velocities with the neighbouring rank's tiles through stores into the
+/* The one-launch subcycle loop ACROSS RANKS: ONE BLOCK PER RANK in any cartesian layout -- full-width j-slabs, the i-slabs
+ * of bld/config.nci.access-om.360x300 (6 x 1 tasks), the 2 x 2 tasks of comp_ice:34-46; source/ice_blocks.F90:133-330 --
+ * with up to eight neighbouring ranks (round 5; before: j-slabs only).  The tiles on
+ * a block's edges exchange their edge velocities with the neighbouring rank's tiles through stores into the
  * neighbour's exchange copies and progress words (what replaces the two ice_HaloUpdate calls per subcycle,
  * source/ice_dyn_evp.F90:397-402, mpi/ice_boundary.F90:1028-1417: no message, no host involvement inside the loop).
  * Every rank exports its buffers (cice_evp_peer_export: device pointers xu0, xu1, progress words, and its plane size),
- * hands them to its neighbours through its control plane and connects what it receives: side 0 = the rank to the
- * south, 1 = to the north.  Two contexts of one process on one GPU pass the pointers as they are (tests); processes on
+ * hands them to its neighbours through its control plane and connects what it receives: cice_evp_peer_ranks lists the
+ * ranks this rank's block exchanges ghost cells with (ascending; diagonal neighbours and the ones across a cyclic edge
+ * included), cice_evp_peer_connect_rank connects one of them.  (The older cice_evp_peer_connect takes a side instead, for
+ * j-slabs: 0 = the rank to the south, 1 = to the north.)  Two contexts of one process on one GPU pass the pointers as they are (tests); processes on
  * different GPUs use the _ipc forms (hipIpcGetMemHandle / hipIpcOpenMemHandle; handles travel like the ncclUniqueId).
  * With every neighbour connected, cice_evp_get_info("resident_peer") is 1 and cice_evp / cice_evp_subcycles run the loop
  * as one launch per rank; a rank whose launch times out raises a flag that is all-reduced over the communicator
@@ -261,6 +265,9 @@ int cice_evp_peer_export(cice_ctx *ctx, void *bufs[3], long long *plane);
 int cice_evp_peer_connect(cice_ctx *ctx, int side, void *xu0, void *xu1, void *rprog, long long plane);
 int cice_evp_peer_export_ipc(cice_ctx *ctx, char handles[3][64], long long *plane);
 int cice_evp_peer_connect_ipc(cice_ctx *ctx, int side, const char handles[3][64], long long plane);
+int cice_evp_peer_ranks(cice_ctx *ctx, int *n, int32_t ranks[8]);
+int cice_evp_peer_connect_rank(cice_ctx *ctx, int rank, void *xu0, void *xu1, void *rprog, long long plane);
+int cice_evp_peer_connect_rank_ipc(cice_ctx *ctx, int rank, const char handles[3][64], long long plane);
 /* Test / tuning aid: `what` = "skew_times" (after cice_evp_set_option("skew_debug", 1)): start and end wall-clock ticks
  * (10 ns) of every workgroup of the last K-subcycle sweep launch; "stamps" (after cice_evp_set_option("stamps", 1), in a
  * DIAGNOSTIC build of the library compiled -DCICE4_AMD_STAMPS only -- the product build's kernels hold no stamp and the

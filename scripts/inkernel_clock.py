@@ -52,7 +52,9 @@ for name, nxg, nyg, ndte, kernel in (("gx1", 320, 384, 120, "k_evp_resident<4> (
           f"loop {np.median(ticks) / 100.0:.1f} us per workgroup; step {ms:.3f} ms; resident={rows[-1][8]} skew={rows[-1][9]}", flush=True)
     del ctx
 with open(out_csv, "w") as f:
-    f.write("workload,kernel,workgroups,clock_ghz_median,clock_ghz_min,clock_ghz_max,loop_us_median,step_ms,commit,method\n")
+    import importlib
+    sha = importlib.import_module("bench").kernel_source_sha()   # (the stamps are outside the loop: the diagnostic build times the product's code)
+    f.write("workload,kernel,workgroups,clock_ghz_median,clock_ghz_min,clock_ghz_max,loop_us_median,step_ms,commit,source_sha,method\n")
     for r in rows:
-        f.write(f"{r[0]},\"{r[1]}\",{r[2]},{r[3]:.4f},{r[4]:.4f},{r[5]:.4f},{r[6]:.2f},{r[7]:.4f},{commit},"
+        f.write(f"{r[0]},\"{r[1]}\",{r[2]},{r[3]:.4f},{r[4]:.4f},{r[5]:.4f},{r[6]:.2f},{r[7]:.4f},{commit},{sha},"
                 f"\"s_memtime / s_memrealtime stamped once around the loop by thread 0 of every workgroup after {seconds} s of back-to-back launches; diagnostic build -DCICE4_AMD_STAMPS\"\n")

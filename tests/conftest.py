@@ -8,6 +8,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Several tests run the ranks of a multi-rank job as contexts of this process whose one-launch loops wait for each other: each
+# needs a hardware queue of its own (on a node each has a GPU of its own).  The runtime multiplexes its streams on four
+# queues unless told otherwise -- read when it starts, hence here, before anything touches the device.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

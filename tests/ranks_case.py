@@ -24,11 +24,12 @@ def owned(dom, f):
 
 
 def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, skew_k=0, split=None, strength_args=None,
-              min_cells=None, timeout=600, info=None):
+              min_cells=None, timeout=600, info=None, npx=1):
     """Run evp(dt) on R ranks (threads) and return [(dom, state)] per rank.
-    mode: 'classic' (one slab per rank, ghost rows after every subcycle), 'peer' (the whole loop in one launch per rank,
+    mode: 'classic' (one block per rank, ghost cells after every subcycle), 'peer' (the whole loop in one launch per rank,
     neighbours' exchange copies mapped), 'slabs' (wide-halo slabs with `overlap` rows; skew_k > 0: K-subcycle sweeps
-    between the refreshes).  info: optional dict that receives what rank 0 reports (evp_get_info)."""
+    between the refreshes).  npx: task columns of the cartesian layout (classic / peer; R / npx task rows): 1 = j-slabs.
+    info: optional dict that receives what rank 0 reports (evp_get_info)."""
     nxg, nyg = gg["nxg"], gg["nyg"]
     _LINK[0] += 1
     link = _LINK[0]
@@ -41,7 +42,9 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
             if mode == "slabs":
                 dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=overlap)
             else:
-                dom = c.domain_create(nxg, nyg, nxg, nyg // R, ew=1, ns=ns, rank=r, npx=1, npy=R)
+                npy = R // npx
+                assert npx * npy == R and nxg % npx == 0 and nyg % npy == 0
+                dom = c.domain_create(nxg, nyg, nxg // npx, nyg // npy, ew=1, ns=ns, rank=r, npx=npx, npy=npy)
             assert dom["nblocks"] == 1 and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
             grid = synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
@@ -52,10 +55,16 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                 c.evp_set_option("resident_peer_share", R)
                 exports[r] = c.evp_peer_export()
                 bar.wait(timeout=120)
-                if r > 0 or ns == 1:
-                    c.evp_peer_connect(0, exports[(r - 1) % R])
-                if r < R - 1 or ns == 1:
-                    c.evp_peer_connect(1, exports[(r + 1) % R])
+                if npx == 1 and R <= 3:          # the older call: by side (0 = the rank to the south, 1 = to the north)
+                    if r > 0 or ns == 1:
+                        c.evp_peer_connect(0, exports[(r - 1) % R])
+                    if r < R - 1 or ns == 1:
+                        c.evp_peer_connect(1, exports[(r + 1) % R])
+                else:                            # any cartesian layout: by rank
+                    nbrs = c.evp_peer_ranks()
+                    assert r not in nbrs and 1 <= len(nbrs) <= 8
+                    for nr in nbrs:
+                        c.evp_peer_connect_rank(nr, exports[nr])
                 assert c.evp_get_info("resident_peer") == 1
                 assert c.evp_get_info("resident_peer_fine") == (0 if os.environ.get("CICE4_AMD_PEER_COARSE") == "1" else 1)
                 bar.wait(timeout=120)
@@ -91,6 +100,16 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
     assert not errs, errs
     assert all(o is not None for o in out), "a rank did not finish"
     return out
+
+
+def assemble_blocks(out, key, nxg, nyg):
+    """every rank's block (classic / peer layouts: no overlap rows) of one field, as one global array"""
+    g = np.zeros((nyg, nxg))
+    for dom, s in out:
+        ni = dom["ihi"][0] - dom["ilo"][0] + 1; nj = dom["jhi"][0] - dom["jlo"][0] + 1
+        g[dom["j0"][0]:dom["j0"][0] + nj, dom["i0"][0]:dom["i0"][0] + ni] = s[key][0, dom["jlo"][0] - 1:dom["jhi"][0],
+                                                                                  dom["ilo"][0] - 1:dom["ihi"][0]]
+    return g
 
 
 def assemble(out, key, nxg, nyg):

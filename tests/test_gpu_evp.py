@@ -636,6 +636,32 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                     assert np.array_equal(s["uvel"][0, gj, 1:-1], s1["uvel"][0, jg + 1, 1:-1]), (mode, r, gj)
 
 
+@pytest.mark.parametrize("mode,npx,npy,nxg,nyg", [("peer", 2, 2, 96, 72), ("classic", 2, 2, 96, 72), ("peer", 2, 1, 130, 40),
+                                                   ("peer", 4, 1, 128, 30), ("peer", 1, 4, 70, 64), ("peer", 2, 2, 20, 16)])
+def test_cartesian_layouts_of_ranks_in_one_process(orc, mode, npx, npy, nxg, nyg):
+    """One block per rank in a CARTESIAN layout (source/ice_blocks.F90:133-330: 2 x 2 tasks as comp_ice:34-46 gives the MPI
+    build, i-slabs as bld/config.nci.access-om.360x300:7-8), ranks = contexts of this process: the cross-rank one-launch loop
+    with EAST-WEST and DIAGONAL neighbours (round 5: cice_evp_peer_ranks / cice_evp_peer_connect_rank; two task columns on a
+    cyclic grid: the eastern and the western neighbour are the same rank) against the per-subcycle message path ("classic")
+    and the checker on the whole grid, bit for bit; blocks narrower and shorter than a tile."""
+    import ranks_case
+    R = npx * npy
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    out = ranks_case.run_ranks(gg, R, mode, NDTE, DT, seed=31, cover="patchy", npx=npx)
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:
+        want, got = _owned(one, s1[k]), ranks_case.assemble_blocks(out, k, nxg, nyg)
+        assert np.array_equal(got, want), (mode, npx, npy, k, np.argwhere(got != want)[:5].tolist())
+
+
 @pytest.mark.parametrize("ns", [3, 4])
 @pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
                                        ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96)])
@@ -813,9 +839,14 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
             for k in keys:
                 assert np.array_equal(ref[k], so[k]), ("one launch per subcycle vs checker", k)
         # (K, rows per workgroup (0: automatic), graph, unequal segments in %, priority rotation)
+        # (K = 5, 6, 8 and three wavefronts per level were measured slower and live in -DCICE4_AMD_EXPERIMENTS builds only)
+        ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
+        experiments = ctx.evp_get_info("experiments") == 1
         for K, seg, graph, pct, prio in ((4, 0, 1, 0, 0), (2, 0, 1, 30, 1), (3, 5, 1, 0, 1), (4, 1, 1, 0, 0), (4, 7, 0, 0, 1),
                                          (5, 3, 1, 0, 0), (6, 11, 1, 0, 0), (8, 4, 1, 0, 1), (8, 0, 1, 10, 0),
                                          (4, 0, 1, 25, 1), (3, 0, 1, 60, 1)):
+            if K > 4 and not experiments:
+                continue
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             for key, v in (("resident", 0), ("skew", 1), ("skew_min_cells", 0), ("skew_levels", K),
@@ -829,7 +860,7 @@ def test_k_subcycles_per_sweep(ctx, orc, nxg, nyg, ew):
             ctx.evp(DT, sg)
             for k in keys:
                 assert np.array_equal(sg[k], ref[k]), (ndte, damping, K, seg, graph, pct, prio, k)
-            if K == 4:       # ... and as ONE 12-wavefront workgroup per CU: three wavefronts per level, their strips side by side
+            if K == 4 and experiments:       # ... and as ONE 12-wavefront workgroup per CU: three wavefronts per level, their strips side by side
                 s3w = {k: v.copy() for k, v in s.items()}      # (option "skew_subs": correct, measured slower, off by default)
                 ctx.evp_set_option("skew_subs", 3)
                 assert ctx.evp_get_info("skew_subs") == 3
@@ -1063,13 +1094,37 @@ def test_one_launch_loop_chooses_its_tile_map_by_the_ice_cover(ctx, cover, expec
     for m in (-1, 0, 1):
         sg = {k: v.copy() for k, v in s.items()}
         ctx.evp_init(grid, ndte=24, krdg_partic=0, krdg_redist=0)
-        ctx.evp_set_option("resident", 1)
+        ctx.evp_set_option("resident", 1); ctx.evp_set_option("resident_granules", 0)    # (three workgroups per CU: progress words)
         ctx.evp_set_option("resident_map", m)
+        assert ctx.evp_get_info("resident_dense") == 1
         ctx.evp(DT, sg)
         assert ctx.evp_get_info("last_launches") == 1, "the one-launch loop should have run"
         assert ctx.evp_get_info("resident_map") == (expect if m < 0 else m), (cover, m)
         for k in keys:
             assert np.array_equal(sg[k], ref[k]), (cover, m, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+
+
+@pytest.mark.parametrize("cover,dense_after", [("caps", 1), ("full", 0), ("patchy", 0)])
+def test_one_launch_loop_chooses_its_shape_by_the_ice_cover(ctx, cover, dense_after):
+    """gx1 size: the free-running granule loop (one 11-wavefront workgroup per CU) is the shape of a covered grid; where the
+    last step's ice cover left most tiles empty (polar caps) the next evp(dt) takes three barrier-coupled workgroups per CU
+    instead, whose tile map puts one tile with ice on every CU.  Both shapes: the bits of one launch per subcycle."""
+    nxg, nyg = 320, 384
+    dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.04, seed=5, land_rows=1), dom, ew_cyclic=True)
+    s = synth.evp_state(grid, dom, seed=9, cover=cover)
+    keys = EVP_OUT_FIELDS + ("iceumask",)
+    ref, _ = _evp_with(ctx, grid, s, 24, False, resident=0, skew=0, skew_fold=0)
+    ctx.evp_init(grid, ndte=24, krdg_partic=0, krdg_redist=0)
+    assert (ctx.evp_get_info("resident_granules"), ctx.evp_get_info("resident_dense"), ctx.evp_get_info("resident_waves")) == (1, 0, 11)
+    for call in range(3):
+        sg = {k: v.copy() for k, v in s.items()}
+        ctx.evp(DT, sg)
+        assert ctx.evp_get_info("last_launches") == 1, "the one-launch loop should have run"
+        assert ctx.evp_get_info("resident_dense") == dense_after, (cover, call)       # (what the NEXT call will take)
+        assert ctx.evp_get_info("resident_granules") == 1 - dense_after
+        for k in keys:
+            assert np.array_equal(sg[k], ref[k]), (cover, call, k)
 
 
 @pytest.mark.parametrize("nxg,nyg,ns,cover", [(130, 400, 0, "caps"), (70, 260, 0, "patchy"), (96, 300, 3, "caps")])

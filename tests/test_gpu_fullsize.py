@@ -284,6 +284,15 @@ def test_gx1_on_eight_ranks(orc, mode):
     import ranks_case
     bench = importlib.import_module("bench")
     nxg, nyg, R, ndte = 320, 384, 8, 120
+    if mode == "peer":
+        # eight loops that wait for each other have to run at the same time: one hardware queue each (tests/ranks_peer_case.py)
+        import os, subprocess, sys
+        env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+        r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranks_peer_case.py"),
+                            "1", str(R), str(nxg), str(nyg), str(ndte)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+        assert "bit-identical" in r.stdout
+        return
     gg = synth.global_grid(nxg, nyg, perturb=0.1, land_frac=0.03, seed=31)
     c1 = lib.Context()
     dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
@@ -338,3 +347,21 @@ def test_tenth_degree_on_eight_ranks(orc, split):
         want, got = ranks_case.owned(one, s1[k]), ranks_case.assemble(out, k, nxg, nyg)
         assert np.array_equal(got, want), (split, k, np.argwhere(got != want)[:5].tolist())
     assert 1e-4 < np.abs(s1["uvel"]).max() < 5.0
+
+
+@pytest.mark.parametrize("npx,npy", [(2, 2), (6, 1), (4, 2)], ids=["2x2", "6-i-slabs", "4x2"])
+def test_gx1_as_a_cartesian_layout_of_one_launch_loops(npx, npy):
+    """The decompositions the reference and COSIMA configure under MPI (comp_ice:34-46: 2 x 2 tasks;
+    bld/config.nci.access-om.360x300:7-8: 6 i-slabs; source/ice_blocks.F90:133-330), one block per rank, gx1 size, ndte 120:
+    the whole subcycle loop as ONE launch per rank, the tiles on a block's four edges and corners exchanging with up to eight
+    neighbouring ranks (round 5; before, such layouts ran one launch and one message per neighbour per subcycle).  Ranks =
+    contexts of a child process (one hardware queue each), against the checker on the whole grid, bit for bit."""
+    import os, subprocess, sys
+    # (2 x 2: gx1.  More ranks on ONE device leave each launch an eighth / a sixth of the chip and every shader engine has
+    #  to hold a workgroup of every launch at once: half the rows there -- 324 = a width that divides by 6)
+    nxg, nyg, ndte = {2: (320, 384, 120), 6: (324, 192, 120), 4: (320, 192, 120)}[npx]
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranks_peer_case.py"),
+                        str(npx), str(npy), str(nxg), str(nyg), str(ndte)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "bit-identical" in r.stdout

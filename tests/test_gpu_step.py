@@ -213,7 +213,9 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     thermodynamics per task, the restart dump gathered by the reference's own MPI gather: the dump after 25 steps equals
     the pure serial reference's (which the pure MPI reference reproduces bit for bit on the CPU).
     cfg gx3s2: two full-width slabs, one per task -- the drop-in dynamics connect the neighbouring task's exchange buffers
-    (IPC handles over MPI) and evp(dt) subcycles in ONE launch per task with device-initiated exchange."""
+    (IPC handles over MPI) and evp(dt) subcycles in ONE launch per task with device-initiated exchange; since round 5 the
+    same with gx3b4 on four tasks: one 50 x 58 block per task in a 2 x 2 layout, every task connected to the three others
+    (its eastern and western neighbour are the same task, so are the two diagonal ones)."""
     exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_%s" % cfg)
     if not os.path.exists(exe):
         pytest.skip("%s not built (MPI=1 DROPIN=1 oracle/build_driver.sh)" % exe)
@@ -226,7 +228,12 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     finally:
         shutil.rmtree(rd, ignore_errors=True)
     assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
-    assert ("EVP subcycling as one launch per task" in log) == (cfg == "gx3s2")
+    # one block per task -- two full-width slabs, or (round 5) the 2 x 2 cartesian layout of comp_ice:34-46 with four tasks,
+    # east-west and diagonal neighbours: the whole subcycle loop is one launch per task
+    one_launch = cfg == "gx3s2" or (cfg == "gx3b4" and nprocs == 4)
+    assert ("EVP subcycling as one launch per task" in log) == one_launch
+    if one_launch:
+        assert "on 1 block(s): 1 kernel launch(es)" in log, log[-3000:]
     if nprocs == 1:     # all 2 x 2 blocks on one task: the one-launch loop on several blocks (round 4)
         assert "on 4 block(s): 1 kernel launch(es)" in log, log[-3000:]
     assert "resident EVP loop timed out" not in log
