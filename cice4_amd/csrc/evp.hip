@@ -1707,9 +1707,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
   __shared__ int s_uf[GRAN ? W : 1], s_sf[GRAN ? W : 1];   // GRAN: subcycles whose row of u | v (s_uv) / of str (s_edge) a wavefront has put into LDS
   // tiles are numbered block by block (a one-rank domain of several blocks: every block is cut into tiles_x x tiles_y
   // tiles of the largest block's extent; the cells of a block are addressed from its own plane, which is what the
-  // forwarding lists and the dependency lists use as well -- the PEER and FOLD forms have one block)
+  // forwarding lists and the dependency lists use as well -- the FOLD form has one block)
   const int per_blk = a.tiles_x * a.tiles_y;
-  const int nt = per_blk * ((PEER || FOLD) ? 1 : a.nblocks);
+  const int nt = per_blk * (FOLD ? 1 : a.nblocks);
   const int chunk = (nt + 7) >> 3;
   // Which tile: the workgroups of an XCD are blockIdx & 7 == XCD, and the three that share a CU are 256 apart in blockIdx.
   // Map 0 gives an XCD a band of neighbouring tile rows (and a CU three tiles a few rows apart); map 1 (tile = blockIdx)
@@ -1719,7 +1719,7 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
   // evp(dt), the map under which the busiest CU holds fewer tiles with ice.  Everything between tiles goes by TILE number.
   const int tile = (r.tile_map && *r.tile_map == 1) ? (int)blockIdx.x : (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (tile >= nt) return;  // whole workgroup
-  const int b = (PEER || FOLD) ? 0 : tile / per_blk;
+  const int b = FOLD ? 0 : tile / per_blk;
   const int rem = tile - b * per_blk;
   const int tyi = rem / a.tiles_x, txi = rem - tyi * a.tiles_x;
   const int ilo = a.blk[6 * b], ihi = a.blk[6 * b + 1], jlo = a.blk[6 * b + 2], jhi = a.blk[6 * b + 3];
@@ -4656,12 +4656,13 @@ void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long pe
 
 bool Evp::can_reside_peer() const {
   if (!resident_on || resident_failed || !halo.multi_rank()) return false;
-  if (!halo.fwd_ok() || dom.nblocks() != 1 || dom.overlap > 0 || halo.has_fold()) return false;
-  if (dom.tripole()) return false;
-  // one block per rank, every block of the same size (a neighbour's tiles are numbered by OUR tile grid)
+  if (!halo.fwd_ok() || dom.nblocks() < 1 || dom.overlap > 0 || halo.has_fold()) return false;
+  if (dom.tripole() || halo.has_onrank_refresh()) return false;
+  // any number of blocks per rank, every block of the same size (a neighbour's tiles are numbered block by block on OUR
+  // tile grid); no eliminated land block (its neighbours' ghost cells have no producer: the one-rank loop handles that,
+  // this one does not)
   for (const Block& b : dom.all)
-    if (b.owner < 0) return false;         // (an eliminated land block: its neighbours' ghost cells have no producer -- the one-rank loop handles that, this one does not)
-  if ((long long)dom.nbx * dom.nby != dom.nranks) return false;
+    if (b.owner < 0) return false;
   // every neighbour this block has must be connected
   const std::vector<int> pr = peer_ranks();
   if (pr.empty() || (int)pr.size() > RES_NPEER) return false;
@@ -4671,11 +4672,12 @@ bool Evp::can_reside_peer() const {
 }
 
 void Evp::build_resident_peer(int W) {
-  const int nx = dom.nx_block, ny = dom.ny_block;
-  const Block& bl = dom.all[dom.local[0]];
-  const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
+  // One or SEVERAL blocks per rank (round 5: tiles are numbered block by block, as in build_resident; a cell's address is
+  // its address in the rank's arrays; ghost cells between two blocks of this rank are forwarded by the on-rank lists of
+  // Halo, ghost cells owned by another rank by rslot / rfwd).
+  const int nx = dom.nx_block, ny = dom.ny_block, nb = dom.nblocks();
   const int tiles_x = ((nx - 2) + (TX - 1) - 1) / (TX - 1), tiles_y = ((ny - 2) + (W - 1) - 1) / (W - 1);
-  const int nt = tiles_x * tiles_y;
+  const int per_blk = tiles_x * tiles_y, nt = per_blk * nb;
   CICE_REQUIRE(nt <= RP_MAX, "resident EVP loop across ranks: too many tiles");
   const size_t np = (size_t)nx * ny;
   // the neighbours' view of the same decomposition (host logic only): their send / receive lists pair up with ours
@@ -4702,19 +4704,21 @@ void Evp::build_resident_peer(int W) {
   // my ghost cell -> (neighbour, its tile that produces it); my edge cell -> ghost cells of neighbours
   const std::vector<int> pranks = peer_ranks();
   auto slot_of = [&](int prank) { return (int)(std::find(pranks.begin(), pranks.end(), prank) - pranks.begin()); };
-  std::vector<int32_t> rsrc_tile(np, -1);            // dep code (<= -2) of a ghost cell owned by another rank
-  std::vector<int32_t> rslot(np, -1), rfwd;
+  std::vector<int32_t> rsrc_tile(np * nb, -1);       // dep code (<= -2) of a ghost cell owned by another rank
+  std::vector<int32_t> rslot(np * nb, -1), rfwd;
   for (const HaloMsg& m : dom.recv) {
     const Domain& d = peer_dom(m.peer);
     const HaloMsg* ps = msg_with(d.send, dom.rank);
     CICE_REQUIRE(ps && ps->addr.size() == m.addr.size(), "resident EVP loop across ranks: message lists do not pair up");
-    const Block& pb = d.all[d.local[0]];
-    CICE_REQUIRE(d.nblocks() == 1 && d.nx_block == nx && d.ny_block == ny, "resident EVP loop across ranks: the neighbour does not hold one block of this size");
+    CICE_REQUIRE(d.nx_block == nx && d.ny_block == ny, "resident EVP loop across ranks: the neighbour's blocks have another size");
+    CICE_REQUIRE((long long)per_blk * d.nblocks() <= RP_MAX, "resident EVP loop across ranks: the neighbour has too many tiles");
     const int side = slot_of(m.peer);
     for (size_t e = 0; e < m.addr.size(); ++e) {
       const int q = m.addr[e];
-      const int sq = ps->addr[e], si = sq % nx + 1, sj = sq / nx + 1;
-      const int ptile = ((sj - pb.jlo) / (W - 1)) * tiles_x + (si - pb.ilo) / (TX - 1);
+      const int sq = ps->addr[e], plb = (int)((size_t)sq / np), sqq = (int)((size_t)sq - (size_t)plb * np);
+      const int si = sqq % nx + 1, sj = sqq / nx + 1;
+      const Block& pb = d.all[d.local[plb]];
+      const int ptile = plb * per_blk + ((sj - pb.jlo) / (W - 1)) * tiles_x + (si - pb.ilo) / (TX - 1);
       CICE_REQUIRE(ptile >= 0 && ptile < RP_MAX, "resident EVP loop across ranks: neighbour tile out of range");
       rsrc_tile[q] = -2 - (side * RP_MAX + ptile);
       rslot[q] = -2;
@@ -4741,24 +4745,31 @@ void Evp::build_resident_peer(int W) {
     }
   }
   if (rfwd.empty()) rfwd.assign(4, -1);
-  std::vector<int32_t> src_of(np, -1);
+  std::vector<int32_t> src_of(np * nb, -1);
   for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
-  auto owner = [&](int i, int j) -> int {   // 1-based cell -> tile producing its velocity: local >= 0, remote <= -2, -1 nobody
+  auto owner = [&](int b, int i, int j) -> int {   // block, 1-based cell -> tile producing its velocity: local >= 0, remote <= -2, -1 nobody
     if (i < 1 || i > nx || j < 1 || j > ny) return -1;
-    int q = (j - 1) * nx + (i - 1);
+    size_t q = (size_t)b * np + (size_t)(j - 1) * nx + (i - 1);
     if (rsrc_tile[q] <= -2) return rsrc_tile[q];
-    if (src_of[q] >= 0) q = src_of[q];
-    const int si = q % nx + 1, sj = q / nx + 1;
-    if (si < ilo || si > ihi || sj < jlo || sj > jhi) return -1;
-    return ((sj - jlo) / (W - 1)) * tiles_x + (si - ilo) / (TX - 1);
+    if (src_of[q] >= 0) q = (size_t)src_of[q];
+    const int sb = (int)(q / np);
+    const size_t qq = q - (size_t)sb * np;
+    const int si = (int)(qq % nx) + 1, sj = (int)(qq / nx) + 1;
+    const Block& sbl = dom.all[dom.local[sb]];
+    if (si < sbl.ilo || si > sbl.ihi || sj < sbl.jlo || sj > sbl.jhi) return -1;
+    return sb * per_blk + ((sj - sbl.jlo) / (W - 1)) * tiles_x + (si - sbl.ilo) / (TX - 1);
   };
   std::vector<int32_t> deps((size_t)nt * RES_MAXDEP, -1);
   for (int t = 0; t < nt; ++t) {
-    const int tyi = t / tiles_x, txi = t - tyi * tiles_x;
+    const int b = t / per_blk, rem = t - b * per_blk;
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const Block& bl = dom.all[dom.local[b]];
+    const int ilo = bl.ilo, ihi = bl.ihi, jlo = bl.jlo, jhi = bl.jhi;
     const int i0 = ilo + txi * (TX - 1), j0 = jlo + tyi * (W - 1);
+    if (i0 > ihi || j0 > jhi) continue;   // (a block smaller than the largest: the kernel's workgroup leaves at once)
     int nd = 0;
     auto add = [&](int i, int j) {
-      const int o = owner(i, j);
+      const int o = owner(b, i, j);
       if (o == -1 || o == t) return;
       for (int k = 0; k < nd; ++k)
         if (deps[(size_t)t * RES_MAXDEP + k] == o) return;
@@ -4788,14 +4799,17 @@ void Evp::build_resident_peer(int W) {
     CICE_REQUIRE(it != v.end(), "resident EVP loop across ranks: a neighbour does not list this rank");
     peer_back[k] = (int)(it - v.begin());
   }
-  for (int j = jlo; j <= jhi; ++j)
-    for (int i = ilo; i <= ihi; ++i) {
-      const int sl = rslot[(size_t)(j - 1) * nx + (i - 1)];
-      if (sl < 0) continue;
-      const int t = ((j - jlo) / (W - 1)) * tiles_x + (i - ilo) / (TX - 1);
-      for (int k = 0; k < 4; ++k)
-        if (rfwd[4 * sl + k] >= 0) pub[t] |= 1 << ((rfwd[4 * sl + k] >> 28) & 7);
-    }
+  for (int b = 0; b < nb; ++b) {
+    const Block& bl = dom.all[dom.local[b]];
+    for (int j = bl.jlo; j <= bl.jhi; ++j)
+      for (int i = bl.ilo; i <= bl.ihi; ++i) {
+        const int sl = rslot[(size_t)b * np + (size_t)(j - 1) * nx + (i - 1)];
+        if (sl < 0) continue;
+        const int t = b * per_blk + ((j - bl.jlo) / (W - 1)) * tiles_x + (i - bl.ilo) / (TX - 1);
+        for (int k = 0; k < 4; ++k)
+          if (rfwd[4 * sl + k] >= 0) pub[t] |= 1 << ((rfwd[4 * sl + k] >> 28) & 7);
+      }
+  }
   res_pub.alloc(pub.size());
   res_pub.upload(pub.data(), stream);
   res_deps.alloc(deps.size());

@@ -551,8 +551,8 @@ contains
       call cice_gpu_check(cice_comm_init(cice_gpu_ctx, uid, my_task, nprocs), 'cice_comm_init')
    end subroutine cice_gpu_comm_setup
 
-   ! The one-launch subcycle loop ACROSS tasks (DESIGN.md section 7): where every task holds ONE block (any cartesian layout:
-   ! j-slabs, i-slabs, 2 x 2 ...), the tasks hand each other the IPC handles of their exchange copies / progress words
+   ! The one-launch subcycle loop ACROSS tasks (DESIGN.md section 7): the tasks (any cartesian layout of blocks: j-slabs,
+   ! i-slabs, 2 x 2 ..., one block per task or several) hand each other the IPC handles of their exchange copies / progress words
    ! (control plane: MPI on the model's communicator) and the library maps those of the tasks it exchanges ghost cells with
    ! (cice_evp_peer_ranks: up to eight, the diagonal ones included) -- after that the two ice_HaloUpdate calls per subcycle of
    ! evp need no message.  Called after cice_evp_init by the drop-in ice_dyn_evp; where the decomposition is another one the
@@ -571,7 +571,7 @@ contains
       call get_environment_variable('CICE4_AMD_PEER_LOOP', txt)
       if (trim(txt) == '0') return
       ok = 0
-      if (nprocs > 1 .and. nblocks_local == 1) ok = 1
+      if (nprocs > 1 .and. nblocks_local >= 1) ok = 1     ! (one block per task or several: the library says whether the layout qualifies)
       call MPI_ALLREDUCE(ok, allok, 1, MPI_INTEGER, MPI_MIN, comm, ierr)
       if (allok /= 1) return
       call get_environment_variable('CICE4_AMD_PEER_SHARE', txt)

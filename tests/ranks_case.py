@@ -24,11 +24,12 @@ def owned(dom, f):
 
 
 def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, skew_k=0, split=None, strength_args=None,
-              min_cells=None, timeout=600, info=None, npx=1):
+              min_cells=None, timeout=600, info=None, npx=1, blocks=(1, 1)):
     """Run evp(dt) on R ranks (threads) and return [(dom, state)] per rank.
     mode: 'classic' (one block per rank, ghost cells after every subcycle), 'peer' (the whole loop in one launch per rank,
     neighbours' exchange copies mapped), 'slabs' (wide-halo slabs with `overlap` rows; skew_k > 0: K-subcycle sweeps
-    between the refreshes).  npx: task columns of the cartesian layout (classic / peer; R / npx task rows): 1 = j-slabs.
+    between the refreshes).  npx: task columns of the cartesian layout (classic / peer; R / npx task rows): 1 = j-slabs;
+    blocks = (bx, by): every task holds bx x by blocks of its part of the grid.
     info: optional dict that receives what rank 0 reports (evp_get_info)."""
     nxg, nyg = gg["nxg"], gg["nyg"]
     _LINK[0] += 1
@@ -43,9 +44,9 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                 dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=overlap)
             else:
                 npy = R // npx
-                assert npx * npy == R and nxg % npx == 0 and nyg % npy == 0
-                dom = c.domain_create(nxg, nyg, nxg // npx, nyg // npy, ew=1, ns=ns, rank=r, npx=npx, npy=npy)
-            assert dom["nblocks"] == 1 and dom["nsend"] >= 1
+                assert npx * npy == R and nxg % (npx * blocks[0]) == 0 and nyg % (npy * blocks[1]) == 0
+                dom = c.domain_create(nxg, nyg, nxg // (npx * blocks[0]), nyg // (npy * blocks[1]), ew=1, ns=ns, rank=r, npx=npx, npy=npy)
+            assert dom["nblocks"] == blocks[0] * blocks[1] and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
             grid = synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
             s = synth.evp_state(grid, dom, seed=seed, cover=cover)
@@ -55,7 +56,7 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                 c.evp_set_option("resident_peer_share", R)
                 exports[r] = c.evp_peer_export()
                 bar.wait(timeout=120)
-                if npx == 1 and R <= 3:          # the older call: by side (0 = the rank to the south, 1 = to the north)
+                if npx == 1 and R <= 3 and blocks == (1, 1):   # the older call: by side (0 = the rank to the south, 1 = to the north)
                     if r > 0 or ns == 1:
                         c.evp_peer_connect(0, exports[(r - 1) % R])
                     if r < R - 1 or ns == 1:
@@ -106,9 +107,10 @@ def assemble_blocks(out, key, nxg, nyg):
     """every rank's block (classic / peer layouts: no overlap rows) of one field, as one global array"""
     g = np.zeros((nyg, nxg))
     for dom, s in out:
-        ni = dom["ihi"][0] - dom["ilo"][0] + 1; nj = dom["jhi"][0] - dom["jlo"][0] + 1
-        g[dom["j0"][0]:dom["j0"][0] + nj, dom["i0"][0]:dom["i0"][0] + ni] = s[key][0, dom["jlo"][0] - 1:dom["jhi"][0],
-                                                                                  dom["ilo"][0] - 1:dom["ihi"][0]]
+        for b in range(dom["nblocks"]):
+            ni = dom["ihi"][b] - dom["ilo"][b] + 1; nj = dom["jhi"][b] - dom["jlo"][b] + 1
+            g[dom["j0"][b]:dom["j0"][b] + nj, dom["i0"][b]:dom["i0"][b] + ni] = s[key][b, dom["jlo"][b] - 1:dom["jhi"][b],
+                                                                                      dom["ilo"][b] - 1:dom["ihi"][b]]
     return g
 
 

@@ -636,14 +636,18 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
                     assert np.array_equal(s["uvel"][0, gj, 1:-1], s1["uvel"][0, jg + 1, 1:-1]), (mode, r, gj)
 
 
-@pytest.mark.parametrize("mode,npx,npy,nxg,nyg", [("peer", 2, 2, 96, 72), ("classic", 2, 2, 96, 72), ("peer", 2, 1, 130, 40),
-                                                   ("peer", 4, 1, 128, 30), ("peer", 1, 4, 70, 64), ("peer", 2, 2, 20, 16)])
-def test_cartesian_layouts_of_ranks_in_one_process(orc, mode, npx, npy, nxg, nyg):
+@pytest.mark.parametrize("mode,npx,npy,nxg,nyg,blocks", [("peer", 2, 2, 96, 72, (1, 1)), ("classic", 2, 2, 96, 72, (1, 1)),
+                                                          ("peer", 2, 1, 130, 40, (1, 1)), ("peer", 4, 1, 128, 30, (1, 1)),
+                                                          ("peer", 1, 4, 70, 64, (1, 1)), ("peer", 2, 2, 20, 16, (1, 1)),
+                                                          ("peer", 2, 1, 96, 72, (1, 2)), ("peer", 1, 2, 96, 72, (2, 2)),
+                                                          ("peer", 2, 2, 144, 80, (3, 2)), ("classic", 2, 1, 96, 72, (1, 2))])
+def test_cartesian_layouts_of_ranks_in_one_process(orc, mode, npx, npy, nxg, nyg, blocks):
     """One block per rank in a CARTESIAN layout (source/ice_blocks.F90:133-330: 2 x 2 tasks as comp_ice:34-46 gives the MPI
     build, i-slabs as bld/config.nci.access-om.360x300:7-8), ranks = contexts of this process: the cross-rank one-launch loop
     with EAST-WEST and DIAGONAL neighbours (round 5: cice_evp_peer_ranks / cice_evp_peer_connect_rank; two task columns on a
     cyclic grid: the eastern and the western neighbour are the same rank) against the per-subcycle message path ("classic")
-    and the checker on the whole grid, bit for bit; blocks narrower and shorter than a tile."""
+    and the checker on the whole grid, bit for bit; blocks narrower and shorter than a tile; SEVERAL blocks per rank
+    (`blocks`: tiles numbered block by block, ghost cells between a rank's own blocks forwarded on the device)."""
     import ranks_case
     R = npx * npy
     gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.05, seed=31)
@@ -654,7 +658,7 @@ def test_cartesian_layouts_of_ranks_in_one_process(orc, mode, npx, npy, nxg, nyg
     orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
     orc.evp(orc.make_domain(dom1, grid1), s1)
     orc.set_strength_parameters()
-    out = ranks_case.run_ranks(gg, R, mode, NDTE, DT, seed=31, cover="patchy", npx=npx)
+    out = ranks_case.run_ranks(gg, R, mode, NDTE, DT, seed=31, cover="patchy", npx=npx, blocks=blocks)
     one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
                own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
     for k in ("uvel", "vvel", "divu", "shear", "strength", "strocnxT", "strocnyT", "strintx", "prs_sig") + synth.SIG_NAMES:

@@ -116,8 +116,9 @@ def test_tenth_degree_rank_slab_against_checker(ctx, orc):
 
 def test_tenth_degree_24_hours(ctx):
     """BASELINE.json configs[4]: 0.1 degree, ndte = 240, 24 h = 24 steps of dt = 3600 s with the state
-    resident on the device (velocity, stresses and masks carried from step to step).  Two subcycles per
-    launch (2,880 launches) must reproduce one per launch (5,760 launches) bit for bit, and the
+    resident on the device (velocity, stresses and masks carried from step to step).  The default path
+    (K = 4 subcycles per sweep: 60 launches per step, the state in the sweep's pair layout in between) must
+    reproduce one launch per subcycle (`fuse = 0` switches sweeps and pairs off: 5,760 launches) bit for bit, and the
     solution has to stay bounded."""
     nxg, nyg = 3600, 2400
     dom, grid, s0 = setup(ctx, nxg, nyg, nxg, nyg)
