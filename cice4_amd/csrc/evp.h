@@ -163,6 +163,7 @@ class Evp {
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
   int res_occ[5][2][4] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN), 0 = not asked yet
   int res_gran = 1;              // one-rank domains without a fold: edge velocities travel as data-tagged granules (option "resident_granules": 0 never, 1 by the ice cover, 2 always)
+  unsigned* res_why = nullptr;   // page-locked: the eight words read back behind every one-launch loop
   bool res_sparse = false;       // the last step's ice cover left most tiles of the loop empty (run_resident reads k_res_choose_map's count)
   bool granules_on() const;
   DevBuf<int32_t> res_src;       // [cells] the owned U-cell whose velocity a cell holds, -1: nobody's

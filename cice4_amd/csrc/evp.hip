@@ -1633,7 +1633,7 @@ __device__ __forceinline__ double gran_val(const u32x4& a) { return __hiloint2do
 __global__ __launch_bounds__(1024) void k_res_choose_map(int nt, int tiles_x, int tiles_y, int W, int nx, int ny, int per_xcd,
                                                          int force, const int32_t* __restrict__ blk,
                                                          const int32_t* __restrict__ tmk, const int32_t* __restrict__ umk,
-                                                         int32_t* __restrict__ out) {
+                                                         int32_t* __restrict__ out, unsigned* __restrict__ cover_word) {
   __shared__ int s_ice[1024];
   __shared__ int s_cnt[2][256];
   __shared__ int s_max[2];
@@ -1668,11 +1668,9 @@ __global__ __launch_bounds__(1024) void k_res_choose_map(int nt, int tiles_x, in
   __syncthreads();
   if (t == 0) out[0] = force >= 0 ? force : (s_max[1] < s_max[0] ? 1 : 0);
   // how many tiles hold ice at all (read by the host behind the loop: the NEXT evp(dt) picks its shape by it, run_resident)
+  // (into the last of the eight words the host reads behind every loop anyway: tiles with ice << 16 | tiles)
   const int cnt = __syncthreads_count(ice);
-  if (t == 0) {
-    out[1] = cnt;
-    out[2] = nt;
-  }
+  if (t == 0 && cover_word) *cover_word = ((unsigned)cnt << 16) | (unsigned)nt;
 }
 
 // PEER: see ResArgs.  Differences to the one-rank loop: progress runs epoch0 + 1 ("this launch has begun: its exchange
@@ -2895,6 +2893,7 @@ Evp::~Evp() {
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (stream2) (void)hipStreamDestroy(stream2);
+  if (res_why) (void)hipHostFree(res_why);
 }
 
 void Evp::drop_graph() {
@@ -5243,7 +5242,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
       }
       hipLaunchKernelGGL(k_res_choose_map, dim3(1), dim3(1024), 0, stream, r.a.tiles_x * r.a.tiles_y * r.a.nblocks, r.a.tiles_x,
                          r.a.tiles_y, W, dom.nx_block, dom.ny_block, std::max(1, ncu / 8), res_map_opt >= 0 ? res_map_opt : force,
-                         (const int32_t*)blk.p, (const int32_t*)icetmask.p, (const int32_t*)iceumask.p, res_map.p);
+                         (const int32_t*)blk.p, (const int32_t*)icetmask.p, (const int32_t*)iceumask.p, res_map.p, r.abort_flag + 7);
       res_map_stale = false;
     }
     r.tile_map = res_map.p;
@@ -5285,11 +5284,13 @@ bool Evp::run_resident(int ksub0, int nsub) {
     CICE_HIP(q);
   }
   if (peer && res_peer_agree) halo.all_max_u32(r.abort_flag);   // every rank falls back, or none does
-  unsigned why[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  int32_t cover[3] = {0, 0, 0};
-  CICE_HIP(hipMemcpyAsync(why, r.abort_flag, sizeof(why), hipMemcpyDeviceToHost, stream));
-  if (r.tile_map) CICE_HIP(hipMemcpyAsync(cover, res_map.p, sizeof(cover), hipMemcpyDeviceToHost, stream));
+  // one read-back per loop: the abort word, who gave up on what, and (word 7) the ice cover k_res_choose_map counted --
+  // into page-locked memory (a copy into pageable memory is staged and synchronous: ~15 us of a 600-us loop)
+  if (!res_why) CICE_HIP(hipHostMalloc((void**)&res_why, 8 * sizeof(unsigned), hipHostMallocDefault));
+  unsigned* why = res_why;
+  CICE_HIP(hipMemcpyAsync(why, r.abort_flag, 8 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
   CICE_HIP(hipStreamSynchronize(stream));
+  const int cover[3] = {0, (int)(why[7] >> 16), (int)(why[7] & 0xffffu)};
   if (r.tile_map && cover[2] > 0) {
     // Which shape the NEXT call takes (granules_on): under an ice cover that leaves most tiles empty three barrier-coupled
     // workgroups per CU win -- a CU then holds one tile with ice and two without (gx1 size, polar caps: 231 k subcycles/s

@@ -19,7 +19,7 @@ try:
 except OSError:
     commit = "unknown"
 rows = []
-for name, nxg, nyg, ndte, kernel in (("gx1", 320, 384, 120, "k_evp_resident<4> (dense, 120 subcycles per launch)"),
+for name, nxg, nyg, ndte, kernel in (("gx1", 320, 384, 120, "k_evp_resident (the shape the library picks, 120 subcycles per launch)"),
                                      ("tenth", 3600, 2400, 240, "k_subcycle_skew<4> (4 subcycles per sweep)")):
     ctx = lib.Context(device=0)
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
@@ -40,7 +40,11 @@ for name, nxg, nyg, ndte, kernel in (("gx1", 320, 384, 120, "k_evp_resident<4> (
         n += 1
     ctx.evp_set_option("stamps", 1)
     ms = ctx.evp_subcycles(1, ndte, timed=True)           # the stamped step follows at once
-    st = ctx.evp_debug("stamps").reshape(-1, 4).astype(np.float64)
+    raw = ctx.evp_debug("stamps")
+    # [4 g] stamps come first; behind them the phase sums of the diagnostic build ([8 g] + a trace of 2400 words for the
+    # one-launch loop, [8 K g] for the sweep): only the stamps are read here
+    g = (len(raw) - 2400) // 12 if ctx.evp_get_info("resident") else len(raw) // (4 * (1 + 2 * ctx.evp_get_info("skew_levels")))
+    st = raw[:4 * g].reshape(-1, 4).astype(np.float64)
     ok = (st[:, 1] > st[:, 0]) & (st[:, 3] > st[:, 2])
     if not ok.any():
         raise SystemExit(f"{name}: no stamps -- is {sys.argv[1]} the -DCICE4_AMD_STAMPS build?")
