@@ -4658,10 +4658,9 @@ bool Evp::can_reside_peer() const {
   if (!halo.fwd_ok() || dom.nblocks() < 1 || dom.overlap > 0 || halo.has_fold()) return false;
   if (dom.tripole() || halo.has_onrank_refresh()) return false;
   // any number of blocks per rank, every block of the same size (a neighbour's tiles are numbered block by block on OUR
-  // tile grid); no eliminated land block (its neighbours' ghost cells have no producer: the one-rank loop handles that,
-  // this one does not)
-  for (const Block& b : dom.all)
-    if (b.owner < 0) return false;
+  // tile grid).  Ghost cells that face an ELIMINATED land block have neither a message nor an on-rank source: nobody
+  // produces them, nobody waits for them, they keep the fill value the halo update of prepare() gave them -- as in the
+  // one-rank loop and in the reference (its halo update fills them, mpi/ice_boundary.F90:1145-1404).
   // every neighbour this block has must be connected
   const std::vector<int> pr = peer_ranks();
   if (pr.empty() || (int)pr.size() > RES_NPEER) return false;

@@ -24,12 +24,13 @@ def owned(dom, f):
 
 
 def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, skew_k=0, split=None, strength_args=None,
-              min_cells=None, timeout=600, info=None, npx=1, blocks=(1, 1)):
+              min_cells=None, timeout=600, info=None, npx=1, blocks=(1, 1), block_map=None):
     """Run evp(dt) on R ranks (threads) and return [(dom, state)] per rank.
     mode: 'classic' (one block per rank, ghost cells after every subcycle), 'peer' (the whole loop in one launch per rank,
     neighbours' exchange copies mapped), 'slabs' (wide-halo slabs with `overlap` rows; skew_k > 0: K-subcycle sweeps
     between the refreshes).  npx: task columns of the cartesian layout (classic / peer; R / npx task rows): 1 = j-slabs;
-    blocks = (bx, by): every task holds bx x by blocks of its part of the grid.
+    blocks = (bx, by): every task holds bx x by blocks of its part of the grid.  block_map = (bsx, bsy, owner): any block -> rank
+    map instead (owner[g] = rank of global block g, -1: an eliminated land block; cice_domain_create_map).
     info: optional dict that receives what rank 0 reports (evp_get_info)."""
     nxg, nyg = gg["nxg"], gg["nyg"]
     _LINK[0] += 1
@@ -42,11 +43,14 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
             c = lib.Context(device=0); c.sync()
             if mode == "slabs":
                 dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=overlap)
+            elif block_map is not None:
+                bsx, bsy, owner = block_map
+                dom = c.domain_create_map(nxg, nyg, bsx, bsy, owner, ew=1, ns=ns, rank=r, nranks=R)
             else:
                 npy = R // npx
                 assert npx * npy == R and nxg % (npx * blocks[0]) == 0 and nyg % (npy * blocks[1]) == 0
                 dom = c.domain_create(nxg, nyg, nxg // (npx * blocks[0]), nyg // (npy * blocks[1]), ew=1, ns=ns, rank=r, npx=npx, npy=npy)
-            assert dom["nblocks"] == blocks[0] * blocks[1] and dom["nsend"] >= 1
+            assert (block_map is not None or dom["nblocks"] == blocks[0] * blocks[1]) and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
             grid = synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
             s = synth.evp_state(grid, dom, seed=seed, cover=cover)
@@ -56,7 +60,7 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                 c.evp_set_option("resident_peer_share", R)
                 exports[r] = c.evp_peer_export()
                 bar.wait(timeout=120)
-                if npx == 1 and R <= 3 and blocks == (1, 1):   # the older call: by side (0 = the rank to the south, 1 = to the north)
+                if npx == 1 and R <= 3 and blocks == (1, 1) and block_map is None:   # the older call: by side (0 = the rank to the south, 1 = to the north)
                     if r > 0 or ns == 1:
                         c.evp_peer_connect(0, exports[(r - 1) % R])
                     if r < R - 1 or ns == 1:

@@ -666,6 +666,36 @@ def test_cartesian_layouts_of_ranks_in_one_process(orc, mode, npx, npy, nxg, nyg
         assert np.array_equal(got, want), (mode, npx, npy, k, np.argwhere(got != want)[:5].tolist())
 
 
+@pytest.mark.parametrize("mode", ["peer", "classic"])
+def test_ranks_with_an_eliminated_land_block(orc, mode):
+    """A block -> rank map as the reference's distributions produce them (source/ice_distribution.F90: blocks without an ocean
+    cell are dropped): 4 x 3 blocks of 24 x 24 on three ranks, one all-land block eliminated, the ranks' blocks scattered.
+    The ghost cells that face the eliminated block have no producer and keep the fill value of the first halo update; the
+    cross-rank one-launch loop (several blocks per rank, neighbours by rank) and the per-subcycle message path against the
+    checker on the whole grid, bit for bit on every ocean cell."""
+    import ranks_case
+    nxg, nyg, bs, R = 96, 72, 24, 3
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=31)
+    gg["hm"][24:48, 48:72] = 0.0                         # block (ib = 2, jb = 1): all land
+    owner = np.array([0, 1, 2, 0,  1, 2, -1, 1,  2, 0, 1, 2], np.int32)       # global block g = jb * 4 + ib
+    c1 = lib.Context()
+    dom1 = c1.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=0)
+    grid1 = synth.block_fields(gg, dom1)
+    s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
+    orc.set_evp_parameters(DT, NDTE, False); orc.set_strength_parameters(1, 0, 0, 4.0)
+    orc.evp(orc.make_domain(dom1, grid1), s1)
+    orc.set_strength_parameters()
+    out = ranks_case.run_ranks(gg, R, mode, NDTE, DT, seed=31, cover="patchy", block_map=(bs, bs, owner))
+    assert sorted(int(d["nblocks"]) for d, _ in out) == [3, 4, 4]
+    one = dict(nxg=nxg, nyg=nyg, nblocks=1, j0=[0], jlo=dom1["jlo"], jhi=dom1["jhi"], own_jlo=dom1["jlo"],
+               own_jhi=dom1["jhi"], ilo=dom1["ilo"], ihi=dom1["ihi"])
+    keep = np.ones((nyg, nxg), bool); keep[24:48, 48:72] = False
+    for k in ("uvel", "vvel", "divu", "shear", "strength", "strintx", "prs_sig") + synth.SIG_NAMES:
+        want, got = _owned(one, s1[k]), ranks_case.assemble_blocks(out, k, nxg, nyg)
+        assert np.array_equal(got[keep], want[keep]), (mode, k, np.argwhere((got != want) & keep)[:5].tolist())
+    assert np.abs(s1["uvel"]).max() > 0.01
+
+
 @pytest.mark.parametrize("ns", [3, 4])
 @pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
                                        ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96)])
