@@ -960,6 +960,7 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t, dev = float(tt[0]), float(tt[1])
         return t, dev
+    measured_before = ctx.evp_get_info("skew_balanced") if skew_k else 0     # sweeps the library has measured (and synchronised on) so far
     blocks = [one_block()]
     n_rep = [int(min(max_repeats, max(1, np.ceil(min_timed_s / max(blocks[0][0], 1e-6))))) - 1]
     if dist is not None:
@@ -968,7 +969,11 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         blocks.append(one_block())
     order = sorted(range(len(blocks)), key=lambda k: blocks[k][0])
     t_evp, dev_ms = blocks[order[len(order) // 2]]
+    measured_inside = (ctx.evp_get_info("skew_balanced") - measured_before) if skew_k else 0
     timing = {"blocks": len(blocks), "steps_per_block": steps, "timed_region_s": sum(b[0] for b in blocks),
+              # sweeps whose workgroup times the library read back INSIDE the timed blocks (eager launch + synchronisation each:
+              # the re-cut of the segment table, one loop in 96; 0 = every timed sweep replayed the graph)
+              "sweeps_measured_inside_timed_region": measured_inside,
               "ms_per_step_median": 1e3 * t_evp / steps, "ms_per_step_min": 1e3 * blocks[order[0]][0] / steps,
               "ms_per_step_max": 1e3 * blocks[order[-1]][0] / steps}
     if dist is not None:
@@ -1003,13 +1008,16 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     # "fractions" > 1 in round 1), so it is reported separately as `survey_8d` and is NOT a roofline fraction.
     bytes_per_launch = EVP_BYTES_PER_CELL * cells_rank
     achieved = bytes_per_launch / (us_per_launch * 1e-6) / 1e9
+    granules = resident and bool(ctx.evp_get_info("resident_granules"))
     kname = ("k_evp_resident (all ndte subcycles in one launch: stresses, metrics, forcing resident in registers / LDS; "
-             "tile-edge velocities through agent-scope stores, progress words and agent-scope loads)" if resident else
+             + ("free-running loop without a workgroup barrier, tile-edge velocities as data-tagged granules: one 16-byte sc1 store, "
+                "polled by the lanes that need them)" if granules else
+                "tile-edge velocities through agent-scope stores, progress words and agent-scope loads)") if resident else
              f"k_subcycle_skew ({skew_k} subcycles per sweep: a pipeline of {skew_k} time levels, rows handed on through LDS; "
              f"stress + stepu + on-rank halo per level)" if skew_k else
              "k_subcycle2 (two subcycles per launch: stress + stepu + stress + stepu + on-rank halo)" if fused
              else "k_subcycle (fused stress + stepu + on-rank halo)")
-    ksub = (f"k_evp_resident<{rw}, false" if resident else
+    ksub = (f"k_evp_resident<{rw}, false, false, false, {'true' if granules else 'false'}>" if resident else
             f"k_subcycle_skew<{skew_k}, false, false" if skew_k else
             f"k_subcycle2<{fw}, false, false, {'true' if derive else 'false'}>" if fused
             else f"k_subcycle<{waves}, {rows}, false, false, {'true' if derive else 'false'}>")
@@ -1038,7 +1046,8 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
         us_sub = us_per_launch / sub_per_launch
         roofline["not_hbm_bound"] = {
             "us_per_subcycle": us_sub,
-            "binding": "fp64 VALU issue of the busiest SIMD + one cross-XCD hand-off (agent-scope store -> load through memory) per subcycle",
+            "binding": "fp64 VALU issue of the busiest SIMD + one cross-XCD hand-off (write-through store -> load through memory: 1.3-1.4 us "
+                       "store to arrival, measured) per subcycle; the VALU count includes the poll's instructions",
             "valu_inst_per_wave_per_subcycle": sq.get("valu_per_wave_subcycle") if sq else None,
             "issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz": (3 * sq["valu_per_wave_subcycle"] * 4 / 2400.0) if sq else None,
             "counters_source": sq.get("source") if sq else None}

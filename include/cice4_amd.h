@@ -221,19 +221,25 @@ int cice_evp_finish(cice_ctx *ctx);
  * before the launch gives up and the range is run by the launch-per-pair loop; 0 makes every wait fail -- tests),
  * "resident_map" (-1 default: which tile a workgroup of that loop takes is chosen on the device, once per evp(dt), by the ice
  * cover -- under ice in latitude bands a CU gets one tile with ice and two without; 0 / 1 fix the map).
- * Sweeps (K subcycles per launch on grids of ~0.1 degree size): "skew" (0/1), "skew_levels" (K: 2, 3, 4 default, 5, 6, 8),
+ * Sweeps (K subcycles per launch on grids of ~0.1 degree size): "skew" (0/1), "skew_levels" (K: 2, 3, 4 default; 5, 6, 8 in -DCICE4_AMD_EXPERIMENTS builds),
  * "skew_min_cells", "skew_seg_rows" (rows per workgroup, 0 = as many workgroups as the chip holds), "skew_rowact" (0/1,
  * default 1: a workgroup walks only the runs of rows of its segment that hold ice), "skew_balance" (0/1, default 1 on
  * one-block domains: the segment table is re-cut from the workgroups' measured times -- the sweeps of the first loop after
- * start-up are measured, eagerly; "skew_balance_every", default 96: loops between two later tuning phases of 8 sweeps),
+ * start-up are measured, eagerly; "skew_balance_every", default 96: loops between two later tuning phases of 8 sweeps.
+ * WHAT THIS COSTS: a measured sweep is launched without the captured graph and followed by one hipStreamSynchronize plus one
+ * blocking read-back of two clock words per workgroup -- the first loop after a new table (36 sweeps) takes about 1.7 x its
+ * later time, and one loop in every 96 runs its first 8 sweeps that way; the segment table then depends on measured times,
+ * so the launch geometry -- never a result -- differs from run to run.  0 keeps the static table and replays the graph always),
+ * "resident_granules" (one-launch loop on one rank: 0 progress words, 1 data-tagged granules in a free-running loop unless the
+ * last step's ice cover left most tiles empty, 2 always),
  * "skew_fill" / "skew_gen_pct" (per cent: static weights of a workgroup's place -- more rows on a CU that holds fewer
  * workgroups, more for the workgroup dispatched first; defaults 26 / 15), "skew_split" (wide-halo slabs: the refresh beside
- * the interior sweep), "skew_subs" (1 / 3 wavefronts per level).  DESIGN.md sections 3.1, 3.2, 7.
+ * the interior sweep), "skew_subs" (1; 3 wavefronts per level in -DCICE4_AMD_EXPERIMENTS builds).  DESIGN.md sections 3.1, 3.2, 7.
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"
  * (1 if this domain runs two subcycles per launch), "fused_waves", "resident" (1 if the next cice_evp_subcycles
  * of two or more subcycles runs as one launch), "resident_waves", "resident_dense" (1 if with several workgroups per
- * compute unit), "resident_map" (the map last chosen, -1 before the first loop), "skew" / "skew_fold" (1 if sweeps apply),
+ * compute unit), "resident_granules" (1 if with the granule hand-off), "resident_map" (the map last chosen, -1 before the first loop), "skew" / "skew_fold" (1 if sweeps apply),
  * "skew_levels", "skew_strips", "skew_seg_rows", "skew_rowact", "skew_balance", "skew_balanced" (sweeps measured so far),
  * "skew_fill", "skew_pairs", "skew_subs", "skew_split", "skew_trim_ext", "last_launches" (kernel launches of the last
  * subcycle range: 1 = the one-launch loop). */
