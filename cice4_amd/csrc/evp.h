@@ -60,7 +60,7 @@ class Evp {
   int last_launches = 0;     // subcycle-loop kernel launches of the last subcycles() call (1: the one-launch loop)
   bool peer_buffers_fine() const { return res_xu[0].fine && res_xu[1].fine && res_rprog.fine; }   // what other devices write / poll is fine-grained memory
   bool resident_dense() const; // three 4-wavefront workgroups per CU instead of one workgroup per CU
-  bool granules_in_use() const { return can_reside() && !halo.has_fold() && granules_on() && !resident_dense(); }   // the one-launch loop hands its edge velocities on as data-tagged granules
+  bool granules_in_use() const { return can_reside() && !halo.multi_rank() && granules_on() && !resident_dense(); }   // the one-launch loop hands its edge velocities on as data-tagged granules
   bool can_skew() const;     // K subcycles per sweep (k_subcycle_skew) on this domain
   bool can_split() const;    // ... and the sweep in front of a wide-halo refresh as edge + interior launches
   bool skew_rows_on() const { return (skew_gen_pct > 0 || skew_fill_on() || balance_on()) && skew_seg_opt == 0; }   // segments of unequal length (build_skew_rows)
@@ -161,13 +161,14 @@ class Evp {
   hipEvent_t res_done_ev = nullptr;   // end of the cross-rank loop, polled (run_resident)
   int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
-  int res_occ[5][2][4] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN), 0 = not asked yet
+  int res_occ[5][2][5] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN), 0 = not asked yet
   int res_gran = 1;              // one-rank domains without a fold: edge velocities travel as data-tagged granules (option "resident_granules": 0 never, 1 by the ice cover, 2 always)
   unsigned* res_why = nullptr;   // page-locked: the eight words read back behind every one-launch loop
   bool res_sparse = false;       // the last step's ice cover left most tiles of the loop empty (run_resident reads k_res_choose_map's count)
   bool granules_on() const;
   DevBuf<int32_t> res_src;       // [cells] the owned U-cell whose velocity a cell holds, -1: nobody's
   DevBuf<double> res_xg;         // [2][cells][4] the granule copies (32 bytes per cell and parity)
+  DevBuf<double> res_xgr;        // [4][cells][4] FOLD: granule copies of the raw top-row velocities
   int resident_occupancy(int W, bool damp, bool peer);
   int res_w = 0, res_tiles = 0;  // what res_deps was built for
   unsigned res_epoch = 0;

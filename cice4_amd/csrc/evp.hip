@@ -1576,6 +1576,7 @@ struct ResArgs {
   const int32_t* src;    // [cells] the owned U-cell whose velocity a cell holds: itself, or the source of a ghost cell; -1: nobody's (constant during the loop)
   void* xg;              // two copies (subcycle parity) of [cells][2][2] granules {low half | tag, high half | tag} of u, then of v: 32 bytes per cell
   unsigned xg_half;      // bytes of one copy
+  void* xgr;             // GRAN && FOLD: the same for the RAW velocities of the top row (the fold's own hand-off, before anything is published)
   int poll_delay, poll_sleep;   // GRAN: s_sleep(8) units (~0.2 us each) before the first poll of a subcycle / between two polls
   int fake_ew;                  // TIMING EXPERIMENT ONLY (wrong results): the wavefronts between the first and the last row never poll
 };
@@ -1608,6 +1609,12 @@ __device__ __forceinline__ void st_gran(__amdgpu_buffer_rsrc_t rs, unsigned off,
   u32x4 g;
   g.x = (unsigned)__double2loint(x); g.y = tag; g.z = (unsigned)__double2hiint(x); g.w = tag;
   __builtin_amdgcn_raw_buffer_store_b128(g, rs, (int)off, (int)soff, 16);   // aux 16 = sc1
+  // The store reads its four data registers over several cycles, and the compiler (ROCm 7.2) holds that a buffer store
+  // with an SGPR soffset needs no wait state before they are written again: on gfx950 it does.  Under register pressure the
+  // u and the v granule are built in the SAME four registers, and `v_cndmask v20` one instruction after `buffer_store_dwordx4
+  // v[18:21] ... s20` put the high word of v into the u granule -- tag right, value wrong, one run in twenty
+  // (profiles/r05_resident_granules.txt, section 11).  The registers stay live, and untouched, through two wait states.
+  asm volatile("s_nop 1" : : "v"(g) : "memory");
 }
 __device__ __forceinline__ u32x4 ld_gran(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned soff) {
   return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, (int)soff, 16);
@@ -1690,7 +1697,7 @@ template <int W, bool DAMP, bool PEER, bool FOLD = false, bool GRAN = false>
 // like to use)
 __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
   static_assert(!(PEER && FOLD), "the fold is handled on one-rank domains");
-  static_assert(!(GRAN && (PEER || FOLD)), "granule hand-off: one rank, no fold");
+  static_assert(!(GRAN && PEER), "granule hand-off: one rank");
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
   __shared__ double s_edge[W][4][TX];
@@ -1902,7 +1909,10 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     // above, which reads s_uv[w] first.  Between workgroups: granules (above).  While a wavefront waits for its granules the
     // other wavefronts of its SIMD compute: the hand-off latency no longer adds to the arithmetic of three wavefronts.
     // Every wait is bounded; a wavefront that gives up raises s_abort and the abort word and every wavefront leaves.
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(r.xg, 0, 2 * r.xg_half, 0x00020000);
+#ifndef GRAN_COPIES
+#define GRAN_COPIES 2
+#endif
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(r.xg, 0, GRAN_COPIES * r.xg_half, 0x00020000);
     const bool prio_work = r.prio_mode >= 5;     // issue priority by what a wavefront is doing: waiting 0, computing 2 (chain rows 3 in mode 5)
     const bool chain_hi = r.prio_mode == 5 && (w == 0 || w >= W - 2);
     auto prio_wait = [&]() { if (prio_work) __builtin_amdgcn_s_setprio(0); };
@@ -2028,10 +2038,73 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
           vn = ro.v;
         }
       }
+      const unsigned par = (unsigned)(k & (GRAN_COPIES - 1)) * r.xg_half;
+      if constexpr (FOLD) {
+        // (C') the fold changes the owned cells of the top row (the halo update after stepu, ice_dyn_evp.F90:397-402, on the
+        // degenerate row; serial/ice_boundary.F90:705-869): their RAW velocities of this subcycle travel as granules of
+        // their own, every lane that has a partner across the pole polls that one cell -- in the last subcycle too
+        if (__any(topc)) {
+          // (FOUR copies by subcycle, not two: a mirror image is read by a cell its source does not read back, so the two
+          //  tiles are held together only through the tiles between them)
+          const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(r.xgr, 0, 4 * r.xg_half, 0x00020000);
+          const unsigned tag2 = gran_tag(r.epoch0 + (unsigned)k + 1u);
+          const unsigned par4 = (unsigned)(k & 3) * r.xg_half;
+          if (topc) {
+            st_gran(rsr, qg, par4, un, tag2);
+            st_gran(rsr, qg + 16u, par4, vn, tag2);
+          }
+          bool pp = topc && fmode != 0 && !(fmode & F_SELF);
+          u32x4 p0 = {0u, 0u, 0u, 0u}, p1 = p0;
+          if (__any(pp)) {
+            prio_wait();
+            const long long t0 = wall_clock64();
+            int it = 0;
+            while (true) {
+              if (pp) { p0 = ld_gran(rsr, (unsigned)fpad * 32u, par4); p1 = ld_gran(rsr, (unsigned)fpad * 32u + 16u, par4); }
+              if (pp && gran_ok(p0, p1, tag2)) pp = false;
+              if (!__any(pp)) break;
+              asm volatile("" ::: "memory");
+              int bad = __hip_atomic_load(&s_abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              if (!bad && (++it & 7) == 0) bad = (int)__hip_atomic_load(r.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (!bad && wall_clock64() - t0 > r.spin_ticks) {
+                if (lx == (int)__builtin_ctzll(__ballot(pp)) &&
+                    __hip_atomic_exchange(r.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                  r.abort_flag[1] = 6u; r.abort_flag[2] = (unsigned)tile; r.abort_flag[3] = (unsigned)k;   // wait 6 = a raw granule across the fold
+                  r.abort_flag[4] = (unsigned)w; r.abort_flag[5] = (unsigned)lx; r.abort_flag[6] = tag2;
+                }
+                bad = 1;
+              }
+              if (__any(bad)) {
+                __hip_atomic_store(&s_abort, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                return;
+              }
+              __builtin_amdgcn_s_sleep(1);
+            }
+            prio_compute();
+          }
+          if (topc && fmode) {
+            if (fmode & F_SELF) {                   // unpaired point of the degenerate row: isign * itself (:861-863)
+              un = -un;
+              vn = -vn;
+            } else {
+              const double pu = gran_val(p0), pv = gran_val(p1);
+              if (fmode & F_MIRROR) {               // the image of the partner
+                un = (fmode & F_NEG) ? -pu : pu;
+                vn = (fmode & F_NEG) ? -pv : pv;
+              } else {                              // xavg = 0.5*(x1 + isign*x2), x1 = the pair's first member (:792-799)
+                const double u1 = (fmode & F_LO) ? un : pu, u2 = (fmode & F_LO) ? pu : un;
+                const double v1 = (fmode & F_LO) ? vn : pv, v2 = (fmode & F_LO) ? pv : vn;
+                const double xu_ = 0.5 * (u1 + (-u2)), xv_ = 0.5 * (v1 + (-v2));
+                un = (fmode & F_NEG) ? -xu_ : xu_;
+                vn = (fmode & F_NEG) ? -xv_ : xv_;
+              }
+            }
+          }
+        }
+      }
       if (k + 1 == r.nsub) break;
       // (D) the edge velocities of subcycle k leave first, then the row for the wavefront above
       const unsigned tag = gran_tag(r.epoch0 + (unsigned)k + 1u);
-      const unsigned par = (k & 1) ? r.xg_half : 0u;
       if (edge) {
         st_gran(rs, qg, par, un, tag);
         st_gran(rs, qg + 16u, par, vn, tag);
@@ -2041,6 +2114,18 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
           if (fd >= 0) {
             st_gran(rs, (unsigned)fd * 32u, par, un, tag);
             st_gran(rs, (unsigned)fd * 32u + 16u, par, vn, tag);
+          }
+        }
+        if (FOLD) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int rf = rfr[c];
+            if (rf >= 0) {                          // a ghost cell the fold fills: this cell's value, negated or not
+              const bool neg = (rf >> 30) & 1;
+              const unsigned ro = (unsigned)(rf & 0x3fffffff) * 32u;
+              st_gran(rs, ro, par, neg ? -un : un, tag);
+              st_gran(rs, ro + 16u, par, neg ? -vn : vn, tag);
+            }
           }
         }
       }
@@ -4565,7 +4650,7 @@ int Evp::resident_waves() const {
   // -- unless the free-running granule loop runs (round 5): ONE workgroup per CU whose wavefronts each wait for exactly what
   // they need beats three barrier-coupled workgroups per CU (gx1: 5.0 us per subcycle against 5.3; the granule loop in the
   // dense shape: 6.8, its polls crowd the CU's memory queue -- profiles/r05_resident_granules.txt)
-  if (single && plain && granules_on()) return single;
+  if (single && !halo.multi_rank() && granules_on()) return single;     // (also under a tripole fold: round 5)
   if (dense_ok && (single == 0 || (tiles(4) + ncu - 1) / ncu <= (single + 3) / 4)) return 4;
   return single;
 }
@@ -5020,7 +5105,7 @@ void Evp::build_resident(int W) {
   res_epoch = 0;
   for (int k = 0; k < 2; ++k)
     if (res_xu[k].n < 2 * n) res_xu[k].alloc(2 * n);
-  if (!halo.has_fold()) {
+  {
     // granule hand-off: whose velocity a cell holds (the kernel polls a cell only if that U-cell carries ice), and the two
     // granule copies -- zeroed once: tags start at 1 and only ever grow
     std::vector<int32_t> src((size_t)np * nb, -1);
@@ -5039,9 +5124,14 @@ void Evp::build_resident(int W) {
     res_src.alloc(src.size());
     res_src.upload(src.data(), stream);
     CICE_REQUIRE((unsigned long long)n * 64ull < (1ull << 32), "resident EVP loop: the granule copies are addressed by 32-bit offsets");
-    if (res_xg.n < 8 * n) {
-      res_xg.alloc(8 * n);
+    if (res_xg.n < 16 * n) {      // (room for four copies: GRAN_COPIES)
+      res_xg.alloc(16 * n);
       res_xg.zero(stream);
+    }
+    if (halo.has_fold() && res_xgr.n < 16 * n) {     // the raw top row across the fold: four copies (see the kernel)
+      CICE_REQUIRE((unsigned long long)n * 128ull < (1ull << 32), "resident EVP loop: the raw granule copies are addressed by 32-bit offsets");
+      res_xgr.alloc(16 * n);
+      res_xgr.zero(stream);
     }
   }
   CICE_HIP(hipStreamSynchronize(stream));
@@ -5061,8 +5151,13 @@ static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream
     }
   } else if (r.ftab) {
     if constexpr (W <= 11) {   // (as above)
-      if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false, true>), g, dim3(64 * W), 0, s, r);
-      else hipLaunchKernelGGL((k_evp_resident<W, false, false, true>), g, dim3(64 * W), 0, s, r);
+      if (r.xg) {
+        if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false, true, true>), g, dim3(64 * W), 0, s, r);
+        else hipLaunchKernelGGL((k_evp_resident<W, false, false, true, true>), g, dim3(64 * W), 0, s, r);
+      } else {
+        if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, false, true>), g, dim3(64 * W), 0, s, r);
+        else hipLaunchKernelGGL((k_evp_resident<W, false, false, true>), g, dim3(64 * W), 0, s, r);
+      }
     } else {
       throw Error{CICE_EINVAL, "resident EVP loop with a tripole fold: at most 11 wavefronts per workgroup"};
     }
@@ -5084,8 +5179,12 @@ static int occ_res(bool damp, bool peer, bool fold = false, bool gran = false) {
              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false, false, true>, 64 * W, 0);
   } else if (fold && !peer) {
     if constexpr (W <= 11) {
-      e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, false, true>, 64 * W, 0)
-               : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false, true>, 64 * W, 0);
+      if (gran)
+        e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, false, true, true>, 64 * W, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false, true, true>, 64 * W, 0);
+      else
+        e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, false, true>, 64 * W, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, false, true>, 64 * W, 0);
     } else {
       return 0;
     }
@@ -5112,8 +5211,8 @@ static int occ_res(bool damp, bool peer, bool fold = false, bool gran = false) {
 int Evp::resident_occupancy(int W, bool damp, bool peer) {
   const int wi = W == 4 ? 0 : W == 6 ? 1 : W == 8 ? 2 : W == 11 ? 3 : 4;
   const bool fold = !peer && halo.has_fold();
-  const bool gran = !peer && !fold && granules_on() && !resident_dense();
-  int& c = res_occ[wi][damp][peer ? 1 : (fold ? 2 : (gran ? 3 : 0))];
+  const bool gran = !peer && granules_on() && !resident_dense();
+  int& c = res_occ[wi][damp][peer ? 1 : (fold ? (gran ? 4 : 2) : (gran ? 3 : 0))];
   if (c == 0) {
     int nb = 0;
     switch (W) {
@@ -5151,6 +5250,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
     res_prog.zero(stream);
     if (res_prog2.p) res_prog2.zero(stream);
     if (res_xg.p) res_xg.zero(stream);
+    if (res_xgr.p) res_xgr.zero(stream);
     res_epoch = 0;
   }
   ResArgs r{};
@@ -5189,11 +5289,12 @@ bool Evp::run_resident(int ksub0, int nsub) {
     }
   }
   const bool dense = !peer && resident_dense();
-  const bool gran = !peer && !halo.has_fold() && granules_on() && !dense && res_xg.p && res_src.p;
+  const bool gran = !peer && granules_on() && !dense && res_xg.p && res_src.p && (!halo.has_fold() || res_xgr.p);
   if (gran) {   // data-tagged granules: nothing to initialise (cells nobody publishes are not polled either)
     r.src = res_src.p;
     r.xg = res_xg.p;
     r.xg_half = (unsigned)(n * 32);
+    r.xgr = res_xgr.p;
     static const int pd = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_POLL_DELAY"); return e ? std::atoi(e) : 2; }();
     static const int ps = [] { const char* e = std::getenv("CICE4_AMD_RESIDENT_POLL_SLEEP"); return e ? std::atoi(e) : 0; }();
     r.poll_delay = pd;
@@ -5337,6 +5438,7 @@ bool Evp::run_resident(int ksub0, int nsub) {
     res_prog.zero(stream);
     if (res_prog2.p) res_prog2.zero(stream);
     if (!peer && res_xg.p) res_xg.zero(stream);
+    if (!peer && res_xgr.p) res_xgr.zero(stream);
     if (!peer) res_epoch = 0;   // (across ranks the neighbours hold words about us: the epoch only ever grows)
     return false;
   }

@@ -1054,18 +1054,23 @@ def test_whole_loop_in_one_launch_across_the_tripole_fold(ctx, nxg, nyg, ns):
         if ndte == NDTE and not damping:
             assert not np.array_equal(ref["uvel"][0, -4:-1], opn["uvel"][0, -4:-1]) and np.abs(ref["uvel"][0, -2]).max() > 1e-4
         tried = 0
-        for W in (0, 4, 6, 8, 11):
+        # (W, granules): round 5 -- the free-running granule loop under the fold too (the raw top row travels as granules of
+        # its own, every top-row lane polls its partner across the pole); 0: the progress words of rounds 3-4
+        for W, gran in ((0, 1), (0, 0), (4, 1), (4, 0), (6, 1), (8, 0), (8, 1), (11, 1), (11, 0)):
             sg = {k: v.copy() for k, v in s.items()}
             ctx.evp_init(grid, ndte=ndte, evp_damping=damping, krdg_partic=0, krdg_redist=0)
             ctx.evp_set_option("resident_fold", 1); ctx.evp_set_option("resident", 2); ctx.evp_set_option("resident_waves", W)
+            ctx.evp_set_option("resident_granules", gran)
             if not ctx.evp_get_info("resident"):
                 continue                      # this height does not give every tile a CU
+            if gran:
+                assert ctx.evp_get_info("resident_granules") == (0 if ctx.evp_get_info("resident_dense") else 1)
             ctx.evp(DT, sg)
-            assert ctx.evp_get_info("resident") == 1, ("fell back", W)
+            assert ctx.evp_get_info("resident") == 1, ("fell back", W, gran)
             for k in keys:
-                assert np.array_equal(sg[k], ref[k]), (ns, ndte, damping, W, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
+                assert np.array_equal(sg[k], ref[k]), (ns, ndte, damping, W, gran, k, np.argwhere(sg[k] != ref[k])[:6].tolist())
             tried += 1
-        assert tried >= 1
+        assert tried >= 2
     ctx.evp_set_option("resident_waves", 0)
     # the same grid cut into blocks (fold after every subcycle through the halo update, ghost rows between blocks):
     # the owned cells must come out as on one block
