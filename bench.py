@@ -1214,17 +1214,33 @@ def main():
     if world == 1 and not args.no_dropin_timing:
         st2 = {k: v.copy() for k, v in state.items()}
         ctx.evp_pin_fields(st2)       # what the Fortran drop-in does with its module arrays on the first call
-        for _ in range(3):            # the first calls create the copy streams and touch the page-locked ranges
-            ctx.evp(DT, st2)
-        ts_ = []
-        for _ in range(9):
-            t1 = time.perf_counter()
-            ctx.evp(DT, st2)
-            ts_.append(time.perf_counter() - t1)
+
+        def timed_calls(calls=9):
+            for _ in range(3):        # the first calls create the copy streams and touch the page-locked ranges
+                ctx.evp(DT, st2)
+            ts = []
+            for _ in range(calls):
+                t1 = time.perf_counter()
+                ctx.evp(DT, st2)
+                ts.append(time.perf_counter() - t1)
+            return ts
+        ts_ = timed_calls()
         t1 = float(np.median(ts_))
-        pcie = {"what": "cice_evp(dt): H2D of 33 fields + prepare + ndte subcycles + finish + D2H of 38 fields, "
-                        "host arrays page-locked once (cice_evp_pin_fields), as the Fortran drop-in does", "ms_per_call": 1e3 * t1, "ms_per_call_min_max": [1e3 * min(ts_), 1e3 * max(ts_)], "calls": len(ts_),
+        pcie = {"what": "cice_evp(dt): H2D of 33 fields + prepare + ndte subcycles + finish + D2H of 38 fields (7 of them while the "
+                        "subcycle loop runs), host arrays page-locked once (cice_evp_pin_fields), as the Fortran drop-in does",
+                "ms_per_call": 1e3 * t1, "ms_per_call_min_max": [1e3 * min(ts_), 1e3 * max(ts_)], "calls": len(ts_),
                 "subcycles_per_s": ndte / t1}
+        # the caller's two statements (include/cice4_amd.h: both hold for the reference's driver): planes that nobody touches stay
+        for key, keep, lazy, what in (
+                ("keep_state", 2, 0, "keep_state = 2: uvel, vvel, 12 stresses, iceumask not uploaded again, the 7 flux fields zeroed "
+                                     "on the device: H2D of 18 fields, D2H of 38"),
+                ("keep_state_lazy_stresses", 2, 1, "keep_state = 2 and lazy_stresses = 1: H2D of 18 fields, D2H of 26 (the stresses on "
+                                                   "request: cice_evp_download_stresses)")):
+            ctx.evp_set_option("keep_state", keep); ctx.evp_set_option("lazy_stresses", lazy)
+            tk = timed_calls()
+            pcie[key] = {"what": what, "ms_per_call": 1e3 * float(np.median(tk)), "ms_per_call_min_max": [1e3 * min(tk), 1e3 * max(tk)],
+                         "calls": len(tk), "subcycles_per_s": ndte / float(np.median(tk))}
+        ctx.evp_set_option("keep_state", 0); ctx.evp_set_option("lazy_stresses", 0)
         ctx.host_unregister_all()     # before the arrays are released (a stale page-locked range faults later)
         del st2
 

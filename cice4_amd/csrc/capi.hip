@@ -811,21 +811,19 @@ int cice_evp_upload(cice_ctx* ctx, const cice_evp_fields* f) {
 int cice_evp_download(cice_ctx* ctx, cice_evp_fields* f) {
   CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->download(*f); CICE_CATCH
 }
-int cice_evp_step(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->step(dt); CICE_CATCH }
+int cice_evp_step(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->forget_host_state(); c_->evp->step(dt); CICE_CATCH }
 int cice_evp(cice_ctx* ctx, double dt, cice_evp_fields* f) {
   CICE_TRY(ctx)
   NEED_EVP;
   CICE_REQUIRE(f, "NULL argument");
   c_->chain_ready = false;
-  c_->evp->upload(*f);
   const bool chain = c_->chain_on && c_->transport;
-  if (chain) {
+  c_->evp->run(dt, *f, [&]() {
+    if (!chain) return;
     // the rest of the transport's state travels while the subcycle loop runs (the link idles then); see cice_transport_chain
     c_->transport->prefetch(c_->chain);
     c_->chain_aicen = f->aicen; c_->chain_vicen = f->vicen; c_->chain_u = f->uvel; c_->chain_v = f->vvel;
-  }
-  c_->evp->step(dt);
-  c_->evp->download(*f);
+  });
   c_->chain_ready = chain;   // only a call that got this far leaves device copies the transport may take over
   CICE_CATCH
 }
@@ -859,11 +857,14 @@ int cice_evp_pin_fields(cice_ctx* ctx, const cice_evp_fields* f) {
   pin(f->iceumask, n * 4);
   CICE_CATCH
 }
-int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->prepare(dt); CICE_CATCH }
+int cice_evp_prepare(cice_ctx* ctx, double dt) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->forget_host_state(); c_->evp->prepare(dt); CICE_CATCH }
 int cice_evp_subcycles(cice_ctx* ctx, int ksub0, int nsub, float* ms) {
-  CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->subcycles(ksub0, nsub, ms); CICE_CATCH
+  CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->forget_host_state(); c_->evp->subcycles(ksub0, nsub, ms); CICE_CATCH
 }
-int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->finish(); CICE_CATCH }
+int cice_evp_finish(cice_ctx* ctx) { CICE_TRY(ctx) c_->chain_ready = false; NEED_EVP; c_->evp->forget_host_state(); c_->evp->finish(); CICE_CATCH }
+int cice_evp_download_stresses(cice_ctx* ctx, cice_evp_fields* f) {
+  CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(f, "NULL argument"); c_->evp->download_stresses(*f); CICE_CATCH
+}
 int cice_evp_set_option(cice_ctx* ctx, const char* key, int value) {
   CICE_TRY(ctx) NEED_EVP; CICE_REQUIRE(key, "NULL key"); c_->evp->set_option(key, value); CICE_CATCH
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <map>
 #include <memory>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -39,6 +40,11 @@ class Evp {
     subcycles(1, sc.ndte, nullptr);
     finish();
   }
+  // evp(dt) on host arrays (cice_evp): upload, step, download as ONE pipeline -- what prepare() has finished travels to
+  // the host while the subcycle loop runs; options "keep_state" / "lazy_stresses" (set_option) leave planes where they are
+  void run(double dt, cice_evp_fields& f, const std::function<void()>& while_looping = nullptr);
+  void download_stresses(cice_evp_fields& f);   // the 12 stresses of the current state ("lazy_stresses": cice_evp left them)
+  void forget_host_state() { io_valid = false; }   // the host copies of the io fields may be newer than the device's
   void set_option(const char* key, int value);
   void active_cells(long long* nt, long long* nu);
   long long debug_read(const char* what, long long* out, long long cap);
@@ -100,6 +106,11 @@ class Evp {
   EvpScalars sc{};
   bool ready = false, prepared = false, counted = false;
   bool adopted = false;   // aice, vice, vsno, aice0, aicen, vicen came from adopt_state: the next upload may omit them
+  int keep_state = 0;        // option: 1 the caller does not change u, v, the stresses, iceumask on the host between two cice_evp calls; 2: and zeroes the flux fields
+  bool lazy_sig = false;     // option: cice_evp does not download the stresses (cice_evp_download_stresses does)
+  bool io_valid = false;     // the device copies of the io fields are those the last cice_evp left (and nothing has touched them)
+  void upload_some(const cice_evp_fields& f, int skip_io);
+  void download_some(cice_evp_fields& f, int part);   // part 1: what prepare() has finished, 2: the rest, 3: both
   int waves = 8, rows_per_wave = 1;  // tile = 64 x (waves*rows_per_wave) T-cells
   bool use_graph = true;
   bool comm_graph = false;   // multi-rank loops: capture the RCCL calls too (opt-in)

@@ -3034,6 +3034,12 @@ void Evp::set_option(const char* key, int value) {
   } else if (!std::strcmp(key, "resident_granules")) {   // edge velocities as data-tagged granules (one rank, no fold); 0: progress words,
     CICE_REQUIRE(value >= 0 && value <= 2, "resident_granules must be 0, 1 or 2");   // 1: by the ice cover of the last step, 2: always
     res_gran = value;
+  } else if (!std::strcmp(key, "keep_state")) {       // cice_evp: see Evp::run
+    CICE_REQUIRE(value >= 0 && value <= 2, "keep_state must be 0, 1 or 2");
+    keep_state = value;
+    io_valid = false;
+  } else if (!std::strcmp(key, "lazy_stresses")) {
+    lazy_sig = value != 0;
   } else if (!std::strcmp(key, "resident_waves")) {   // 0 = auto
     CICE_REQUIRE(value == 0 || value == 4 || value == 6 || value == 8 || value == 11 || value == 12,
                  "resident_waves must be 0, 4, 6, 8, 11 or 12");
@@ -3238,13 +3244,22 @@ void Evp::init(const cice_evp_config& c, const cice_evp_grid& g) {
 }
 
 void Evp::upload(const cice_evp_fields& f) {
+  upload_some(f, 0);
+  CICE_HIP(hipStreamSynchronize(stream));
+}
+
+// skip_io 1: the device copies of u, v, the stresses and iceumask are current; 2: and the seven flux fields (fm, strtlt,
+// strocn, strint) are zero on the host (the caller's statement), so they are zeroed here instead of uploaded
+void Evp::upload_some(const cice_evp_fields& f, int skip_io) {
   CICE_REQUIRE(ready, "cice_evp_upload before cice_evp_init");
-  struct U { DevBuf<double>* d; const double* h; };
-  U us[] = {{&aice, f.aice}, {&vice, f.vice}, {&vsno, f.vsno}, {&aice0, f.aice0}, {&aicen, f.aicen},
-            {&vicen, f.vicen}, {&strairxT, f.strairxT}, {&strairyT, f.strairyT}, {&uocn, f.uocn},
-            {&vocn, f.vocn}, {&ss_tltx, f.ss_tltx}, {&ss_tlty, f.ss_tlty}, {&fm, f.fm},
-            {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx}, {&strocny, f.strocny},
-            {&strintx, f.strintx}, {&strinty, f.strinty}};
+  io_valid = false;
+  struct U { DevBuf<double>* d; const double* h; bool io; };
+  U us[] = {{&aice, f.aice, false}, {&vice, f.vice, false}, {&vsno, f.vsno, false}, {&aice0, f.aice0, false},
+            {&aicen, f.aicen, false}, {&vicen, f.vicen, false}, {&strairxT, f.strairxT, false},
+            {&strairyT, f.strairyT, false}, {&uocn, f.uocn, false}, {&vocn, f.vocn, false},
+            {&ss_tltx, f.ss_tltx, false}, {&ss_tlty, f.ss_tlty, false}, {&fm, f.fm, true},
+            {&strtltx, f.strtltx, true}, {&strtlty, f.strtlty, true}, {&strocnx, f.strocnx, true},
+            {&strocny, f.strocny, true}, {&strintx, f.strintx, true}, {&strinty, f.strinty, true}};
   fan.fork(stream);
   for (U& x : us) {
     // after adopt_state the six state fields are on the device already: a NULL pointer keeps them
@@ -3253,46 +3268,97 @@ void Evp::upload(const cice_evp_fields& f) {
 #ifndef CICE4_AMD_AUSCOM   // the stand-alone build forms the tilt from the currents (:919-922) and never reads the slope
     if (x.d == &ss_tltx || x.d == &ss_tlty) continue;
 #endif
+    if (skip_io == 2 && x.io) {
+      CICE_HIP(hipMemsetAsync(x.d->p, 0, n * 8, stream));   // (on the main stream, which every later kernel follows)
+      continue;
+    }
     CICE_REQUIRE(x.h != nullptr, "cice_evp_upload: NULL field");
     x.d->upload(x.h, fan.next());
   }
   adopted = false;
-  CICE_REQUIRE(f.uvel && f.vvel && f.iceumask, "cice_evp_upload: NULL field");
-  CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, fan.next()));
-  CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, fan.next()));
-  const double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
-                          f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3,
-                          f.stress12_4};
-  for (int c = 0; c < 12; ++c) {
-    CICE_REQUIRE(hs[c] != nullptr, "cice_evp_upload: NULL stress");
-    CICE_HIP(hipMemcpyAsync(sig[cur].p + (size_t)c * n, hs[c], n * 8, hipMemcpyHostToDevice, fan.next()));
+  if (!skip_io) {
+    CICE_REQUIRE(f.uvel && f.vvel && f.iceumask, "cice_evp_upload: NULL field");
+    CICE_HIP(hipMemcpyAsync(uv[cur].p, f.uvel, n * 8, hipMemcpyHostToDevice, fan.next()));
+    CICE_HIP(hipMemcpyAsync(uv[cur].p + n, f.vvel, n * 8, hipMemcpyHostToDevice, fan.next()));
+    const double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
+                            f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3,
+                            f.stress12_4};
+    for (int c = 0; c < 12; ++c) {
+      CICE_REQUIRE(hs[c] != nullptr, "cice_evp_upload: NULL stress");
+      CICE_HIP(hipMemcpyAsync(sig[cur].p + (size_t)c * n, hs[c], n * 8, hipMemcpyHostToDevice, fan.next()));
+    }
+    iceumask.upload(f.iceumask, fan.next());
   }
-  iceumask.upload(f.iceumask, fan.next());
   fan.join();
-  CICE_HIP(hipStreamSynchronize(stream));
   prepared = false;
 }
 
 void Evp::download(cice_evp_fields& f) {
   CICE_REQUIRE(ready, "cice_evp_download before cice_evp_init");
   fan.fork(stream);
-  CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, fan.next()));
-  CICE_HIP(hipMemcpyAsync(f.vvel, uv[cur].p + n, n * 8, hipMemcpyDeviceToHost, fan.next()));
+  download_some(f, 3);
+  download_stresses(f);
+}
+
+// part 1: the fields prepare() leaves final (nothing in the subcycle loop or in finish() writes them); part 2: the rest
+// but the stresses.  Enqueued on the side streams: the caller has forked them.
+void Evp::download_some(cice_evp_fields& f, int part) {
+  struct D { const DevBuf<double>* d; double* h; int part; };
+  D ds[] = {{&fm, f.fm, 1}, {&strtltx, f.strtltx, 1}, {&strtlty, f.strtlty, 1}, {&strairx, f.strairx, 1},
+            {&strairy, f.strairy, 1}, {&strength, f.strength, 1}, {&strocnx, f.strocnx, 2},
+            {&strocny, f.strocny, 2}, {&strintx, f.strintx, 2}, {&strinty, f.strinty, 2}, {&divu, f.divu, 2},
+            {&shear, f.shear, 2}, {&rdg_conv, f.rdg_conv, 2}, {&rdg_shear, f.rdg_shear, 2}, {&prs_sig, f.prs_sig, 2},
+            {&strocnxT, f.strocnxT, 2}, {&strocnyT, f.strocnyT, 2}};
+  if (part & 2) {
+    CICE_HIP(hipMemcpyAsync(f.uvel, uv[cur].p, n * 8, hipMemcpyDeviceToHost, fan.next()));
+    CICE_HIP(hipMemcpyAsync(f.vvel, uv[cur].p + n, n * 8, hipMemcpyDeviceToHost, fan.next()));
+  }
+  if (part & 1) iceumask.download(f.iceumask, fan.next());
+  for (D& x : ds)
+    if (x.h && (x.part & part)) x.d->download(x.h, fan.next());
+}
+
+// (with the side streams forked by the caller, or not: then it forks them itself)
+void Evp::download_stresses(cice_evp_fields& f) {
+  CICE_REQUIRE(ready, "cice_evp_download before cice_evp_init");
+  if (!fan.forked) fan.fork(stream);
   double* hs[12] = {f.stressp_1, f.stressp_2, f.stressp_3, f.stressp_4, f.stressm_1, f.stressm_2,
                     f.stressm_3, f.stressm_4, f.stress12_1, f.stress12_2, f.stress12_3, f.stress12_4};
-  for (int c = 0; c < 12; ++c)
+  for (int c = 0; c < 12; ++c) {
+    CICE_REQUIRE(hs[c] != nullptr, "cice_evp_download: NULL stress");
     CICE_HIP(hipMemcpyAsync(hs[c], sig[cur].p + (size_t)c * n, n * 8, hipMemcpyDeviceToHost, fan.next()));
-  iceumask.download(f.iceumask, fan.next());
-  struct D { const DevBuf<double>* d; double* h; };
-  D ds[] = {{&fm, f.fm}, {&strtltx, f.strtltx}, {&strtlty, f.strtlty}, {&strocnx, f.strocnx},
-            {&strocny, f.strocny}, {&strintx, f.strintx}, {&strinty, f.strinty}, {&strairx, f.strairx},
-            {&strairy, f.strairy}, {&strength, f.strength}, {&divu, f.divu}, {&shear, f.shear},
-            {&rdg_conv, f.rdg_conv}, {&rdg_shear, f.rdg_shear}, {&prs_sig, f.prs_sig},
-            {&strocnxT, f.strocnxT}, {&strocnyT, f.strocnyT}};
-  for (D& x : ds)
-    if (x.h) x.d->download(x.h, fan.next());
+  }
   fan.join();
   CICE_HIP(hipStreamSynchronize(stream));
+}
+
+// cice_evp: `call evp(dt)` on host arrays (ice_dyn_evp.F90:119-432) as one pipeline.  The link is idle while the subcycle loop
+// runs (0.6 ms at gx1 size, as long as all the copies together): the six fields prepare() leaves final, and iceumask, go down
+// then.  "keep_state" 1: uvel, vvel, the 12 stresses and iceumask are where the last call left them -- the caller has not
+// changed them on the host since (in the reference nothing but evp itself and the restart reader, before the first step,
+// writes them) -- and are not uploaded again; 2: and the seven flux fields evp reads back outside its ice mask (fm,
+// strtltx/y, strocnx/y, strintx/y) are ZERO on the host when evp is called, as init_history_dyn (ice_flux.F90:585-602,
+// called at the top of every step: drivers/cice4/CICE_RunMod.F90) leaves them: zeroed on the device, not uploaded.
+// "lazy_stresses": the stresses stay on the device until someone asks (download_stresses: the reference reads them on the
+// host only for its history and restart files).
+void Evp::run(double dt, cice_evp_fields& f, const std::function<void()>& while_looping) {
+  upload_some(f, io_valid ? keep_state : 0);
+  prepare(dt);
+  fan.fork(stream);          // the side streams wait for prepare()
+  download_some(f, 1);
+  fan.detach();              // ... and nobody waits for them yet
+  if (while_looping) while_looping();   // (cice_transport_chain: the transport's state travels up now)
+  subcycles(1, sc.ndte, nullptr);
+  finish();
+  fan.fork(stream);          // (the side streams run in order: the copies above are done before these)
+  download_some(f, 2);
+  if (lazy_sig) {
+    fan.join();
+    CICE_HIP(hipStreamSynchronize(stream));
+  } else {
+    download_stresses(f);
+  }
+  io_valid = true;
 }
 
 void Evp::prepare(double dt) {

@@ -400,6 +400,11 @@ module cice4_amd_c
          type(c_ptr), value :: ctx
          type(cice_evp_fields), intent(in) :: f
       end function
+      integer(c_int) function cice_evp_download_stresses(ctx, f) bind(C, name='cice_evp_download_stresses')
+         import
+         type(c_ptr), value :: ctx
+         type(cice_evp_fields), intent(in) :: f
+      end function
       integer(c_int) function cice_thermo_init(ctx, cfg, salin, Tmlt) bind(C, name='cice_thermo_init')
          import
          type(c_ptr), value :: ctx

@@ -53,6 +53,7 @@
 
       real (kind=dbl_kind), allocatable :: fcor_blk(:,:,:)
       logical, save, private :: fields_pinned = .false.
+      logical, save, private :: stresses_on_device = .false.   ! CICE4_AMD_LAZY_STRESSES=1: evp_sync_stresses fetches them
 
       contains
 
@@ -69,6 +70,8 @@
 #endif
       real (kind=dbl_kind), intent(in) :: dt
       type (cice_evp_fields) :: f
+      character (len=8) :: env
+      integer :: keep, ios
 #if defined(AusCOM)
       integer (kind=int_kind) :: iblk
 #endif
@@ -109,10 +112,48 @@
       if (.not. fields_pinned) then   ! module arrays never move: page-lock them once (asynchronous DMA)
          call cice_gpu_check(cice_evp_pin_fields(cice_gpu_ctx, f), 'cice_evp_pin_fields')
          fields_pinned = .true.
+         ! Two statements about the DRIVER, hence opt-in (include/cice4_amd.h, cice_evp):
+         ! CICE4_AMD_KEEP_STATE=1: nothing but evp writes uvel, vvel, the stresses, iceumask between two steps (true of the
+         !   reference; the restart reader runs before the first step) -- they are uploaded once;
+         ! CICE4_AMD_KEEP_STATE=2: and init_history_dyn has zeroed fm, strtlt, strocn, strint before evp is called (true
+         !   of CICE_RunMod.F90's ice_step) -- zeroed on the device instead of uploaded;
+         ! CICE4_AMD_LAZY_STRESSES=1: the stresses stay on the device; whoever reads them on the host (ice_history's
+         !   principal_stress, ice_restart's dumpfile) calls evp_sync_stresses first.
+         call get_environment_variable('CICE4_AMD_KEEP_STATE', env)
+         read(env, *, iostat=ios) keep
+         if (ios == 0 .and. keep >= 1 .and. keep <= 2) then
+            call cice_gpu_check(cice_evp_set_option(cice_gpu_ctx, 'keep_state'//c_null_char, int(keep, c_int)), 'keep_state')
+            if (my_task == master_task) write(nu_diag,*) &
+               'evp keeps uvel, vvel, the stresses and iceumask on the device (CICE4_AMD_KEEP_STATE)', keep
+         endif
+         call get_environment_variable('CICE4_AMD_LAZY_STRESSES', env)
+         if (trim(env) == '1') then
+            call cice_gpu_check(cice_evp_set_option(cice_gpu_ctx, 'lazy_stresses'//c_null_char, 1_c_int), 'lazy_stresses')
+            stresses_on_device = .true.
+            if (my_task == master_task) write(nu_diag,*) &
+               'evp leaves the stresses on the device until evp_sync_stresses (CICE4_AMD_LAZY_STRESSES=1)'
+         endif
       endif
       call cice_gpu_check(cice_evp(cice_gpu_ctx, dt, f), 'evp')
       call ice_timer_stop(timer_dynamics)
       end subroutine evp
+
+!=======================================================================
+! The 12 stresses of the device state into the module arrays (a no-op unless CICE4_AMD_LAZY_STRESSES=1): one line
+! before `call principal_stress` in ice_history.F90:1939 and at the top of dumpfile (ice_restart.F90:74).
+      subroutine evp_sync_stresses
+      use ice_state
+      use ice_flux
+      type (cice_evp_fields) :: f
+      if (.not. stresses_on_device) return
+      f%stressp_1 = addr_r8(stressp_1); f%stressp_2 = addr_r8(stressp_2)
+      f%stressp_3 = addr_r8(stressp_3); f%stressp_4 = addr_r8(stressp_4)
+      f%stressm_1 = addr_r8(stressm_1); f%stressm_2 = addr_r8(stressm_2)
+      f%stressm_3 = addr_r8(stressm_3); f%stressm_4 = addr_r8(stressm_4)
+      f%stress12_1 = addr_r8(stress12_1); f%stress12_2 = addr_r8(stress12_2)
+      f%stress12_3 = addr_r8(stress12_3); f%stress12_4 = addr_r8(stress12_4)
+      call cice_gpu_check(cice_evp_download_stresses(cice_gpu_ctx, f), 'evp_sync_stresses')
+      end subroutine evp_sync_stresses
 
 !=======================================================================
       subroutine init_evp (dt)

@@ -384,6 +384,10 @@ class Context:
         f = self._evp_fields(s)
         self._ck(self.lib.cice_evp_download(self.h, C.byref(f)))
 
+    def evp_download_stresses(self, s):
+        f = self._evp_fields(s)
+        self._ck(self.lib.cice_evp_download_stresses(self.h, C.byref(f)))
+
     def evp_step(self, dt):
         self._ck(self.lib.cice_evp_step(self.h, C.c_double(dt)))
 

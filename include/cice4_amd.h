@@ -186,8 +186,22 @@ typedef struct {
 int cice_evp_pin_fields(cice_ctx *ctx, const cice_evp_fields *f);
 
 /* Drop-in for `call evp(dt)` (ice_dyn_evp.F90:119-432): upload, run on the GPU,
- * download.  Equivalent to cice_evp_upload + cice_evp_step + cice_evp_download. */
+ * download.  Same results as cice_evp_upload + cice_evp_step + cice_evp_download, as one pipeline: the six fields the
+ * preparation leaves final (strairx, strairy, strength, fm, strtltx, strtlty) and iceumask travel to the host while the
+ * subcycle loop runs.
+ * Two statements a caller may make about itself (cice_evp_set_option; both off by default, both hold for the reference's
+ * unchanged driver):
+ *   "keep_state" = 1: between two cice_evp calls the caller does not change uvel, vvel, the 12 stresses or iceumask on
+ *     the host (in the reference only evp itself writes them, and the restart reader before the first step): from the
+ *     second call on they are not uploaded -- the device copies the last call left are the input.  = 2: and fm,
+ *     strtltx/y, strocnx/y, strintx/y (which evp reads back outside its ice mask) are ZERO on the host when cice_evp is
+ *     called, as init_history_dyn leaves them at the top of every step (ice_flux.F90:585-602): zeroed on the device.
+ *     cice_evp_init, cice_evp_upload / _prepare / _subcycles / _finish / _step end the statement's effect for one call.
+ *   "lazy_stresses" = 1: cice_evp leaves the 12 stresses on the device; cice_evp_download_stresses brings them to the host
+ *     (the reference reads them there only for its history and restart files: ice_history.F90:1939, ice_restart.F90:74-256).
+ * gx1 size over PCIe (profiles/r05_bench_gx1.json, pcie_inclusive): see DESIGN.md section 6. */
 int cice_evp(cice_ctx *ctx, double dt, cice_evp_fields *f);
+int cice_evp_download_stresses(cice_ctx *ctx, cice_evp_fields *f);   /* the 12 stresses of the device state -> host */
 /* Device-resident hand-off from the thermodynamic half-step to the dynamics (SURVEY section 8 f1;
  * drivers/cice4/CICE_RunMod.F90:374-591 -> source/ice_step_mod.F90:575): aicen, vicen of the batched thermo state
  * (cice_step_therm1 / cice_thermo_batch_step leave them on the device) become the dynamics' aicen, vicen, and aice, vice,

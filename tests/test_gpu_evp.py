@@ -1383,3 +1383,73 @@ def test_page_locked_host_arrays_give_the_same_result(orc):
         assert np.array_equal(a[k], b[k]), k
     c.host_unregister_all()                             # before the arrays go away
     del c
+
+
+FLUX7 = ("fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty")
+
+
+@pytest.mark.parametrize("keep,lazy,pinned", [(1, 0, False), (2, 0, True), (2, 1, True), (1, 1, False)])
+def test_evp_over_pcie_leaves_on_the_device_what_the_caller_does_not_touch(keep, lazy, pinned):
+    """cice_evp with the caller's two statements (include/cice4_amd.h: "keep_state", "lazy_stresses") against plain cice_evp,
+    five steps of a driver that does what the reference's does between two evp calls: new forcing and state every step,
+    the dynamic history fields zeroed (init_history_dyn, /root/reference/source/ice_flux.F90:585-602).  Bit for bit the same
+    fields on the host after every step.  That the planes really stay where they are: the kept host arrays are filled with
+    NaN behind the library's back (a caller that breaks its statement) and nothing changes."""
+    c = lib.Context(); c.sync()
+    dom = c.domain_create(100, 116, 100, 116, ew=1, ns=0)
+    grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.1, land_frac=0.05, seed=5), dom)
+    s0 = synth.evp_state(grid, dom, seed=5, cover="patchy", moving=False)
+    rng = np.random.default_rng(11)
+    forcing = [{k: s0[k] * (1.0 + 0.2 * rng.standard_normal()) for k in ("strairxT", "strairyT", "uocn", "vocn")} for _ in range(5)]
+    cover = [np.clip(s0["aicen"] * (1.0 + 0.05 * step), 0.0, 0.19) for step in range(5)]
+
+    def drive(state, step):
+        """the host side of one step, before evp"""
+        for k, v in forcing[step].items():
+            state[k][...] = v
+        state["aicen"][...] = cover[step]
+        state["aice"][...] = state["aicen"].sum(axis=1) if state["aicen"].ndim == 4 else state["aicen"].sum(axis=0)
+        state["aice0"][...] = 1.0 - state["aice"]
+        for k in FLUX7 + ("prs_sig",):
+            state[k][...] = 0.0
+
+    c.evp_init(grid, ndte=8)
+    plain = {k: v.copy() for k, v in s0.items()}
+    want = []
+    for step in range(5):
+        drive(plain, step)
+        c.evp(DT, plain)
+        want.append({k: plain[k].copy() for k in EVP_OUT_FIELDS + ("iceumask",)})
+    assert np.abs(want[-1]["uvel"]).max() > 1e-3 and not np.array_equal(want[1]["stressp_1"], want[4]["stressp_1"])
+
+    c.evp_init(grid, ndte=8)
+    c.evp_set_option("keep_state", keep); c.evp_set_option("lazy_stresses", lazy)
+    got = {k: v.copy() for k, v in s0.items()}
+    if pinned:
+        c.evp_pin_fields(got)
+    for step in range(5):
+        drive(got, step)
+        c.evp(DT, got)
+        for k in EVP_OUT_FIELDS + ("iceumask",):
+            if lazy and k in synth.SIG_NAMES:
+                continue
+            assert np.array_equal(got[k], want[step][k]), (step, k)
+        if lazy:
+            if step in (2, 4):          # a step that writes history / a restart file
+                c.evp_download_stresses(got)
+                for k in synth.SIG_NAMES:
+                    assert np.array_equal(got[k], want[step][k]), (step, k)
+            else:
+                for k in synth.SIG_NAMES:
+                    assert not np.array_equal(got[k], want[step][k]), (step, k, "was downloaded all the same")
+        # the kept planes are not read again: a caller that overwrites them on the host changes nothing
+        for k in ("uvel", "vvel", "iceumask") + synth.SIG_NAMES:
+            got[k][...] = 0 if k == "iceumask" else np.nan
+    # an explicit upload ends the statement for one call: the host arrays are the input again
+    fresh = {k: v.copy() for k, v in s0.items()}
+    drive(fresh, 0)
+    c.evp_upload(fresh); c.evp_step(DT); c.evp_download(fresh)
+    for k in EVP_OUT_FIELDS:
+        assert np.array_equal(fresh[k], want[0][k]), k
+    c.host_unregister_all()
+    del c

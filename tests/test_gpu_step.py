@@ -81,9 +81,12 @@ def test_pure_reference_reproduces_its_golden_dump(name):
 @pytest.mark.parametrize("name,tol", [("gx3_exact3", 0.0), ("gx3_default3", TOL_EXP), ("gx3_default25", TOL_EXP),
                                       ("gx1_default3", TOL_EXP)])
 def test_reference_step_loop_with_dropin_modules(name, tol):
-    # (gx3_default25 also runs with the evp -> transport chain: same dump)
-    rec, gold, stride, log = _run_case("dropin", name, {"CICE4_AMD_STATS": "1", **({"CICE4_AMD_CHAIN": "1"} if name == "gx3_default25" else {})})
+    # (gx3_default25 also runs with the evp -> transport chain: same dump; gx3_exact3 and gx1_default3 with evp's io state
+    #  kept on the device between the steps -- the reference's driver is a caller of which both statements hold)
+    extra = {"CICE4_AMD_CHAIN": "1"} if name == "gx3_default25" else {"CICE4_AMD_KEEP_STATE": "2"} if name in ("gx3_exact3", "gx1_default3") else {}
+    rec, gold, stride, log = _run_case("dropin", name, {"CICE4_AMD_STATS": "1", **extra})
     assert "EVP dynamics on the GPU" in log and "Incremental remapping on the GPU" in log
+    assert ("evp keeps uvel, vvel, the stresses and iceumask on the device" in log) == ("CICE4_AMD_KEEP_STATE" in extra)
     assert "on 1 block(s): 1 kernel launch(es)" in log
     assert ("transport_remap takes its state from the device after evp" in log) == (name == "gx3_default25")
     worst = _compare(rec, gold, stride, tol)
@@ -115,8 +118,10 @@ def test_restart_round_trip_with_dropin_modules():
             shutil.copy(f, dirs["B"] + "/restart/")
         with open(dirs["B"] + "/restart/ice.restart_file", "w") as f:
             f.write("./restart/iced.1997-01-02-00000\n")
-        log = driver.run(exe["dropin"], dirs["B"])
-        assert "Using restart dump" in log and "EVP dynamics on the GPU" in log
+        # (the restarted run also keeps evp's io state on the device: what the restart reader put into the module arrays
+        #  travels up with the first call)
+        log = driver.run(exe["dropin"], dirs["B"], env={"CICE4_AMD_KEEP_STATE": "2"})
+        assert "Using restart dump" in log and "EVP dynamics on the GPU" in log and "evp keeps uvel, vvel" in log
         a2 = driver.read_restart(dumps["A"][1], 100, 116)
         b2 = driver.read_restart(dirs["B"] + "/restart/iced.1997-01-03-00000", 100, 116)
         r2 = driver.read_restart(dumps["R"][1], 100, 116)
