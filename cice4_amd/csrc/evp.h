@@ -172,7 +172,7 @@ class Evp {
   hipEvent_t res_done_ev = nullptr;   // end of the cross-rank loop, polled (run_resident)
   int res_retry_steps = 64;      // evp(dt) calls after which a time-out is forgiven (a co-tenant may have left), 0 = never
   int res_retry_in = 0;          // calls left until then (0: nothing to forgive, or not forgivable)
-  int res_occ[5][2][5] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN), 0 = not asked yet
+  int res_occ[5][2][6] = {};     // workgroups of k_evp_resident<W, DAMP, PEER | FOLD | GRAN> one CU holds (last index: plain, PEER, FOLD, GRAN, FOLD + GRAN, PEER + FOLD), 0 = not asked yet
   int res_gran = 1;              // one-rank domains without a fold: edge velocities travel as data-tagged granules (option "resident_granules": 0 never, 1 by the ice cover, 2 always)
   unsigned* res_why = nullptr;   // page-locked: the eight words read back behind every one-launch loop
   bool res_sparse = false;       // the last step's ice cover left most tiles of the loop empty (run_resident reads k_res_choose_map's count)
@@ -196,7 +196,7 @@ class Evp {
   bool res_fold_on = true;       // one-block tripole domains run the one-launch loop with the fold inside
   void build_resident(int W);
   void build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W);   // tripole north boundary inside the loop
-  DevBuf<int32_t> res_ftab, res_deps2;
+  DevBuf<int32_t> res_ftab, res_deps2, res_fslot, res_ffwd;
   DevBuf<unsigned> res_prog2;
   DevBuf<double> res_xraw[2];
   void build_resident_peer(int W);

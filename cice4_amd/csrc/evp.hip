@@ -1562,6 +1562,8 @@ struct ResArgs {
   // changed by the fold itself -- symmetric average with the partner across the pole, or a mirror image, or a sign
   // flip -- from the RAW values of the subcycle, which the tiles of the top row hand to each other in a phase of their
   // own (xraw, prog2, deps2) before anything is published.
+  const int32_t* fslot;  // [cells] / [slots][4]: ghost cells of THIS block the fold fills from a cell -- as rslot / rfwd, entries
+  const int32_t* ffwd;   //   (negate << 30) | address (tables of their own: across ranks rslot / rfwd name the neighbours' cells)
   const int32_t* ftab;   // [2 * cells] owned top-row cells: partner address (-1: none) and mode bits (F_*)
   double* xraw[2];       // [parity] raw top-row velocities (u at 0, v at a.n)
   unsigned* prog2;       // [tiles * RES_STRIDE] raw top row of subcycle k published = epoch0 + k + 1
@@ -1696,7 +1698,8 @@ template <int W, bool DAMP, bool PEER, bool FOLD = false, bool GRAN = false>
 // 12 put three wavefronts of one workgroup on a SIMD: both need the 168-register budget whatever the compiler would
 // like to use)
 __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256)) void k_evp_resident(const ResArgs r) {
-  static_assert(!(PEER && FOLD), "the fold is handled on one-rank domains");
+  // (PEER && FOLD: the rank that holds the top slab of a tripole grid cut into full-width slabs -- its fold is its own affair,
+  //  handled exactly as on one rank, its southern neighbour is reached as in any cross-rank loop)
   static_assert(!(GRAN && PEER), "granule hand-off: one rank");
   const SubArgs& a = r.a;
   __shared__ double s_uv[W][2][TX];
@@ -1804,9 +1807,9 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
     s_fd[w][0][lx] = fd0; s_fd[w][1][lx] = fd1; s_fd[w][2][lx] = fd2;
     // (GRAN: every owned edge cell is published, with or without ice -- see `produced` below)
     edge = (GRAN ? uown : uact) && (lx == 0 || lx == TX - 2 || w == 0 || w == W - 2 || i == ihi || j == jhi || fd0 >= 0);
-    if (PEER || FOLD) {
+    if (PEER) {
       int rf[4] = {-1, -1, -1, -1};
-      if (FOLD ? uown : uact) {
+      if (uact) {
         const int rs = r.rslot[q];
         if (rs >= 0) {
 #pragma unroll
@@ -1814,11 +1817,18 @@ __global__ __launch_bounds__(64 * W, (W == 4 && !PEER ? 3 : (64 * W + 255) / 256
         }
       }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (PEER) s_rfd[w][c][lx] = rf[c];
-        else rfr[c] = rf[c];
-      }
+      for (int c = 0; c < 4; ++c) s_rfd[w][c][lx] = rf[c];
       edge = edge || rf[0] >= 0;
+    }
+    if (FOLD) {
+      if (uown) {
+        const int rs = r.fslot[q];
+        if (rs >= 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) rfr[c] = r.ffwd[4 * rs + c];
+        }
+      }
+      edge = edge || rfr[0] >= 0;
     }
   }
   // FOLD: the owned cells of the top row (with or without ice: the average with an ice-covered partner is not zero)
@@ -3344,14 +3354,19 @@ void Evp::download_stresses(cice_evp_fields& f) {
 void Evp::run(double dt, cice_evp_fields& f, const std::function<void()>& while_looping) {
   upload_some(f, io_valid ? keep_state : 0);
   prepare(dt);
-  fan.fork(stream);          // the side streams wait for prepare()
-  download_some(f, 1);
-  fan.detach();              // ... and nobody waits for them yet
+  // (not where the loop waits for other ranks' loops: ranks that share ONE device -- the rehearsals of tests/ranks_case.py --
+  //  need a hardware queue each for their loops, and copy streams that are busy at that moment take queues away)
+  const bool early = !halo.multi_rank();
+  if (early) {
+    fan.fork(stream);        // the side streams wait for prepare()
+    download_some(f, 1);
+    fan.detach();            // ... and nobody waits for them yet
+  }
   if (while_looping) while_looping();   // (cice_transport_chain: the transport's state travels up now)
   subcycles(1, sc.ndte, nullptr);
   finish();
   fan.fork(stream);          // (the side streams run in order: the copies above are done before these)
-  download_some(f, 2);
+  download_some(f, early ? 2 : 3);
   if (lazy_sig) {
     fan.join();
     CICE_HIP(hipStreamSynchronize(stream));
@@ -4806,8 +4821,11 @@ void Evp::peer_connect(int side, void* xu0, void* xu1, void* rprog, long long pe
 
 bool Evp::can_reside_peer() const {
   if (!resident_on || resident_failed || !halo.multi_rank()) return false;
-  if (!halo.fwd_ok() || dom.nblocks() < 1 || dom.overlap > 0 || halo.has_fold()) return false;
-  if (dom.tripole() || halo.has_onrank_refresh()) return false;
+  if (!halo.fwd_ok() || dom.nblocks() < 1 || dom.overlap > 0) return false;
+  // a tripole grid: full-width slabs, one per rank -- the partner of every top-row cell then lies on the rank of the top
+  // slab itself, which runs the PEER && FOLD form of the loop; the other ranks run as on any grid
+  if ((dom.tripole() || halo.has_fold()) && (dom.nbx != 1 || dom.nblocks() != 1 || !res_fold_on)) return false;
+  if (halo.has_onrank_refresh()) return false;
   // any number of blocks per rank, every block of the same size (a neighbour's tiles are numbered block by block on OUR
   // tile grid).  Ghost cells that face an ELIMINATED land block have neither a message nor an on-rank source: nobody
   // produces them, nobody waits for them, they keep the fill value the halo update of prepare() gave them -- as in the
@@ -4896,6 +4914,9 @@ void Evp::build_resident_peer(int W) {
   if (rfwd.empty()) rfwd.assign(4, -1);
   std::vector<int32_t> src_of(np * nb, -1);
   for (size_t e = 0; e < dom.hsrc.size(); ++e) src_of[dom.hdst[e]] = dom.hsrc[e];
+  // the top slab of a tripole grid: its fold is this rank's own affair, exactly as on one rank (the ghost row above it
+  // gets its sources from the fold, the top row its partners; can_reside_peer has checked that the block spans the width)
+  if (halo.has_fold()) build_resident_fold(src_of, tiles_x, W);
   auto owner = [&](int b, int i, int j) -> int {   // block, 1-based cell -> tile producing its velocity: local >= 0, remote <= -2, -1 nobody
     if (i < 1 || i > nx || j < 1 || j > ny) return -1;
     size_t q = (size_t)b * np + (size_t)(j - 1) * nx + (i - 1);
@@ -5104,8 +5125,8 @@ void Evp::build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W) 
     deps2[(size_t)t * 4 + k] = o;
   }
   res_ftab.alloc(ftab.size()); res_ftab.upload(ftab.data(), stream);
-  res_rslot.alloc(rslot.size()); res_rslot.upload(rslot.data(), stream);
-  res_rfwd.alloc(rfwd.size()); res_rfwd.upload(rfwd.data(), stream);
+  res_fslot.alloc(rslot.size()); res_fslot.upload(rslot.data(), stream);
+  res_ffwd.alloc(rfwd.size()); res_ffwd.upload(rfwd.data(), stream);
   res_deps2.alloc(deps2.size()); res_deps2.upload(deps2.data(), stream);
   res_prog2.alloc((size_t)nt * RES_STRIDE); res_prog2.zero(stream);
   for (int k = 0; k < 2; ++k)
@@ -5210,8 +5231,13 @@ template <int W>
 static void launch_res(const ResArgs& r, bool damp, bool peer, dim3 g, hipStream_t s) {
   if (peer) {
     if constexpr (W <= 11) {   // (12 wavefronts + the table of remote ghost cells do not fit the LDS)
-      if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, true>), g, dim3(64 * W), 0, s, r);
-      else hipLaunchKernelGGL((k_evp_resident<W, false, true>), g, dim3(64 * W), 0, s, r);
+      if (r.ftab) {
+        if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, true, true>), g, dim3(64 * W), 0, s, r);
+        else hipLaunchKernelGGL((k_evp_resident<W, false, true, true>), g, dim3(64 * W), 0, s, r);
+      } else {
+        if (damp) hipLaunchKernelGGL((k_evp_resident<W, true, true>), g, dim3(64 * W), 0, s, r);
+        else hipLaunchKernelGGL((k_evp_resident<W, false, true>), g, dim3(64 * W), 0, s, r);
+      }
     } else {
       throw Error{CICE_EINVAL, "resident EVP loop across ranks: at most 11 wavefronts per workgroup"};
     }
@@ -5256,6 +5282,10 @@ static int occ_res(bool damp, bool peer, bool fold = false, bool gran = false) {
     }
   } else if (peer) {
     if constexpr (W <= 11) {
+      if (fold)
+        e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, true, true>, 64 * W, 0)
+                 : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, true, true>, 64 * W, 0);
+      else
       e = damp ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, true, true>, 64 * W, 0)
                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_evp_resident<W, false, true>, 64 * W, 0);
     } else {
@@ -5276,9 +5306,9 @@ static int occ_res(bool damp, bool peer, bool fold = false, bool gran = false) {
 // loop needs every tile resident at once, and a kernel that grew past its budget must not find that out by time-out
 int Evp::resident_occupancy(int W, bool damp, bool peer) {
   const int wi = W == 4 ? 0 : W == 6 ? 1 : W == 8 ? 2 : W == 11 ? 3 : 4;
-  const bool fold = !peer && halo.has_fold();
+  const bool fold = halo.has_fold();
   const bool gran = !peer && granules_on() && !resident_dense();
-  int& c = res_occ[wi][damp][peer ? 1 : (fold ? (gran ? 4 : 2) : (gran ? 3 : 0))];
+  int& c = res_occ[wi][damp][peer ? (fold ? 5 : 1) : (fold ? (gran ? 4 : 2) : (gran ? 3 : 0))];
   if (c == 0) {
     int nb = 0;
     switch (W) {
@@ -5332,9 +5362,9 @@ bool Evp::run_resident(int ksub0, int nsub) {
   r.xu[0] = res_xu[0].p;
   r.xu[1] = res_xu[1].p;
   r.spin_ticks = (long long)res_spin_us * 100;   // wall_clock64() runs at 100 MHz
-  if (!peer && halo.has_fold()) {
-    r.rslot = res_rslot.p;
-    r.rfwd = res_rfwd.p;
+  if (halo.has_fold()) {   // (one rank, or the rank with the top slab of a tripole grid cut into full-width slabs)
+    r.fslot = res_fslot.p;
+    r.ffwd = res_ffwd.p;
     r.ftab = res_ftab.p;
     r.xraw[0] = res_xraw[0].p;
     r.xraw[1] = res_xraw[1].p;

@@ -277,6 +277,10 @@ int cice_evp_active_cells(cice_ctx *ctx, long long *n_tcells, long long *n_ucell
  * With every neighbour connected, cice_evp_get_info("resident_peer") is 1 and cice_evp / cice_evp_subcycles run the loop
  * as one launch per rank; a rank whose launch times out raises a flag that is all-reduced over the communicator
  * ("resident_peer_agree", default 1) so that all ranks fall back to the launch-per-pair loop together.
+ * Under a tripole north boundary (ns_boundary 3, 4) the loop runs where every rank holds ONE block that spans the width
+ * (j-slabs): the rank with the top slab carries the fold inside its loop, as a one-rank domain does
+ * (serial/ice_boundary.F90:705-869 on the degenerate row); layouts with a rank boundary through the fold keep the
+ * message path (resident_peer stays 0).
  * "resident_peer_share": contexts sharing one device (default 1; the one-GPU test uses 2).
  * Memory types: the three exported buffers -- what another device writes (edge velocities, progress words) while a launch
  * of this one polls and reads them -- are FINE-GRAINED device memory (hipExtMallocWithFlags(hipDeviceMallocFinegrained));

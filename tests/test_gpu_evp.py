@@ -698,14 +698,17 @@ def test_ranks_with_an_eliminated_land_block(orc, mode):
 
 @pytest.mark.parametrize("ns", [3, 4])
 @pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
-                                       ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96)])
+                                       ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96), ("peer", 2, 72), ("peer", 3, 96),
+                                       ("peer", 3, 36)])
 def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     """Wide-halo slabs under a tripole north boundary (ns 3: fold through U points, 4: through T points), R ranks = R
     contexts of this process: the rank with the top slab folds u, v after every subcycle (its overlap rows come with the
     refresh like everybody's); it runs one launch per subcycle or, "sweep", K subcycles per sweep with the band of top
     rows beside it (K = 3, or 4 which does not divide the refresh interval), while the ranks below keep their pairs /
     plain sweeps.  slabs0: no overlap, ghost rows and the fold
-    after every subcycle.  Against the one-block domain through one launch per subcycle (pinned to the compiled reference
+    after every subcycle.  peer (round 5): the whole loop in ONE launch per rank -- the rank with the top slab runs the
+    cross-rank loop WITH the fold inside (its top-row tiles exchange their raw velocities among themselves, as on one rank),
+    the others the plain cross-rank loop.  Against the one-block domain through one launch per subcycle (pinned to the compiled reference
     on such a grid), bit for bit on every owned cell; ocean and patchy ice up to the fold."""
     import threading
     nxg = 96
@@ -715,28 +718,46 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
     s1, _ = _evp_with(ctx, grid1, s1, NDTE, False, resident=0, skew=0, skew_fold=0)
     assert np.abs(s1["uvel"][0, -3:]).max() > 1e-4
-    H = int(mode[5])
+    H = 0 if mode == "peer" else int(mode[5])
     _LINK[0] += 1
     link = _LINK[0]
     bar = threading.Barrier(R)
-    out, errs = [None] * R, []
+    out, errs, exports = [None] * R, [], [None] * R
 
     def rank_fn(r):
         try:
             c = lib.Context(device=0); c.sync()
-            dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=ns, rank=r, nranks=R, overlap=H)
+            if mode == "peer":
+                dom = c.domain_create(nxg, nyg, nxg, nyg // R, ew=1, ns=ns, rank=r, npx=1, npy=R)
+            else:
+                dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=ns, rank=r, nranks=R, overlap=H)
             assert dom["nblocks"] == 1 and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
             grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True)
             s = synth.evp_state(grid, dom, seed=31, cover="patchy")
             c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
-            c.evp_set_option("resident", 0)
-            if "sweep" in mode:      # "sweep4": K = 4 does not divide the 6 subcycles between refreshes (4 + 1 + 1 / 4 + 2)
+            if mode == "peer":
+                c.evp_set_option("resident_peer_share", R)
+                exports[r] = c.evp_peer_export()
+                bar.wait(timeout=120)
+                nbrs = c.evp_peer_ranks()
+                assert nbrs == [x for x in (r - 1, r + 1) if 0 <= x < R], nbrs      # (nobody is the top slab's northern neighbour)
+                for nr in nbrs:
+                    c.evp_peer_connect_rank(nr, exports[nr])
+                assert c.evp_get_info("resident_peer") == 1
+                bar.wait(timeout=120)
+            else:
+                c.evp_set_option("resident", 0)
+            if mode == "peer":
+                pass
+            elif "sweep" in mode:      # "sweep4": K = 4 does not divide the 6 subcycles between refreshes (4 + 1 + 1 / 4 + 2)
                 c.evp_set_option("skew_min_cells", 0); c.evp_set_option("skew_levels", int(mode[-1]) if mode[-1].isdigit() else 3)
                 assert c.evp_get_info("skew_fold" if r == R - 1 else "skew") == 1, r
             else:
                 c.evp_set_option("skew", 0); c.evp_set_option("skew_fold", 0)
             c.evp(DT, s)
+            if mode == "peer":
+                assert c.evp_get_info("resident_peer") == 1 and c.evp_get_info("last_launches") == 1, "the cross-rank loop fell back"
             out[r] = (dom, s)
             bar.wait(timeout=120)
         except BaseException as e:       # noqa: BLE001 -- reported by the main thread
