@@ -52,7 +52,7 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                 dom = c.domain_create(nxg, nyg, nxg // (npx * blocks[0]), nyg // (npy * blocks[1]), ew=1, ns=ns, rank=r, npx=npx, npy=npy)
             assert (block_map is not None or dom["nblocks"] == blocks[0] * blocks[1]) and dom["nsend"] >= 1
             c.comm_init_local(link, r, R)
-            grid = synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
+            grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True) if ns in (3, 4) else synth.block_fields(gg, dom, ns_cyclic=(ns == 1))
             s = synth.evp_state(grid, dom, seed=seed, cover=cover)
             kw = dict(krdg_partic=0, krdg_redist=0) if strength_args is None else strength_args
             c.evp_init(grid, ndte=ndte, **kw)

@@ -699,7 +699,7 @@ def test_ranks_with_an_eliminated_land_block(orc, mode):
 @pytest.mark.parametrize("ns", [3, 4])
 @pytest.mark.parametrize("mode,R,nyg", [("slabs0", 2, 72), ("slabs4", 2, 72), ("slabs4", 3, 96), ("slabs6-sweep", 2, 96),
                                        ("slabs6-sweep", 3, 144), ("slabs6-sweep4", 2, 96), ("peer", 2, 72), ("peer", 3, 96),
-                                       ("peer", 3, 36)])
+                                       ("peer", 3, 36), ("peer-W11", 2, 72), ("peer-W8", 3, 96), ("peer-W6", 2, 72)])
 def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     """Wide-halo slabs under a tripole north boundary (ns 3: fold through U points, 4: through T points), R ranks = R
     contexts of this process: the rank with the top slab folds u, v after every subcycle (its overlap rows come with the
@@ -718,6 +718,9 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     s1 = synth.evp_state(grid1, dom1, seed=31, cover="patchy")
     s1, _ = _evp_with(ctx, grid1, s1, NDTE, False, resident=0, skew=0, skew_fold=0)
     assert np.abs(s1["uvel"][0, -3:]).max() > 1e-4
+    peer_w = int(mode[6:]) if mode.startswith("peer-W") else 0
+    if peer_w:
+        mode = "peer"
     H = 0 if mode == "peer" else int(mode[5])
     _LINK[0] += 1
     link = _LINK[0]
@@ -738,6 +741,8 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
             c.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
             if mode == "peer":
                 c.evp_set_option("resident_peer_share", R)
+                if peer_w:
+                    c.evp_set_option("resident_waves", peer_w)
                 exports[r] = c.evp_peer_export()
                 bar.wait(timeout=120)
                 nbrs = c.evp_peer_ranks()

@@ -270,7 +270,7 @@ def test_tenth_degree_width_tripole_grid_on_two_ranks(ctx, ns):
 # 48-row slabs under bench.auto_overlap's H, eight one-launch loops joined edge to edge, the sweep's tile lists with the
 # extension trimmed on BOTH edges (Evp::tiles_for).
 
-@pytest.mark.parametrize("mode", ["classic", "peer", "slabs", "slabs-sweep"])
+@pytest.mark.parametrize("mode", ["classic", "peer", "peer-tripole", "slabs", "slabs-sweep"])
 def test_gx1_on_eight_ranks(orc, mode):
     """gx1 320 x 384, ndte 120, as 8 j-slabs of 48 rows (configs[3]) against the checker on the whole grid, bit for bit on
     every owned cell of u, v, the 12 stresses and the diagnostics:
@@ -285,12 +285,14 @@ def test_gx1_on_eight_ranks(orc, mode):
     import ranks_case
     bench = importlib.import_module("bench")
     nxg, nyg, R, ndte = 320, 384, 8, 120
-    if mode == "peer":
+    if mode in ("peer", "peer-tripole"):
         # eight loops that wait for each other have to run at the same time: one hardware queue each (tests/ranks_peer_case.py)
+        # (peer-tripole, round 5: the same under a tripole fold -- rank 7 runs the cross-rank loop with the fold inside)
         import os, subprocess, sys
         env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
         r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "ranks_peer_case.py"),
-                            "1", str(R), str(nxg), str(nyg), str(ndte)], env=env, capture_output=True, text=True, timeout=600)
+                            "1", str(R), str(nxg), str(nyg), str(ndte)] + (["3"] if mode == "peer-tripole" else []),
+                           env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
         assert "bit-identical" in r.stdout
         return
