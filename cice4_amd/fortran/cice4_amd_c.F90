@@ -595,7 +595,14 @@ contains
       enddo
       deallocate(every, planes)
       call MPI_BARRIER(comm, ierr)
-      if (my_task == 0) write(*,*) 'EVP subcycling as one launch per task: exchange buffers of the neighbouring tasks connected'
+      call cice_gpu_check(cice_evp_get_info(cice_gpu_ctx, 'resident_peer'//c_null_char, share), 'resident_peer')
+      if (my_task == 0) then
+         if (share == 1) then
+            write(*,*) 'EVP subcycling as one launch per task: exchange buffers of the neighbouring tasks connected'
+         else     ! e.g. a task boundary through a tripole fold, more tiles than compute units
+            write(*,*) 'EVP subcycling keeps its message exchange (the cross-task loop does not cover this decomposition)'
+         endif
+      endif
    end subroutine cice_gpu_peer_setup
 #endif
 

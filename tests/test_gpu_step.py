@@ -251,12 +251,15 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ns,nprocs", [("tripole", 2), ("tripole", 4), ("tripoleT", 4)])
-def test_whole_model_as_an_mpi_job_across_a_tripole_fold(ns, nprocs):
+@pytest.mark.parametrize("ns,nprocs,cfg", [("tripole", 2, "gx3b4"), ("tripole", 4, "gx3b4"), ("tripoleT", 4, "gx3b4"),
+                                           ("tripole", 2, "gx3s2"), ("tripoleT", 2, "gx3s2")])
+def test_whole_model_as_an_mpi_job_across_a_tripole_fold(ns, nprocs, cfg):
     """The same MPI job with a tripole north boundary and ocean up to the fold: the top rows of the two blocks of the top
     block row travel between tasks into every task's fold buffer (one more message pair per ice_HaloUpdate), the fold is
-    applied after every EVP subcycle.  Against the pure SERIAL reference (one block) with the same namelist and mask."""
-    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_gx3b4")
+    applied after every EVP subcycle.  Against the pure SERIAL reference (one block) with the same namelist and mask.
+    cfg gx3s2 (round 5): two full-width slabs -- every partner across the pole lies on the task of the top slab, which runs
+    the cross-task one-launch loop with the fold inside; the task below the plain cross-task loop: ONE launch per task."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "cice_dropinmpi_%s" % cfg)
     ref_exe = os.path.join(ROOT, "oracle", "_ref", "cice_ref_gx3")
     for e in (exe, ref_exe):
         if not os.path.exists(e):
@@ -270,7 +273,12 @@ def test_whole_model_as_an_mpi_job_across_a_tripole_fold(ns, nprocs):
             driver.write_rundir(rd, npt=25, nprocs=n, overrides={"domain_nml": dict(ns_boundary_type=ns)})
             with open(os.path.join(rd, "kmt"), "wb") as f:
                 f.write(kmt.astype(">i4").tobytes())
-            driver.run(e, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(n)}, nprocs=n)
+            log = driver.run(e, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(n), "CICE4_AMD_STATS": "1"}, nprocs=n)
+            if kind == "mpi":
+                assert ("EVP subcycling as one launch per task" in log) == (cfg == "gx3s2"), log[-3000:]
+                assert "resident EVP loop timed out" not in log
+                if cfg == "gx3s2":
+                    assert "on 1 block(s): 1 kernel launch(es)" in log, log[-3000:]
             rec[kind] = driver.read_restart(driver.restart_path(rd), 100, 116)
         finally:
             shutil.rmtree(rd, ignore_errors=True)
