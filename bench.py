@@ -650,6 +650,7 @@ def cpu_baseline(wl, grid, state, dom, ndte, tcols, budget_s):
     return out
 
 
+ARITH_VALU_PER_WAVE_SUBCYCLE = 575.0   # stress + momentum of one row, one subcycle (SQ_INSTS_VALU of the barrier loop / wavefronts / subcycles)
 KERNEL_SOURCES = ("evp.hip", "evp.h", "therm.hip", "therm.h", "common.h", "libm_exact.h")
 
 
@@ -1053,7 +1054,19 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
             "counters_source": sq.get("source") if sq else None}
         if sq:   # the fraction that means something for this kernel: fp64 issue slots of the busiest SIMD that are used
             roofline["bound_effective"] = "valu_f64_issue"
-            roofline["frac_valu_issue"] = roofline["not_hbm_bound"]["issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] / us_sub
+            nh = roofline["not_hbm_bound"]
+            counted = nh["issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] / us_sub
+            if granules:
+                # The free-running loop WAITS by polling: its counted VALU instructions include the polls' (address arithmetic,
+                # tag compares), which are not work.  The arithmetic of a subcycle is the same code as in the barrier loop,
+                # whose waits issue next to nothing: 575 VALU instructions per wavefront (profiles/r04_sq_counters.csv,
+                # profiles/r02_sq_counters_resident.csv).  `frac_valu_issue` is the fraction by THAT count.
+                nh["valu_inst_per_wave_per_subcycle_arithmetic"] = ARITH_VALU_PER_WAVE_SUBCYCLE
+                nh["arithmetic_issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] = 3 * ARITH_VALU_PER_WAVE_SUBCYCLE * 4 / 2400.0
+                roofline["frac_valu_issue_counting_the_polls"] = counted
+                roofline["frac_valu_issue"] = nh["arithmetic_issue_us_per_subcycle_3_waves_per_simd_at_2p4GHz"] / us_sub
+            else:
+                roofline["frac_valu_issue"] = counted
             ghz, src = inkernel_clock(wl)
             if ghz:   # the same fraction at the clock the kernel really holds (2.4 GHz is the nominal figure)
                 roofline["clock_ghz"] = ghz

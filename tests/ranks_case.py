@@ -85,9 +85,18 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
                     assert c.evp_get_info("skew_trim_ext") == 1
                 else:
                     c.evp_set_option("skew", 0)
-            c.evp(dt, s)
             if mode == "peer":
+                # R loops on ONE device wait for each other, and a copy stream of one rank may share a hardware queue with the
+                # main stream of another: no rank's loop may start while another rank's uploads are still queued (on a node
+                # every rank has a device, and queues, of its own).  Same entry points as cice_evp, a barrier in between.
+                c.evp_upload(s)
+                bar.wait(timeout=120)
+                c.evp_step(dt)
+                bar.wait(timeout=timeout)
+                c.evp_download(s)
                 assert c.evp_get_info("resident_peer") == 1, "the cross-rank loop timed out and fell back"
+            else:
+                c.evp(dt, s)
             if info is not None and r == 0:
                 for k in ("fused", "skew", "skew_levels", "last_launches"):
                     info[k] = c.evp_get_info(k)
