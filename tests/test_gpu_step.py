@@ -227,8 +227,11 @@ def test_whole_model_as_an_mpi_job_on_one_gpu(cfg, nprocs):
     rd = tempfile.mkdtemp(prefix="cice_mpi_")
     try:
         driver.write_rundir(rd, npt=25, nprocs=nprocs)
-        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(nprocs), "CICE4_AMD_STATS": "1"},
+        # (gx3s2 and the four-task job also keep evp's io state on the device between the steps: CICE4_AMD_KEEP_STATE, same dump)
+        keep = {"CICE4_AMD_KEEP_STATE": "2"} if (cfg == "gx3s2" or nprocs == 4) else {}
+        log = driver.run(exe, rd, env={"CICE4_AMD_LINK": "shm", "CICE4_AMD_PEER_SHARE": str(nprocs), "CICE4_AMD_STATS": "1", **keep},
                          nprocs=nprocs)
+        assert ("evp keeps uvel, vvel, the stresses and iceumask on the device" in log) == bool(keep)
         hdr, rec = driver.read_restart(driver.restart_path(rd), 100, 116)
     finally:
         shutil.rmtree(rd, ignore_errors=True)
