@@ -1,3 +1,7 @@
+"""The one-launch granule loop under a tripole fold at 11 wavefronts per workgroup, many evp(dt) calls from one state against the
+per-subcycle path: the case that showed the store-data hazard of profiles/r05_resident_granules.txt section 11 (18 of 40 calls
+wrong at ndte = 32 before st_gran kept its registers live behind the store; none since).
+usage: soak_fold_granules_w11.py <library.so> <ndte,ndte,...>   (scripts/gpu_r5_24.sh)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
