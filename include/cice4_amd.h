@@ -217,7 +217,9 @@ int cice_evp_download(cice_ctx *ctx, cice_evp_fields *f);       /* io + out fiel
  * prepare = ice_dyn_evp.F90:214-344 (prep1, masks, T->U, prep2, strength, halos);
  * subcycles = nsub passes of :347-404 starting at subcycle ksub0 (1-based; the pass with
  * ksub == ndte also writes divu, shear, rdg_conv, rdg_shear, prs_sig, strint, strocn); finish = :410-428.
- * elapsed_ms (may be NULL) is the HIP-event time of the launches on the library's stream. */
+ * elapsed_ms (may be NULL) is the HIP-event time of the launches on the library's stream; where the range runs as the one-launch
+ * loop, of that ONE launch (what rocprofv3 reports for the kernel), without the small launch that picks the tile map in front
+ * of it and the read-back of the abort word behind it. */
 int cice_evp_prepare(cice_ctx *ctx, double dt);
 int cice_evp_subcycles(cice_ctx *ctx, int ksub0, int nsub, float *elapsed_ms);
 int cice_evp_finish(cice_ctx *ctx);
