@@ -948,12 +948,16 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
     # EXACTLY `steps` steps between barrier + synchronise on both sides, maximum over the ranks -- and that block
     # repeated until about `min_timed_s` of device time have been timed (a 13 ms block alone is not a measurement):
     # the reported block is the MEDIAN one; minimum, maximum and the number of blocks go into the line.
-    def one_block():
+    # Two kinds of blocks, alternating: the ones `value` comes from run the steps as a caller does; the others carry the HIP-event
+    # bracket of every launch (`us_per_launch` of the roofline) -- two event records per launch cost a step of the one-launch
+    # loop 7 us of its 585 (scripts/step_overhead.py; 20 us before the events lived with the object), which is the
+    # instrument's time, not the path's.  Both medians are in the line (timing.ms_per_step_with_event_bracket).
+    def one_block(events=False):
         sync_all()
         t0 = time.perf_counter()
         dev = 0.0
         for _ in range(steps):
-            dev += ctx.evp_subcycles(1, ndte, timed=True)
+            dev += ctx.evp_subcycles(1, ndte, timed=events)
         sync_all()
         t = time.perf_counter() - t0
         if dist is not None:
@@ -962,21 +966,27 @@ def measure_evp(ctx, args, wl, rank, world, dist, torch, have_torch_gpu, steps, 
             t, dev = float(tt[0]), float(tt[1])
         return t, dev
     measured_before = ctx.evp_get_info("skew_balanced") if skew_k else 0     # sweeps the library has measured (and synchronised on) so far
-    blocks = [one_block()]
+    blocks, eblocks = [one_block()], [one_block(True)]
     n_rep = [int(min(max_repeats, max(1, np.ceil(min_timed_s / max(blocks[0][0], 1e-6))))) - 1]
     if dist is not None:
         dist.broadcast_object_list(n_rep, src=0)
     for _ in range(n_rep[0]):
         blocks.append(one_block())
+        eblocks.append(one_block(True))
     order = sorted(range(len(blocks)), key=lambda k: blocks[k][0])
-    t_evp, dev_ms = blocks[order[len(order) // 2]]
+    t_evp = blocks[order[len(order) // 2]][0]
+    eorder = sorted(range(len(eblocks)), key=lambda k: eblocks[k][0])
+    t_events, dev_ms = eblocks[eorder[len(eorder) // 2]]
     measured_inside = (ctx.evp_get_info("skew_balanced") - measured_before) if skew_k else 0
     timing = {"blocks": len(blocks), "steps_per_block": steps, "timed_region_s": sum(b[0] for b in blocks),
               # sweeps whose workgroup times the library read back INSIDE the timed blocks (eager launch + synchronisation each:
               # the re-cut of the segment table, one loop in 96; 0 = every timed sweep replayed the graph)
               "sweeps_measured_inside_timed_region": measured_inside,
               "ms_per_step_median": 1e3 * t_evp / steps, "ms_per_step_min": 1e3 * blocks[order[0]][0] / steps,
-              "ms_per_step_max": 1e3 * blocks[order[-1]][0] / steps}
+              "ms_per_step_max": 1e3 * blocks[order[-1]][0] / steps,
+              "event_blocks": len(eblocks), "ms_per_step_with_event_bracket": 1e3 * t_events / steps,
+              "note": "value: the median of `blocks` blocks of exactly `steps` steps without per-launch events; roofline.us_per_launch: HIP "
+                      "events around every launch in `event_blocks` further blocks of the same steps, alternating with the first kind"}
     if dist is not None:
         cells = torch.tensor([nt, nu], dtype=torch.int64)
         dist.all_reduce(cells, op=dist.ReduceOp.SUM)

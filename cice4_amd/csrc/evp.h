@@ -198,6 +198,7 @@ class Evp {
   void build_resident_fold(std::vector<int32_t>& src_of, int tiles_x, int W);   // tripole north boundary inside the loop
   DevBuf<int32_t> res_ftab, res_deps2, res_fslot, res_ffwd;
   hipEvent_t res_t0 = nullptr, res_t1 = nullptr;   // subcycles(..., elapsed_ms): the bracket of the one launch of the loop
+  hipEvent_t sub_t0 = nullptr, sub_t1 = nullptr;   // ... of every other form of the range
   bool res_time_it = false, res_timed = false;
   DevBuf<unsigned> res_prog2;
   DevBuf<double> res_xraw[2];

@@ -2985,8 +2985,8 @@ inline dim3 grid1(size_t n) { return dim3((unsigned)((n + 255) / 256)); }
 Evp::~Evp() {
   drop_graph();
   if (res_done_ev) (void)hipEventDestroy(res_done_ev);
-  if (res_t0) (void)hipEventDestroy(res_t0);
-  if (res_t1) (void)hipEventDestroy(res_t1);
+  for (hipEvent_t e : {res_t0, res_t1, sub_t0, sub_t1})
+    if (e) (void)hipEventDestroy(e);
   if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (ev_join) (void)hipEventDestroy(ev_join);
   if (stream2) (void)hipStreamDestroy(stream2);
@@ -5609,15 +5609,16 @@ void Evp::launch_range(int ksub0, int nsub) {
 void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   CICE_REQUIRE(prepared, "cice_evp_subcycles before cice_evp_prepare");
   CICE_REQUIRE(ksub0 >= 1 && nsub >= 0, "bad subcycle range");
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // elapsed_ms: events that live as long as the object (creating and destroying a pair per call, and four records instead of
+  // two, cost a step of the one-launch loop 20 us of its 600: scripts/step_overhead.py).  The one-launch loop is timed around
+  // its ONE launch -- what rocprofv3 reports for the kernel -- not around the small launch that chooses the tile map before it
+  // and the read-back of the abort word behind it (run_resident); every other form of the range around all its launches.
+  hipEvent_t &e0 = sub_t0, &e1 = sub_t1;
+  const bool try_resident = nsub >= 2 && (can_reside() || can_reside_peer());
   if (elapsed_ms) {
-    CICE_HIP(hipEventCreate(&e0));
-    CICE_HIP(hipEventCreate(&e1));
-    CICE_HIP(hipEventRecord(e0, stream));
-    // (the one-launch loop is timed around its ONE launch -- what rocprofv3 reports for the kernel -- not around the small
-    //  launch that chooses the tile map before it and the read-back of the abort word behind it: run_resident)
-    if (!res_t0) CICE_HIP(hipEventCreate(&res_t0));
-    if (!res_t1) CICE_HIP(hipEventCreate(&res_t1));
+    for (hipEvent_t* e : {&sub_t0, &sub_t1, &res_t0, &res_t1})
+      if (!*e) CICE_HIP(hipEventCreate(e));
+    if (!try_resident) CICE_HIP(hipEventRecord(e0, stream));
   }
   res_time_it = elapsed_ms != nullptr;
   res_timed = false;
@@ -5653,10 +5654,11 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
   if (tuning) graph_ok = false;
   bool replayed = false;
   loop_launches = 0;
-  if (nsub >= 2 && (can_reside() || can_reside_peer())) {
+  if (try_resident) {
     replayed = run_resident(ksub0, nsub);
     if (replayed) loop_launches = 1;
     else res_timed = false;
+    if (!replayed && elapsed_ms) CICE_HIP(hipEventRecord(e0, stream));   // (the loop gave up: the other loops run the range)
   }
   res_time_it = false;
   if (!replayed && graph_ok) {
@@ -5714,12 +5716,14 @@ void Evp::subcycles(int ksub0, int nsub, float* elapsed_ms) {
     }
   }
   if (elapsed_ms) {
-    CICE_HIP(hipEventRecord(e1, stream));
-    CICE_HIP(hipEventSynchronize(e1));
-    if (res_timed) CICE_HIP(hipEventElapsedTime(elapsed_ms, res_t0, res_t1));
-    else CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (res_timed) {
+      CICE_HIP(hipEventSynchronize(res_t1));
+      CICE_HIP(hipEventElapsedTime(elapsed_ms, res_t0, res_t1));
+    } else {
+      CICE_HIP(hipEventRecord(e1, stream));
+      CICE_HIP(hipEventSynchronize(e1));
+      CICE_HIP(hipEventElapsedTime(elapsed_ms, e0, e1));
+    }
   }
 }
 
