@@ -1,5 +1,6 @@
 """Soak of the one-launch loop with a tripole fold inside: REPS whole evp(dt) calls from one state on a gx1-size grid, each
-the bits of the per-subcycle path (launch per subcycle + halo update with the fold).  usage: python scripts/soak_fold.py [reps]"""
+the bits of the per-subcycle path (launch per subcycle + halo update with the fold).
+usage: python scripts/soak_fold.py [reps] [boundaries, default tripole,tripoleT; "open" = no fold: the plain granule loop]"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,10 +10,12 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 nxg, nyg, NDTE, DT = 320, 384, 120, 3600.0
 KEYS = ("uvel", "vvel") + synth.SIG_NAMES
 t0 = time.time()
-for name, ns in (("tripole", 3), ("tripoleT", 4)):
+CODES = {"open": 0, "tripole": 3, "tripoleT": 4}
+for name, ns in [(x, CODES[x]) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("tripole", "tripoleT"))]:
     ctx = lib.Context()
     dom = ctx.domain_create(nxg, nyg, nxg, nyg, ew=1, ns=ns)
-    grid = synth.block_fields(synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8, land_rows=0), dom, ew_cyclic=True, north_ocean=(ns != 0))
+    gg = synth.global_grid(nxg, nyg, perturb=0.15, land_frac=0.03, seed=8, **({"land_rows": 0} if ns else {}))
+    grid = synth.block_fields(gg, dom, ew_cyclic=True, north_ocean=True) if ns else synth.block_fields(gg, dom)
     s = synth.evp_state(grid, dom, seed=8, cover="patchy")
     ctx.evp_init(grid, ndte=NDTE, krdg_partic=0, krdg_redist=0)
     ctx.evp_set_option("resident", 0)
@@ -32,5 +35,5 @@ for name, ns in (("tripole", 3), ("tripoleT", 4)):
         assert ctx.evp_get_info("resident") == 1, "fell back at rep %d" % rep
         ctx.evp_upload({k: v.copy() for k, v in s.items()})
     ctx.close()
-print("SOAK-OK fold inside the loop: %d evp(dt) calls of %d subcycles with each fold on %d x %d, every one the bits of the per-subcycle path, %.0f s"
+print("SOAK-OK one-launch loop: %d evp(dt) calls of %d subcycles with each boundary on %d x %d, every one the bits of the per-subcycle path, %.0f s"
       % (reps, NDTE, nxg, nyg, time.time() - t0))
