@@ -188,7 +188,8 @@ int cice_evp_pin_fields(cice_ctx *ctx, const cice_evp_fields *f);
 /* Drop-in for `call evp(dt)` (ice_dyn_evp.F90:119-432): upload, run on the GPU,
  * download.  Same results as cice_evp_upload + cice_evp_step + cice_evp_download, as one pipeline: the six fields the
  * preparation leaves final (strairx, strairy, strength, fm, strtltx, strtlty) and iceumask travel to the host while the
- * subcycle loop runs.
+ * subcycle loop runs (on a domain of several ranks they follow the loop with the rest: ranks that share one device in the
+ * rehearsals need their hardware queues for the loops that wait for each other).
  * Two statements a caller may make about itself (cice_evp_set_option; both off by default, both hold for the reference's
  * unchanged driver):
  *   "keep_state" = 1: between two cice_evp calls the caller does not change uvel, vvel, the 12 stresses or iceumask on
