@@ -4184,6 +4184,54 @@ void Evp::balance_after_sweep(hipStream_t s) {
       }
       changed = true;
     }
+    // WHICH place a tile takes.  A strip's time is its cost over the sum of its places' weights, and the strips that kept
+    // one tile less (0.1 degree: 12 of 65) have 218-row segments where the others have 200: they get the places that are
+    // dispatched first on their CUs (+15 %), the others more of the late ones.  Tiles change places only INSIDE an XCD's part
+    // of the list (tiles of neighbouring strips over the same rows stay on one L2), heaviest place to the tile whose strip
+    // is shortest of weight per unit of cost.  The re-cuts that follow work with the weights of the new places.
+    static const bool place_env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_PLACES"); return !(e && e[0] == '0'); }();
+    if (place_env && (int)bal_tiles.size() > ns) {
+      const int n2 = (int)bal_tiles.size(), chunk2 = (n2 + 7) >> 3;
+      std::vector<double> pw((size_t)n2);
+      for (int q = 0; q < n2; ++q) pw[(size_t)q] = place_weight(q, n2, bal_gens, bal_per_xcd, skew_fill_on());
+      std::vector<double> got(ns, 0.0), wstar(ns, 0.0);
+      std::vector<int> cnt(ns, 0), placed(ns, 0);
+      for (const BalTile& bt : bal_tiles) ++cnt[bt.strip];
+      double csum = 0, wtot = 0, cmean = 0;
+      int nc2 = 0;
+      for (int sx = 0; sx < ns; ++sx)
+        if (strip_cost[sx] > 0) { cmean += strip_cost[sx]; ++nc2; }
+      cmean = nc2 ? cmean / nc2 : 1.0;
+      for (int sx = 0; sx < ns; ++sx)
+        if (cnt[sx]) csum += strip_cost[sx] > 0 ? strip_cost[sx] : cmean;
+      for (double v : pw) wtot += v;
+      for (int sx = 0; sx < ns; ++sx)          // the weight that would make every strip take the same time
+        if (cnt[sx]) wstar[sx] = (strip_cost[sx] > 0 ? strip_cost[sx] : cmean) / csum * wtot;
+      for (int c0 = 0; c0 < n2; c0 += chunk2) {
+        const int c1 = std::min(n2, c0 + chunk2);
+        std::vector<int> places;
+        const std::vector<BalTile> tiles(bal_tiles.begin() + c0, bal_tiles.begin() + c1);
+        for (int q = c0; q < c1; ++q) places.push_back(q);
+        std::stable_sort(places.begin(), places.end(), [&](int a, int b) { return pw[(size_t)a] > pw[(size_t)b]; });
+        std::vector<char> used(tiles.size(), 0);
+        for (int q : places) {                 // heaviest place first, to the tile whose strip lacks most per tile still to place
+          int best = -1;
+          double need = -1e300;
+          for (size_t i = 0; i < tiles.size(); ++i) {
+            if (used[i]) continue;
+            const int sx = tiles[i].strip;
+            const double lack = (wstar[sx] - got[sx]) / std::max(1, cnt[sx] - placed[sx]);
+            if (lack > need) { need = lack; best = (int)i; }
+          }
+          if (best < 0) break;
+          used[(size_t)best] = 1;
+          bal_tiles[(size_t)q] = tiles[(size_t)best];
+          got[tiles[(size_t)best].strip] += pw[(size_t)q];
+          ++placed[tiles[(size_t)best].strip];
+        }
+      }
+      changed = true;
+    }
   }
   if (changed) bal_upload(s);
   ++bal_sweeps;
