@@ -136,6 +136,9 @@ class Evp {
   DevBuf<int32_t> bal_list;
   int bal_nt = 0, bal_strips = 0, bal_slots = 0, bal_gens = 1, bal_per_xcd = 32, bal_seen = 0, bal_k = 4;
   bool bal_recounted = false;
+  std::vector<double> bal_got;                      // weight of the places every strip's tiles hold (deal_places)
+  bool places_on() const;
+  void deal_places(const std::vector<double>& target);
   void bal_upload(hipStream_t s);
   double place_weight(int tile_lin, int nt, int gens, int per_xcd, bool fill) const;
   DevBuf<int32_t> res_map;        // k_res_choose_map: the tile map of the one-launch loop, chosen once per evp(dt)

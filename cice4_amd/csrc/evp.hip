@@ -3973,6 +3973,7 @@ void Evp::build_skew_rows(int K, int tiles_x, int tiles_y, int nblocks, int seg_
   // the same as a LIST of tiles (SkewArgs::tiles), which is what the measured balancing works on: a strip may then hold
   // more tiles than another
   bal_tiles.clear();
+  bal_got.clear();
   bal_nt = 0;
   if (balance_on() && nblocks == 1) {
     bal_strips = tiles_x;
@@ -4070,6 +4071,55 @@ double balance_strip(int rows, int n, const int* e, const double* d, const doubl
     prev = end;
   }
   return omega;
+}
+
+bool Evp::places_on() const {   // CICE4_AMD_SKEW_PLACES=0: off (A/B)
+  static const bool env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_PLACES"); return !(e && e[0] == '0'); }();
+  return env;
+}
+
+// The tiles of the list change places inside every XCD's part of it so that strip sx ends up with the share target[sx] /
+// sum(target) of all places' static weights (balance_after_sweep): heaviest place first, to the tile whose strip lacks most
+// weight per tile it has still to place.  bal_got <- the weight every strip got.  (Dealt ONCE per table: a second deal ten
+// sweeps later, from the times the strips were then measured to take, narrows the strips' means from 3.2 to 2.0 % and makes
+// the launch no shorter -- 255.4 against 254.6 us per subcycle, it disturbs the cuts inside the strips: profiles/r05_sweep_places_by_strip.txt)
+void Evp::deal_places(const std::vector<double>& target) {
+  const int ns = bal_strips, n2 = (int)bal_tiles.size(), chunk2 = (n2 + 7) >> 3;
+  std::vector<double> pw((size_t)n2), wstar(ns, 0.0);
+  for (int q = 0; q < n2; ++q) pw[(size_t)q] = place_weight(q, n2, bal_gens, bal_per_xcd, skew_fill_on());
+  std::vector<int> cnt(ns, 0), placed(ns, 0);
+  for (const BalTile& bt : bal_tiles) ++cnt[bt.strip];
+  double tsum = 0, wtot = 0;
+  for (int sx = 0; sx < ns; ++sx)
+    if (cnt[sx]) tsum += target[sx];
+  for (double v : pw) wtot += v;
+  if (!(tsum > 0)) return;
+  for (int sx = 0; sx < ns; ++sx)
+    if (cnt[sx]) wstar[sx] = target[sx] / tsum * wtot;
+  bal_got.assign(ns, 0.0);
+  for (int c0 = 0; c0 < n2; c0 += chunk2) {
+    const int c1 = std::min(n2, c0 + chunk2);
+    std::vector<int> places;
+    const std::vector<BalTile> tiles(bal_tiles.begin() + c0, bal_tiles.begin() + c1);
+    for (int q = c0; q < c1; ++q) places.push_back(q);
+    std::stable_sort(places.begin(), places.end(), [&](int a, int b) { return pw[(size_t)a] > pw[(size_t)b]; });
+    std::vector<char> used(tiles.size(), 0);
+    for (int q : places) {
+      int best = -1;
+      double need = -1e300;
+      for (size_t i = 0; i < tiles.size(); ++i) {
+        if (used[i]) continue;
+        const int sx = tiles[i].strip;
+        const double lack = (wstar[sx] - bal_got[sx]) / std::max(1, cnt[sx] - placed[sx]);
+        if (lack > need) { need = lack; best = (int)i; }
+      }
+      if (best < 0) break;
+      used[(size_t)best] = 1;
+      bal_tiles[(size_t)q] = tiles[(size_t)best];
+      bal_got[tiles[(size_t)best].strip] += pw[(size_t)q];
+      ++placed[tiles[(size_t)best].strip];
+    }
+  }
 }
 
 void Evp::balance_after_sweep(hipStream_t s) {
@@ -4189,47 +4239,15 @@ void Evp::balance_after_sweep(hipStream_t s) {
     // dispatched first on their CUs (+15 %), the others more of the late ones.  Tiles change places only INSIDE an XCD's part
     // of the list (tiles of neighbouring strips over the same rows stay on one L2), heaviest place to the tile whose strip
     // is shortest of weight per unit of cost.  The re-cuts that follow work with the weights of the new places.
-    static const bool place_env = [] { const char* e = std::getenv("CICE4_AMD_SKEW_PLACES"); return !(e && e[0] == '0'); }();
-    if (place_env && (int)bal_tiles.size() > ns) {
-      const int n2 = (int)bal_tiles.size(), chunk2 = (n2 + 7) >> 3;
-      std::vector<double> pw((size_t)n2);
-      for (int q = 0; q < n2; ++q) pw[(size_t)q] = place_weight(q, n2, bal_gens, bal_per_xcd, skew_fill_on());
-      std::vector<double> got(ns, 0.0), wstar(ns, 0.0);
-      std::vector<int> cnt(ns, 0), placed(ns, 0);
-      for (const BalTile& bt : bal_tiles) ++cnt[bt.strip];
-      double csum = 0, wtot = 0, cmean = 0;
+    if (places_on() && (int)bal_tiles.size() > ns) {
+      std::vector<double> target(ns, 0.0);
+      double cmean = 0;
       int nc2 = 0;
       for (int sx = 0; sx < ns; ++sx)
         if (strip_cost[sx] > 0) { cmean += strip_cost[sx]; ++nc2; }
       cmean = nc2 ? cmean / nc2 : 1.0;
-      for (int sx = 0; sx < ns; ++sx)
-        if (cnt[sx]) csum += strip_cost[sx] > 0 ? strip_cost[sx] : cmean;
-      for (double v : pw) wtot += v;
-      for (int sx = 0; sx < ns; ++sx)          // the weight that would make every strip take the same time
-        if (cnt[sx]) wstar[sx] = (strip_cost[sx] > 0 ? strip_cost[sx] : cmean) / csum * wtot;
-      for (int c0 = 0; c0 < n2; c0 += chunk2) {
-        const int c1 = std::min(n2, c0 + chunk2);
-        std::vector<int> places;
-        const std::vector<BalTile> tiles(bal_tiles.begin() + c0, bal_tiles.begin() + c1);
-        for (int q = c0; q < c1; ++q) places.push_back(q);
-        std::stable_sort(places.begin(), places.end(), [&](int a, int b) { return pw[(size_t)a] > pw[(size_t)b]; });
-        std::vector<char> used(tiles.size(), 0);
-        for (int q : places) {                 // heaviest place first, to the tile whose strip lacks most per tile still to place
-          int best = -1;
-          double need = -1e300;
-          for (size_t i = 0; i < tiles.size(); ++i) {
-            if (used[i]) continue;
-            const int sx = tiles[i].strip;
-            const double lack = (wstar[sx] - got[sx]) / std::max(1, cnt[sx] - placed[sx]);
-            if (lack > need) { need = lack; best = (int)i; }
-          }
-          if (best < 0) break;
-          used[(size_t)best] = 1;
-          bal_tiles[(size_t)q] = tiles[(size_t)best];
-          got[tiles[(size_t)best].strip] += pw[(size_t)q];
-          ++placed[tiles[(size_t)best].strip];
-        }
-      }
+      for (int sx = 0; sx < ns; ++sx) target[sx] = strip_cost[sx] > 0 ? strip_cost[sx] : cmean;
+      deal_places(target);
       changed = true;
     }
   }
