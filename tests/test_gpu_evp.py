@@ -1422,15 +1422,16 @@ def test_page_locked_host_arrays_give_the_same_result(orc):
 FLUX7 = ("fm", "strtltx", "strtlty", "strocnx", "strocny", "strintx", "strinty")
 
 
-@pytest.mark.parametrize("keep,lazy,pinned", [(1, 0, False), (2, 0, True), (2, 1, True), (1, 1, False)])
-def test_evp_over_pcie_leaves_on_the_device_what_the_caller_does_not_touch(keep, lazy, pinned):
+@pytest.mark.parametrize("keep,lazy,pinned,blocks", [(1, 0, False, 1), (2, 0, True, 1), (2, 1, True, 1), (1, 1, False, 1), (2, 1, True, 4)])
+def test_evp_over_pcie_leaves_on_the_device_what_the_caller_does_not_touch(keep, lazy, pinned, blocks):
     """cice_evp with the caller's two statements (include/cice4_amd.h: "keep_state", "lazy_stresses") against plain cice_evp,
     five steps of a driver that does what the reference's does between two evp calls: new forcing and state every step,
     the dynamic history fields zeroed (init_history_dyn, /root/reference/source/ice_flux.F90:585-602).  Bit for bit the same
     fields on the host after every step.  That the planes really stay where they are: the kept host arrays are filled with
     NaN behind the library's back (a caller that breaks its statement) and nothing changes."""
     c = lib.Context(); c.sync()
-    dom = c.domain_create(100, 116, 100, 116, ew=1, ns=0)
+    dom = c.domain_create(100, 116, 100 if blocks == 1 else 50, 116 if blocks == 1 else 58, ew=1, ns=0)   # (blocks = 4: 2 x 2 blocks on the one rank)
+    assert dom["nblocks"] == blocks
     grid = synth.block_fields(synth.global_grid(100, 116, perturb=0.1, land_frac=0.05, seed=5), dom)
     s0 = synth.evp_state(grid, dom, seed=5, cover="patchy", moving=False)
     rng = np.random.default_rng(11)
