@@ -118,7 +118,7 @@ class Evp {
   bool skew_on = true;       // K subcycles per sweep where the domain allows and the grid is large enough
   int skew_blocks_opt = 0;
   bool fwd_is_ew_wrap = false;   // the on-rank ghost list is the east-west wrap of full-width blocks and nothing else
-  int skew_gen_pct = 15;         // see build_skew_rows
+  int skew_gen_pct = 10;         // see build_skew_rows (15 until the tiles of a strip were dealt their places by weight: profiles/r05_sweep_places_by_strip.txt)
   int skew_fill = 26;            // see build_skew_rows: longer segments for workgroups on CUs that hold fewer of them
   DevBuf<int32_t> skew_rows;
   int skew_rows_key[6] = {0, 0, 0, 0, 0, 0};

@@ -250,7 +250,7 @@ int cice_evp_finish(cice_ctx *ctx);
  * "resident_granules" (one-launch loop on one rank: 0 progress words, 1 data-tagged granules in a free-running loop unless the
  * last step's ice cover left most tiles empty, 2 always),
  * "skew_fill" / "skew_gen_pct" (per cent: static weights of a workgroup's place -- more rows on a CU that holds fewer
- * workgroups, more for the workgroup dispatched first; defaults 26 / 15), "skew_split" (wide-halo slabs: the refresh beside
+ * workgroups, more for the workgroup dispatched first; defaults 26 / 10), "skew_split" (wide-halo slabs: the refresh beside
  * the interior sweep), "skew_subs" (1; 3 wavefronts per level in -DCICE4_AMD_EXPERIMENTS builds).  DESIGN.md sections 3.1, 3.2, 7.
  * Results never depend on them; cice_evp_init picks waves / rows_per_wave from the grid size.
  * cice_evp_get_info keys: "derive_metrics" (1 if active), "waves", "rows_per_wave", "fused"

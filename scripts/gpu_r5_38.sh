@@ -4,7 +4,7 @@ set -o pipefail
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 : > gpurun_out/r5_38.txt
-for rep in 1 2; do for pct in 15 10 20 25; do
+for rep in 1 2 3; do for pct in 15 12 10 8; do
 timeout -k 10 300 python bench.py --workload tenth --no-thermo --no-cpu-baseline --no-dropin-timing --skew-gen-pct $pct > gpurun_out/r5_38.json 2>gpurun_out/r5_38.err || { tail -20 gpurun_out/r5_38.err; exit 1; }
 python -c "
 import json
