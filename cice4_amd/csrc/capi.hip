@@ -147,6 +147,14 @@ struct cice_ctx {
     if (device >= 0) CICE_HIP(hipSetDevice(device));
     else CICE_HIP(hipGetDevice(&device));
     CICE_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    // one operation at once: the runtime binds a stream to a hardware queue when it first has work, and contexts that share a
+    // device (ranks of a rehearsal on one GPU, whose one-launch loops wait for each other) need their MAIN streams on queues
+    // of their own -- created, and bound, one after the other (tests/ranks_case.py)
+    void* p = nullptr;
+    CICE_HIP(hipMalloc(&p, 64));
+    CICE_HIP(hipMemsetAsync(p, 0, 64, stream));
+    CICE_HIP(hipStreamSynchronize(stream));
+    CICE_HIP(hipFree(p));
   }
   void need_halo() {
     need_device();

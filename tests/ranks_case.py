@@ -41,6 +41,10 @@ def run_ranks(gg, R, mode, ndte, dt, ns=0, seed=31, cover="patchy", overlap=0, s
     def rank_fn(r):
         try:
             c = lib.Context(device=0); c.sync()
+            # every rank's MAIN stream first, one after the other: the runtime deals its streams to the hardware queues in
+            # the order they are created, and two loops that wait for each other must not share a queue (a copy stream that
+            # another rank creates in between would shift the count)
+            bar.wait(timeout=120)
             if mode == "slabs":
                 dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=overlap)
             elif block_map is not None:

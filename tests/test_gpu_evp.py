@@ -562,6 +562,7 @@ def test_ranks_in_one_process(orc, mode, R, nyg):
     def rank_fn(r):
         try:
             c = lib.Context(device=0); c.sync()
+            bar.wait(timeout=60)         # (every rank's main stream before anybody's copy streams: tests/ranks_case.py)
             if mode.startswith("slabs"):
                 H = int(mode[5])
                 dom = c.domain_create_slabs(nxg, nyg, R, ew=1, ns=0, rank=r, nranks=R, overlap=H)
@@ -734,6 +735,7 @@ def test_tripole_grid_cut_into_slabs(ctx, ns, mode, R, nyg):
     def rank_fn(r):
         try:
             c = lib.Context(device=0); c.sync()
+            bar.wait(timeout=120)        # (every rank's main stream before anybody's copy streams: tests/ranks_case.py)
             if mode == "peer":
                 dom = c.domain_create(nxg, nyg, nxg, nyg // R, ew=1, ns=ns, rank=r, npx=1, npy=R)
             else:
