@@ -49,3 +49,14 @@ def test_bench_finds_the_newest_passes_and_calls_them_fresh():
     ghz, _ = bench.inkernel_clock("gx1")
     assert t and sq and ghz and "r05_" in src and "r05_" in sq["source"]
     assert not bench.STALE, bench.STALE
+
+
+def test_archived_bench_line_is_of_these_kernel_sources():
+    """profiles/r05_bench_gx1.json -- the line DESIGN.md and README.md quote -- was printed by these kernels, with fresh counters"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_gx1.json")))
+    assert d["counters"]["kernel_source_sha"] == bench.kernel_source_sha(), "archive a new bench line (scripts/gpu_r5_32.sh)"
+    assert d["counters_stale"] is False and d["counters"]["stale_sources"] == []
+    assert d["metric"] == "EVP subcycles/sec" and d["n_gpus"] == 1 and d["config"]["nx_global"] == 320 and d["config"]["ndte"] == 120
+    for k in ("roofline", "cpu_baseline", "tenth", "thermo", "pcie_inclusive"):
+        assert k in d, k
